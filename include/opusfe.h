@@ -1,0 +1,135 @@
+/* opusfe — MI355X-native front end (lex -> parse -> IR) for the Opus language of ftxqxd/opus.
+ *
+ * C ABI of the drop-in boundary.  Everything here is plain C: pointers and sizes,
+ * no C++/torch types.  The library (libopusfe.so) is built by hipcc for gfx950; every compute entry
+ * point runs hand-written HIP kernels and FAILS (OPUSFE_ERR_HIP) when no GPU is present — there is
+ * no CPU fallback.
+ *
+ * Reference interfaces replaced (file:line relative to the reference repository):
+ *   opusfe_parse*      <- frontend.rs:120-138  get_definitions(compiler, source)
+ *                         = Parser::from_source (parse.rs:396) + is_at_end_of_file (parse.rs:411)
+ *                           + parse_definition (parse.rs:1262) + the four span tables
+ *                           (compile.rs:20-23)
+ *   opusfe_lower       <- frontend.rs:140-187  compile_source: finalize_definition for every
+ *                         definition (compile.rs:1002) then IrGenerator::from_function
+ *                         (generate_ir.rs:100) per Definition::Function
+ *   opusfe_dump(IR)    <- impl Display for IrGenerator (generate_ir.rs:1201-1283), the text that
+ *                         `opus -Z` prints (frontend.rs:167-169)
+ *   opusfe_error       <- parse::Error (parse.rs:352-360) as data instead of
+ *                         report_error + process::exit(1) (frontend.rs:130-133)
+ */
+#ifndef OPUSFE_H
+#define OPUSFE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct opusfe_ctx opusfe_ctx;
+typedef struct opusfe_unit opusfe_unit;
+
+/* return codes */
+enum {
+    OPUSFE_OK = 0,
+    OPUSFE_SYNTAX = 1,        /* first syntax error available through opusfe_get_error */
+    OPUSFE_UNSUPPORTED = 2,   /* input on which the reference hangs/panics or needs unpinned Unicode tables */
+    OPUSFE_ERR_HIP = 3,       /* HIP failure, including "no GPU" */
+    OPUSFE_ERR_OOM = 4,
+    OPUSFE_ERR_ARG = 5,
+    OPUSFE_ERR_INTERNAL = 6,  /* internal capacity / consistency check tripped (never silently wrong) */
+    OPUSFE_SEMANTIC = 7       /* opusfe_lower: finalize reported semantic errors, no IR (frontend.rs:145) */
+};
+
+/* ---- flat result records (device layout == host layout) ---- */
+
+/* parse.rs:5-67 Token, same variant order; 60 = lexical error token */
+typedef struct opusfe_token {
+    uint8_t kind;
+    uint8_t flags;      /* OPUSFE_TF_* */
+    uint16_t aux;       /* Integer: bit15 has-suffix, bit8 signed, bits0-7 size; Float: size (0,32,64); Error: parse::Error kind */
+    uint32_t low;       /* byte offset of the token start (parse.rs token_low) */
+    uint32_t len;       /* bytes up to where lexing resumes (real_position - token_low) */
+    uint32_t payload;   /* Integer: value if OPUSFE_TF_INLINE else index into val64 pool; Float: val64 index (f64 bits);
+                           String: byte offset into the string pool ([u32 n][n bytes] padded to 4);
+                           Identifier: FNV-1a hash of the name; Error: val64 index of {span, payload} */
+} opusfe_token;
+#define OPUSFE_TF_INLINE 1u   /* Integer value stored inline */
+#define OPUSFE_TF_RESYNC 2u   /* Error token after which the reference resumes inside a string body (Q7 note) */
+#define OPUSFE_TOK_ERROR 60
+
+typedef struct opusfe_node {
+    uint8_t kind;          /* OPUSFE_N_* */
+    uint8_t sub;           /* Operator: parse::Operator; Bool: value; For: has-type */
+    uint16_t nchild;
+    uint32_t first_child;  /* node index or 0xFFFFFFFF */
+    uint32_t next;         /* next sibling or 0xFFFFFFFF */
+    uint32_t payload;      /* token index (names, literals) */
+    uint32_t low, high;    /* byte span [low, high) as recorded by the reference's span tables */
+} opusfe_node;
+
+typedef struct opusfe_instr {
+    uint16_t opcode;       /* generate_ir.rs:8-56 Instruction, same variant order */
+    uint16_t sub;          /* Cast: CastType; Bool: value; Call: number of arguments */
+    uint32_t dst, a, b;    /* variable ids in declaration order; Jump/Branch/Phi: bb indices where the reference has them */
+    uint32_t c, extra;     /* Integer/Float: 64-bit immediate in (c, extra); Call: c = offset into the call-arg pool;
+                              String/Field: token index; Sizeof/Alignof: type id; Function: function id; globals: global id */
+} opusfe_instr;
+
+typedef struct opusfe_variable { uint32_t type_id; uint32_t is_temporary; } opusfe_variable;
+
+typedef struct opusfe_error {
+    uint32_t kind;         /* parse.rs:352-360 variant index */
+    uint32_t tok_kind;     /* found token kind (UnexpectedToken / ExpectedFoundToken / ExpectedIdentifier) */
+    uint64_t low;          /* span start */
+    uint32_t len;          /* span length */
+    uint32_t expected;     /* expected token kind (ExpectedFoundToken) */
+    uint64_t payload;      /* UnexpectedCharacter: char; InvalidNumericSize: size */
+    uint64_t line;         /* 1 + number of '\n' before low (frontend.rs:213-225) */
+    uint32_t tok_index;    /* index of the found token in the token stream */
+    uint32_t _pad;
+} opusfe_error;
+
+typedef struct opusfe_counts {
+    uint64_t source_bytes, tokens, nodes, definitions, functions, instrs, vars, bbs, types;
+} opusfe_counts;
+
+/* ---- context ---- */
+int opusfe_create(opusfe_ctx** out, int device);          /* one ctx per (thread, device); calls on one ctx are serialised */
+void opusfe_destroy(opusfe_ctx* ctx);
+const char* opusfe_last_message(opusfe_ctx* ctx);          /* human-readable detail of the last non-OK return */
+void* opusfe_stream(opusfe_ctx* ctx);                      /* the hipStream_t all kernels of this ctx are launched on */
+
+/* ---- seam A: source -> tokens + AST (frontend.rs:120 get_definitions) ---- */
+/* host buffer: copied to HBM first (PCIe-inclusive path) */
+int opusfe_parse(opusfe_ctx* ctx, const uint8_t* src, uint64_t len, opusfe_unit** out);
+/* source already resident in HBM on ctx's device (the timed path of bench.py) */
+int opusfe_parse_device(opusfe_ctx* ctx, const uint8_t* d_src, uint64_t len, opusfe_unit** out);
+/* only the lexer (token stream); `force_dents` != 0 lexes as if ignore_dents were always 0 (KAT-L mode) */
+int opusfe_lex_device(opusfe_ctx* ctx, const uint8_t* d_src, uint64_t len, int force_dents, opusfe_unit** out);
+int opusfe_lex(opusfe_ctx* ctx, const uint8_t* src, uint64_t len, int force_dents, opusfe_unit** out);
+
+/* ---- seam B: AST -> IR (frontend.rs:140 compile_source, IR part) ---- */
+int opusfe_lower(opusfe_ctx* ctx, opusfe_unit* unit);
+
+/* ---- results ---- */
+int opusfe_unit_status(const opusfe_unit* unit);           /* OPUSFE_OK / _SYNTAX / _UNSUPPORTED ... of the unit */
+int opusfe_get_counts(const opusfe_unit* unit, opusfe_counts* out);
+int opusfe_get_error(const opusfe_unit* unit, opusfe_error* out);
+/* copies device result arrays to caller-provided host buffers (cap in elements); returns element count via *n */
+int opusfe_copy_tokens(opusfe_unit* unit, opusfe_token* dst, uint64_t cap, uint64_t* n);
+/* canonical text dumps (formats: SURVEY.md §8c).  what: 0 tokens, 1 AST, 2 IR, 3 first-error line.
+   *out is malloc'ed by the library; release with opusfe_free_text. */
+int opusfe_dump(opusfe_unit* unit, int what, char** out, uint64_t* out_len);
+void opusfe_free_text(char* p);
+void opusfe_free_unit(opusfe_unit* unit);
+
+/* ---- measurement hooks (bench.py): HIP-event timing of each kernel of the last call on ctx ---- */
+int opusfe_set_profiling(opusfe_ctx* ctx, int enabled);
+int opusfe_kernel_count(opusfe_ctx* ctx);
+int opusfe_kernel_info(opusfe_ctx* ctx, int index, const char** name, double* ms, uint64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

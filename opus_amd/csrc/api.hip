@@ -1,0 +1,343 @@
+// libopusfe: C ABI entry points (include/opusfe.h) and host drivers of the HIP pipeline.
+#include <hip/hip_runtime.h>
+#include "defs.h"
+#include "runtime.h"
+#include "unit.h"
+#include "scan.h"
+#include "lex.h"
+#include "parse.h"
+#include "lower.h"
+#include "dump.h"
+#include "dump_ast.h"
+#include "dump_ir.h"
+
+using namespace opusfe;
+
+namespace {
+
+// status / totals block layout (uint32 words) inside ctx->d_status
+enum { W_STATUS = 0, W_LEXTOT = 4 /* Cnt3: 4 words */, W_FINTOK = 8, W_NSEG = 9, W_PARSE = 16, W_LOWER = 32 };
+
+int fail(opusfe_ctx* ctx, int code, const std::string& msg) { if (ctx) ctx->msg = msg; return code; }
+
+void sync_stream(opusfe_ctx* ctx) { HIP_TRY(hipStreamSynchronize(ctx->stream)); prof_collect(ctx); }
+
+void fetch_status(opusfe_ctx* ctx) {
+    HIP_TRY(hipMemcpyAsync(ctx->h_status, ctx->d_status, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    sync_stream(ctx);
+}
+
+int status_to_code(uint32_t ds) {
+    if (ds == DS_OK) return OPUSFE_OK;
+    if (ds >= DS_INTERNAL_CAPACITY) return OPUSFE_ERR_INTERNAL;
+    return OPUSFE_UNSUPPORTED;
+}
+const char* status_text(uint32_t ds) {
+    switch (ds) {
+        case DS_UNSUPPORTED_NONASCII: return "non-ASCII character outside string/comment (Unicode tables unpinned)";
+        case DS_UNSUPPORTED_FLOAT: return "float literal outside the exact fast path (more than 15 significant digits)";
+        case DS_UNSUPPORTED_HANG: return "float literal followed by 'f' at end of file (the reference never terminates)";
+        case DS_UNSUPPORTED_RESYNC: return "swallowed lexical error after which the reference re-lexes a string body as code";
+        case DS_UNSUPPORTED_SEMANTIC: return "construct on which the reference panics (unreachable!/unwrap)";
+        case DS_INTERNAL_CAPACITY: return "internal capacity exceeded";
+        case DS_INTERNAL_SEGMENT: return "internal segment consistency check failed";
+        default: return "";
+    }
+}
+
+// ---- lexer driver ---------------------------------------------------------------------------
+void run_lexer(opusfe_ctx* ctx, opusfe_unit* u, int force_dents) {
+    const uint8_t* src = u->d_src;
+    const uint32_t n = (uint32_t)u->len;
+    hipStream_t st = ctx->stream;
+    TempList tmp(ctx);
+    HIP_TRY(hipMemsetAsync(ctx->d_status, 0, 64 * sizeof(uint32_t), st));
+    uint32_t* status = ctx->d_status + W_STATUS;
+
+    const uint64_t nchunks = ((uint64_t)n + LEX_CHUNK - 1) / LEX_CHUNK;
+    const uint64_t ntiles = (nchunks + LEX_THREADS - 1) / LEX_THREADS;
+    uint32_t T = 0, nval = 0, nstr = 0;
+    opusfe_token* raw = nullptr;
+    if (ntiles > 0) {
+        uint32_t* chunk_fn = tmp.get<uint32_t>(nchunks);
+        uint32_t* tile_fn = tmp.get<uint32_t>(ntiles);
+        uint8_t* tile_state = tmp.get<uint8_t>(ntiles);
+        uint8_t* chunk_state = tmp.get<uint8_t>(nchunks);
+        uint32_t* chunk_cnt = tmp.get<uint32_t>(nchunks);
+        uint32_t* chunk_str = tmp.get<uint32_t>(nchunks);
+        Cnt3* tile_cnt = tmp.get<Cnt3>(ntiles);
+        Cnt3* scan_tmp = tmp.get<Cnt3>((ntiles + SCAN_TILE - 1) / SCAN_TILE + 1);
+        LAUNCH(ctx, "lex_ctx_chunk", k_ctx_chunk, ntiles, LEX_THREADS, src, n, chunk_fn, tile_fn);
+        LAUNCH(ctx, "lex_ctx_tiles", k_ctx_tiles, 1, SCAN_THREADS, tile_fn, tile_state, (uint32_t)ntiles);
+        LAUNCH(ctx, "lex_count", k_lex_count, ntiles, LEX_THREADS, src, n, chunk_fn, tile_state, chunk_state, chunk_cnt, chunk_str, tile_cnt, status);
+        prof_begin(ctx, "scan_cnt3");
+        device_scan<true>(tile_cnt, tile_cnt, ntiles, OpAddCnt3(), Cnt3{0, 0, 0, 0}, scan_tmp, (Cnt3*)(ctx->d_status + W_LEXTOT), st);
+        prof_end(ctx);
+        fetch_status(ctx);
+        T = ctx->h_status[W_LEXTOT]; nval = ctx->h_status[W_LEXTOT + 1]; nstr = ctx->h_status[W_LEXTOT + 2];
+        raw = tmp.get<opusfe_token>(T);
+        u->d_val64 = dev_alloc_t<uint64_t>(ctx, nval);
+        u->d_strpool = dev_alloc_t<uint8_t>(ctx, nstr);
+        u->n_val64 = nval; u->n_strpool = nstr;
+        LAUNCH(ctx, "lex_emit", k_lex_emit, ntiles, LEX_THREADS, src, n, chunk_state, chunk_cnt, chunk_str, tile_cnt, raw, u->d_val64, u->d_strpool, status);
+    }
+    // token-level passes over T raw tokens and T + 1 gaps
+    const uint64_t G = (uint64_t)T + 1;
+    int32_t* depth = tmp.get<int32_t>(G);
+    uint32_t* gapval = tmp.get<uint32_t>(G);
+    uint32_t* prev = tmp.get<uint32_t>(G);
+    uint32_t* cnt = tmp.get<uint32_t>(G);
+    uint32_t* out_off = tmp.get<uint32_t>(G);
+    uint32_t* seg_flag = tmp.get<uint32_t>(G);
+    uint32_t* seg_excl = tmp.get<uint32_t>(G);
+    uint32_t* scan_tmp32 = tmp.get<uint32_t>((G + SCAN_TILE - 1) / SCAN_TILE + 1);
+    if (T > 0) {
+        LAUNCH(ctx, "tok_delta", k_tok_delta, grid_for(T, 256), 256, raw, T, depth, force_dents);
+        prof_begin(ctx, "scan_depth");
+        device_scan<false>(depth, depth, T, OpAddI32(), (int32_t)0, (int32_t*)scan_tmp32, (int32_t*)nullptr, st);
+        prof_end(ctx);
+    }
+    LAUNCH(ctx, "tok_gap", k_gap, grid_for(G, 256), 256, src, n, raw, T, depth, gapval);
+    prof_begin(ctx, "scan_indent");
+    device_scan<true>(gapval, prev, G, OpLast(), (uint32_t)0, scan_tmp32, (uint32_t*)nullptr, st);
+    prof_end(ctx);
+    LAUNCH(ctx, "tok_dent_count", k_dent_count, grid_for(G, 256), 256, gapval, prev, T, cnt);
+    prof_begin(ctx, "scan_tokoff");
+    device_scan<true>(cnt, out_off, G, OpAddU32(), (uint32_t)0, scan_tmp32, ctx->d_status + W_FINTOK, st);
+    prof_end(ctx);
+    fetch_status(ctx);
+    const uint32_t total = ctx->h_status[W_FINTOK];
+    u->d_tokens = dev_alloc_t<opusfe_token>(ctx, total);
+    u->n_tokens = total;
+    LAUNCH(ctx, "tok_final", k_final, grid_for(G, 256), 256, raw, T, n, gapval, prev, out_off, u->d_tokens, seg_flag);
+    if (T > 0) {
+        prof_begin(ctx, "scan_seg");
+        device_scan<true>(seg_flag, seg_excl, T, OpAddU32(), (uint32_t)0, scan_tmp32, ctx->d_status + W_NSEG, st);
+        prof_end(ctx);
+        u->d_seg_start = dev_alloc_t<uint32_t>(ctx, (uint64_t)T + 1);
+        LAUNCH(ctx, "tok_seg_starts", k_seg_starts, grid_for(T, 256), 256, seg_flag, seg_excl, out_off, cnt, T, u->d_seg_start);
+    }
+    fetch_status(ctx);
+    u->n_segs = T > 0 ? ctx->h_status[W_NSEG] : 0;
+    u->dev_status = ctx->h_status[W_STATUS];
+    u->status = status_to_code(u->dev_status);
+    if (u->status != OPUSFE_OK) ctx->msg = status_text(u->dev_status);
+}
+
+void ensure_host_lex(opusfe_unit* u) {
+    if (u->have_h_lex) return;
+    opusfe_ctx* ctx = u->ctx;
+    u->h_tokens.resize(u->n_tokens); u->h_val64.resize(u->n_val64); u->h_strpool.resize(u->n_strpool);
+    if (u->n_tokens) HIP_TRY(hipMemcpyAsync(u->h_tokens.data(), u->d_tokens, u->n_tokens * sizeof(opusfe_token), hipMemcpyDeviceToHost, ctx->stream));
+    if (u->n_val64) HIP_TRY(hipMemcpyAsync(u->h_val64.data(), u->d_val64, u->n_val64 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (u->n_strpool) HIP_TRY(hipMemcpyAsync(u->h_strpool.data(), u->d_strpool, u->n_strpool, hipMemcpyDeviceToHost, ctx->stream));
+    if (!u->have_h_src) {
+        u->h_src.resize(u->len);
+        if (u->len) HIP_TRY(hipMemcpyAsync(u->h_src.data(), u->d_src, u->len, hipMemcpyDeviceToHost, ctx->stream));
+        u->have_h_src = true;
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    u->have_h_lex = true;
+}
+
+opusfe_unit* new_unit(opusfe_ctx* ctx, const uint8_t* d_src, uint64_t len, bool own) {
+    opusfe_unit* u = new opusfe_unit();
+    u->ctx = ctx; u->d_src = d_src; u->len = len; u->own_src = own;
+    return u;
+}
+
+template <class F>
+int guarded(opusfe_ctx* ctx, F&& f) {
+    if (!ctx) return OPUSFE_ERR_ARG;
+    try {
+        HIP_TRY(hipSetDevice(ctx->device));
+        return f();
+    } catch (HipError& e) {
+        ctx->pending.clear();
+        return fail(ctx, e.e == hipErrorOutOfMemory ? OPUSFE_ERR_OOM : OPUSFE_ERR_HIP, std::string("HIP error: ") + hipGetErrorString(e.e) + " in " + e.what);
+    } catch (std::bad_alloc&) {
+        return fail(ctx, OPUSFE_ERR_OOM, "host allocation failed");
+    }
+}
+
+constexpr uint64_t MAX_LEN = 0xFFFF0000ull;   // positions are u32 per unit (SURVEY §7 hard part 6: larger inputs are sharded)
+
+}  // namespace
+
+extern "C" {
+
+int opusfe_create(opusfe_ctx** out, int device) {
+    if (!out) return OPUSFE_ERR_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return OPUSFE_ERR_HIP;   // no GPU: fail loudly, no CPU path
+    if (device < 0 || device >= count) return OPUSFE_ERR_ARG;
+    opusfe_ctx* ctx = new opusfe_ctx();
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess
+        || hipMalloc((void**)&ctx->d_status, 64 * sizeof(uint32_t)) != hipSuccess
+        || hipHostMalloc((void**)&ctx->h_status, 64 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
+        delete ctx;
+        return OPUSFE_ERR_HIP;
+    }
+    *out = ctx;
+    return OPUSFE_OK;
+}
+
+void opusfe_destroy(opusfe_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->free_blocks) (void)hipFree(kv.second);
+    for (auto& kv : ctx->live_blocks) (void)hipFree(kv.first);
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    (void)hipFree(ctx->d_status);
+    (void)hipHostFree(ctx->h_status);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* opusfe_last_message(opusfe_ctx* ctx) { return ctx ? ctx->msg.c_str() : ""; }
+void* opusfe_stream(opusfe_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int opusfe_lex_device(opusfe_ctx* ctx, const uint8_t* d_src, uint64_t len, int force_dents, opusfe_unit** out) {
+    if (!out || (len && !d_src)) return OPUSFE_ERR_ARG;
+    *out = nullptr;
+    if (len > MAX_LEN) return fail(ctx, OPUSFE_ERR_ARG, "unit larger than 4 GiB: shard it (opusfe positions are 32-bit per unit)");
+    return guarded(ctx, [&] {
+        opusfe_unit* u = new_unit(ctx, d_src, len, false);
+        *out = u;
+        run_lexer(ctx, u, force_dents);
+        return u->status;
+    });
+}
+
+static int with_host_source(opusfe_ctx* ctx, const uint8_t* src, uint64_t len, opusfe_unit** out, int (*body)(opusfe_ctx*, opusfe_unit*, int), int arg) {
+    if (!out || (len && !src)) return OPUSFE_ERR_ARG;
+    *out = nullptr;
+    if (len > MAX_LEN) return fail(ctx, OPUSFE_ERR_ARG, "unit larger than 4 GiB: shard it (opusfe positions are 32-bit per unit)");
+    return guarded(ctx, [&] {
+        uint8_t* d = dev_alloc_t<uint8_t>(ctx, len + 16);
+        if (len) HIP_TRY(hipMemcpyAsync(d, src, len, hipMemcpyHostToDevice, ctx->stream));
+        opusfe_unit* u = new_unit(ctx, d, len, true);
+        u->h_src.assign(src, src + len); u->have_h_src = true;
+        *out = u;
+        return body(ctx, u, arg);
+    });
+}
+
+static int body_lex(opusfe_ctx* ctx, opusfe_unit* u, int force_dents) { run_lexer(ctx, u, force_dents); return u->status; }
+static int body_parse(opusfe_ctx* ctx, opusfe_unit* u, int) {
+    run_lexer(ctx, u, 0);
+    if (u->status != OPUSFE_OK) return u->status;
+    run_parser(ctx, u);
+    return u->status;
+}
+
+int opusfe_lex(opusfe_ctx* ctx, const uint8_t* src, uint64_t len, int force_dents, opusfe_unit** out) {
+    return with_host_source(ctx, src, len, out, body_lex, force_dents);
+}
+int opusfe_parse(opusfe_ctx* ctx, const uint8_t* src, uint64_t len, opusfe_unit** out) {
+    return with_host_source(ctx, src, len, out, body_parse, 0);
+}
+int opusfe_parse_device(opusfe_ctx* ctx, const uint8_t* d_src, uint64_t len, opusfe_unit** out) {
+    if (!out || (len && !d_src)) return OPUSFE_ERR_ARG;
+    *out = nullptr;
+    if (len > MAX_LEN) return fail(ctx, OPUSFE_ERR_ARG, "unit larger than 4 GiB: shard it (opusfe positions are 32-bit per unit)");
+    return guarded(ctx, [&] {
+        opusfe_unit* u = new_unit(ctx, d_src, len, false);
+        *out = u;
+        return body_parse(ctx, u, 0);
+    });
+}
+
+int opusfe_lower(opusfe_ctx* ctx, opusfe_unit* unit) {
+    if (!unit || unit->ctx != ctx) return OPUSFE_ERR_ARG;
+    if (!unit->parsed || unit->status != OPUSFE_OK) return fail(ctx, OPUSFE_ERR_ARG, "opusfe_lower needs a successfully parsed unit");
+    return guarded(ctx, [&] { run_lower(ctx, unit); return unit->status; });
+}
+
+int opusfe_unit_status(const opusfe_unit* unit) { return unit ? unit->status : OPUSFE_ERR_ARG; }
+
+int opusfe_get_counts(const opusfe_unit* u, opusfe_counts* out) {
+    if (!u || !out) return OPUSFE_ERR_ARG;
+    out->source_bytes = u->len; out->tokens = u->n_tokens; out->nodes = u->n_nodes; out->definitions = u->n_defs;
+    out->functions = u->n_funcs; out->instrs = u->n_instrs; out->vars = u->n_vars; out->bbs = u->n_bbs; out->types = u->n_types;
+    return OPUSFE_OK;
+}
+
+int opusfe_get_error(const opusfe_unit* u, opusfe_error* out) {
+    if (!u || !out) return OPUSFE_ERR_ARG;
+    if (!u->has_error) return OPUSFE_ERR_ARG;
+    *out = u->error;
+    return OPUSFE_OK;
+}
+
+int opusfe_copy_tokens(opusfe_unit* u, opusfe_token* dst, uint64_t cap, uint64_t* n) {
+    if (!u || !n) return OPUSFE_ERR_ARG;
+    *n = u->n_tokens;
+    if (!dst) return OPUSFE_OK;
+    if (cap < u->n_tokens) return OPUSFE_ERR_ARG;
+    return guarded(u->ctx, [&] {
+        if (u->n_tokens) HIP_TRY(hipMemcpy(dst, u->d_tokens, u->n_tokens * sizeof(opusfe_token), hipMemcpyDeviceToHost));
+        return (int)OPUSFE_OK;
+    });
+}
+
+int opusfe_dump(opusfe_unit* u, int what, char** out, uint64_t* out_len) {
+    if (!u || !out) return OPUSFE_ERR_ARG;
+    *out = nullptr;
+    return guarded(u->ctx, [&] {
+        std::string s;
+        ensure_host_lex(u);
+        switch (what) {
+            case 0: {
+                // after a syntax error only the tokens the reference had lexed are meaningful
+                uint64_t limit = u->has_error ? (uint64_t)u->error.tok_index + 1 : ~0ull;
+                s = dump_tokens(u, limit);
+                break;
+            }
+            case 1: ensure_host_ast(u); s = dump_ast(u); break;
+            case 2: s = dump_ir(u); break;
+            case 3: s = dump_error_line(u); break;
+            default: return (int)OPUSFE_ERR_ARG;
+        }
+        char* p = (char*)malloc(s.size() + 1);
+        if (!p) return (int)OPUSFE_ERR_OOM;
+        memcpy(p, s.data(), s.size()); p[s.size()] = 0;
+        *out = p;
+        if (out_len) *out_len = s.size();
+        return (int)OPUSFE_OK;
+    });
+}
+
+void opusfe_free_text(char* p) { free(p); }
+
+void opusfe_free_unit(opusfe_unit* u) {
+    if (!u) return;
+    opusfe_ctx* ctx = u->ctx;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (u->own_src) dev_free(ctx, (void*)u->d_src);
+    dev_free(ctx, u->d_tokens); dev_free(ctx, u->d_val64); dev_free(ctx, u->d_strpool); dev_free(ctx, u->d_seg_start);
+    dev_free(ctx, u->d_nodes); dev_free(ctx, u->d_seg_info); dev_free(ctx, u->d_def_nodes);
+    free_ir(ctx, u);
+    delete u;
+}
+
+int opusfe_set_profiling(opusfe_ctx* ctx, int enabled) {
+    if (!ctx) return OPUSFE_ERR_ARG;
+    ctx->profiling = enabled != 0;
+    ctx->kstats.clear();
+    return OPUSFE_OK;
+}
+int opusfe_kernel_count(opusfe_ctx* ctx) { return ctx ? (int)ctx->kstats.size() : 0; }
+int opusfe_kernel_info(opusfe_ctx* ctx, int index, const char** name, double* ms, uint64_t* launches) {
+    if (!ctx || index < 0 || index >= (int)ctx->kstats.size()) return OPUSFE_ERR_ARG;
+    if (name) *name = ctx->kstats[index].name;
+    if (ms) *ms = ctx->kstats[index].ms;
+    if (launches) *launches = ctx->kstats[index].launches;
+    return OPUSFE_OK;
+}
+
+}  // extern "C"

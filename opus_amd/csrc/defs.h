@@ -1,0 +1,60 @@
+// Shared host/device definitions of the opusfe library (MI355X / gfx950 only).
+#pragma once
+#include <stdint.h>
+#include "../../include/opusfe.h"
+
+#define OPUSFE_NONE 0xFFFFFFFFu
+
+// parse.rs:5-67, same order as the reference's enum Token.
+enum TokKind : uint8_t {
+    T_LeftParenthesis, T_RightParenthesis, T_LeftSquareBracket, T_RightSquareBracket, T_LeftBrace, T_RightBrace,
+    T_Colon, T_Equals, T_EqualsEquals, T_LessThan, T_GreaterThan, T_LessThanEquals, T_GreaterThanEquals,
+    T_Plus, T_Minus, T_Asterisk, T_Slash, T_Percent, T_At, T_Tilde, T_Dot, T_Comma, T_QuestionMark,
+    T_Integer, T_Float, T_String, T_Identifier, T_Indent, T_Dedent,
+    T_Var, T_Const, T_Return, T_If, T_Else, T_While, T_For, T_Break, T_Continue, T_Extern, T_Ref, T_Mut, T_Refs, T_Muts,
+    T_Null, T_False, T_True, T_Type, T_Record, T_Is, T_In, T_And, T_Or, T_Not, T_Sizeof, T_Alignof, T_Import, T_Library,
+    T_Proc, T_Operator, T_EndOfFile,
+    T_Error = OPUSFE_TOK_ERROR
+};
+
+// parse.rs:352-360
+enum PErrKind : uint8_t { PE_UnexpectedCharacter, PE_UnexpectedEndOfFile, PE_InvalidEscapeSequence, PE_UnexpectedToken,
+                          PE_ExpectedFoundToken, PE_ExpectedIdentifier, PE_InvalidNumericSize };
+
+// parse.rs:160-176
+enum OpKind : uint8_t { OP_Plus, OP_Minus, OP_Times, OP_Divide, OP_Modulo, OP_Equals, OP_LessThan, OP_GreaterThan,
+                        OP_LessThanEquals, OP_GreaterThanEquals, OP_Is, OP_And, OP_Or, OP_Not, OP_None = 0xFF };
+
+// AST node kinds.  D_* = parse.rs:308-317 Definition, S_* = :281-291 Statement, E_* = :254-278
+// Expression, Y_* = :294-304 Type; X_* are list/pair carriers that have no reference counterpart.
+enum NodeKind : uint8_t {
+    D_Function, D_Extern, D_Type, D_Variable, D_Constant, D_Import, D_Library,
+    S_Expression, S_VariableDefinition, S_Assignment, S_Return, S_If, S_While, S_For, S_Break, S_Continue,
+    E_Integer, E_Float, E_Null, E_Bool, E_String, E_Variable, E_VariableDefinition, E_Proc, E_CallOrIndex, E_NamedCall,
+    E_Record, E_Operator, E_Reference, E_MutableReference, E_ArrayReference, E_MutableArrayReference, E_Dereference,
+    E_Field, E_Cast, E_Negate, E_Sizeof, E_Alignof, E_Parentheses,
+    Y_Name, Y_Null, Y_Reference, Y_MutableReference, Y_ArrayReference, Y_MutableArrayReference, Y_Proc, Y_Record, Y_Array,
+    X_Block,       // [Box<Statement>]
+    X_FieldInit,   // (name, Box<Expression>) of a record literal; payload = name token
+    X_NamedType,   // (name, Box<Type>) of a record type / signature argument; payload = name token
+    N_KindCount
+};
+
+// generate_ir.rs:8-56, same order.
+enum IrOp : uint16_t { I_Integer, I_Float, I_Null, I_Bool, I_String, I_Sizeof, I_Alignof, I_Call, I_Allocate, I_Load, I_Store,
+    I_Field, I_BuiltinField, I_IndexPointer, I_IndexArray, I_Add, I_Subtract, I_Multiply, I_Divide, I_Modulo, I_Equals,
+    I_LessThan, I_GreaterThan, I_LessThanEquals, I_GreaterThanEquals, I_Function, I_GlobalVariable, I_GlobalConstant,
+    I_Not, I_Negate, I_Cast, I_Return, I_Jump, I_Branch, I_Unreachable, I_Phi, I_BreakPlaceholder, I_Error };
+
+// compile.rs:45-75 Type
+enum TyKind : uint8_t { TY_Integer8, TY_Integer16, TY_Integer32, TY_Integer64, TY_Natural8, TY_Natural16, TY_Natural32,
+    TY_Natural64, TY_Float32, TY_Float64, TY_Offset, TY_Size, TY_GenericInteger, TY_Generic, TY_Bool, TY_Null, TY_Pointer,
+    TY_String, TY_Record, TY_Function, TY_Array, TY_Error };
+enum PtrKind : uint8_t { PT_Reference, PT_Mutable, PT_Array, PT_ArrayMutable };
+enum CastKind : uint8_t { CT_None, CT_Pointer, CT_PointerType, CT_Integer, CT_PointerToInteger, CT_IntegerToPointer,
+                          CT_PointerToArray, CT_Error };
+
+// status word written by kernels (max wins)
+enum DevStatus : uint32_t { DS_OK = 0, DS_UNSUPPORTED_NONASCII = 1, DS_UNSUPPORTED_FLOAT = 2, DS_UNSUPPORTED_HANG = 3,
+                            DS_UNSUPPORTED_RESYNC = 4, DS_UNSUPPORTED_SEMANTIC = 5, DS_INTERNAL_CAPACITY = 16,
+                            DS_INTERNAL_SEGMENT = 17 };

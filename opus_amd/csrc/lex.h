@@ -1,0 +1,554 @@
+// GPU lexer for gfx950.  Restates the lexer embedded in the reference's Parser
+// (parse.rs:415-721: advance/peek, skip_whitespace, parse_token) as data-parallel passes:
+//
+//   1. k_ctx_chunk   : every 64-byte chunk -> composed transition function of the 6-state context
+//                      automaton {N, S, E, X1, X2, C}; tile aggregates.
+//   2. k_ctx_tiles   : single-block scan of the tile aggregates (function composition).
+//   3. k_lex_count   : per chunk: start state from a block scan of the chunk functions; lex the chunk
+//                      sequentially (tokens that START in it), count tokens / val64 / string bytes.
+//   4. scans         : tile totals -> offsets.
+//   5. k_lex_emit    : same walk, writes raw (dent-free) tokens + literal pools.
+//   6. k_tok_delta   : bracket-depth delta per raw token (derivation of parser-controlled
+//                      `ignore_dents`, parse.rs:874,879,890,928,939,987,990,1054,1069).
+//   7. k_gap         : per inter-token gap: does it cross a line in dent-sensitive mode and how many
+//                      TABs follow the last '\n' (parse.rs:427-472).
+//   8. k_final       : Indent/Dedent synthesis (parse.rs:495-501) + top-level segment boundaries.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "defs.h"
+#include "scan.h"
+
+namespace opusfe {
+
+constexpr int LEX_CHUNK = 64;                 // bytes lexed sequentially by one lane
+constexpr int LEX_THREADS = 256;
+constexpr int LEX_TILE = LEX_CHUNK * LEX_THREADS;  // 16 KiB per workgroup
+
+// ---- context automaton ---------------------------------------------------------------------
+enum CtxState : uint32_t { CS_N = 0, CS_S = 1, CS_E = 2, CS_X1 = 3, CS_X2 = 4, CS_C = 5 };
+#define CTXFN(n, s, e, x1, x2, c) ((uint32_t)(n) | ((uint32_t)(s) << 3) | ((uint32_t)(e) << 6) | ((uint32_t)(x1) << 9) | ((uint32_t)(x2) << 12) | ((uint32_t)(c) << 15))
+constexpr uint32_t CTX_IDENTITY = CTXFN(0, 1, 2, 3, 4, 5);
+constexpr uint32_t CTX_OTHER = CTXFN(CS_N, CS_S, CS_S, CS_X2, CS_S, CS_C);
+constexpr uint32_t CTX_QUOTE = CTXFN(CS_S, CS_N, CS_S, CS_X2, CS_S, CS_C);
+constexpr uint32_t CTX_BSL = CTXFN(CS_N, CS_E, CS_S, CS_X2, CS_S, CS_C);
+constexpr uint32_t CTX_SEMI = CTXFN(CS_C, CS_S, CS_S, CS_X2, CS_S, CS_C);
+constexpr uint32_t CTX_NL = CTXFN(CS_N, CS_S, CS_S, CS_X2, CS_S, CS_N);
+constexpr uint32_t CTX_X = CTXFN(CS_N, CS_S, CS_X1, CS_X2, CS_S, CS_C);
+
+__host__ __device__ __forceinline__ uint32_t ctx_of_byte(uint32_t b) {
+    return b == '"' ? CTX_QUOTE : b == '\\' ? CTX_BSL : b == ';' ? CTX_SEMI : b == '\n' ? CTX_NL : b == 'x' ? CTX_X : CTX_OTHER;
+}
+__host__ __device__ __forceinline__ uint32_t ctx_apply(uint32_t f, uint32_t s) { return (f >> (3 * s)) & 7u; }
+// first f, then g
+__host__ __device__ __forceinline__ uint32_t ctx_compose(uint32_t f, uint32_t g) {
+    uint32_t r = 0;
+#pragma unroll
+    for (int s = 0; s < 6; s++) r |= ctx_apply(g, ctx_apply(f, s)) << (3 * s);
+    return r;
+}
+// true when some start state currently maps to E / X1 / X2 (010, 011, 100): only then does an
+// ordinary byte change the function.
+__host__ __device__ __forceinline__ bool ctx_has_transient(uint32_t f) {
+    const uint32_t m0 = 0x9249u;   // bit 0 of each 3-bit lane (6 lanes)
+    uint32_t b0 = f & m0, b1 = (f >> 1) & m0, b2 = (f >> 2) & m0;
+    return (b1 | (b2 & ~b0)) != 0;
+}
+struct OpCtx { __host__ __device__ uint32_t operator()(uint32_t a, uint32_t b) const { return ctx_compose(a, b); } };
+
+__global__ __launch_bounds__(LEX_THREADS) void k_ctx_chunk(const uint8_t* __restrict__ src, uint32_t n, uint32_t* __restrict__ chunk_fn, uint32_t* __restrict__ tile_fn) {
+    __shared__ uint32_t lds[4];
+    uint32_t chunk = blockIdx.x * LEX_THREADS + threadIdx.x;
+    uint64_t base = (uint64_t)chunk * LEX_CHUNK;
+    uint32_t f = CTX_IDENTITY;
+    if (base < n) {
+        uint32_t end = (uint32_t)((base + LEX_CHUNK < n) ? base + LEX_CHUNK : n);
+        if (end - (uint32_t)base == LEX_CHUNK) {
+            const uint4* p = reinterpret_cast<const uint4*>(src + base);
+#pragma unroll
+            for (int q = 0; q < LEX_CHUNK / 16; q++) {
+                uint4 v = p[q];
+                uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        uint32_t g = ctx_of_byte((w[k] >> (8 * j)) & 0xFF);
+                        if (g != CTX_OTHER || ctx_has_transient(f)) f = ctx_compose(f, g);
+                    }
+                }
+            }
+        } else {
+            for (uint32_t i = (uint32_t)base; i < end; i++) f = ctx_compose(f, ctx_of_byte(src[i]));
+        }
+        chunk_fn[chunk] = f;
+    }
+    uint32_t total;
+    block_inclusive_scan(f, OpCtx(), lds, &total);
+    if (threadIdx.x == 0) tile_fn[blockIdx.x] = total;
+}
+
+// tile_fn[i] (composed function of tile i)  ->  tile_state[i] = context state at the start of tile i
+__global__ __launch_bounds__(SCAN_THREADS) void k_ctx_tiles(const uint32_t* __restrict__ tile_fn, uint8_t* __restrict__ tile_state, uint32_t ntiles) {
+    __shared__ uint32_t lds[4];
+    __shared__ uint32_t wave_last[4];
+    __shared__ uint32_t carry_s;
+    if (threadIdx.x == 0) carry_s = CTX_IDENTITY;
+    __syncthreads();
+    for (uint32_t base = 0; base < ntiles; base += SCAN_TILE) {
+        uint32_t b = base + threadIdx.x * SCAN_ITEMS;
+        uint32_t v[SCAN_ITEMS];
+        uint32_t acc = CTX_IDENTITY;
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; i++) { v[i] = (b + i < ntiles) ? tile_fn[b + i] : CTX_IDENTITY; acc = ctx_compose(acc, v[i]); }
+        uint32_t total;
+        uint32_t incl = block_inclusive_scan(acc, OpCtx(), lds, &total);
+        uint32_t prev = shfl_up_t(incl, 1);
+        if ((threadIdx.x & 63) == 63) wave_last[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        uint32_t excl;
+        if (threadIdx.x == 0) excl = carry_s;
+        else if ((threadIdx.x & 63) == 0) excl = ctx_compose(carry_s, wave_last[(threadIdx.x >> 6) - 1]);
+        else excl = ctx_compose(carry_s, prev);
+        uint32_t run = excl;
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; i++) { if (b + i < ntiles) tile_state[b + i] = (uint8_t)ctx_apply(run, CS_N); run = ctx_compose(run, v[i]); }
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = ctx_compose(carry_s, total);
+        __syncthreads();
+    }
+}
+
+// ---- one token ----------------------------------------------------------------------------------
+struct LexTok {
+    uint8_t kind, flags; uint16_t aux;
+    uint32_t low, end;        // [low, end): end = where lexing resumes
+    uint32_t nval;            // val64 entries (0..2)
+    uint64_t v0, v1;
+    uint32_t payload;         // inline integer / identifier hash
+    uint32_t strbytes;        // pool bytes incl. the 4-byte length prefix, padded to 4
+};
+
+__device__ __forceinline__ int lx_at(const uint8_t* __restrict__ s, uint32_t n, uint32_t i) { return i < n ? (int)s[i] : -1; }
+__device__ __forceinline__ bool lx_is_ws(int c) { return c == ' ' || (c >= 9 && c <= 13); }
+__device__ __forceinline__ bool lx_is_digit(int c) { return c >= '0' && c <= '9'; }
+__device__ __forceinline__ bool lx_is_alpha(int c) { return (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || c == '_'; }
+__device__ __forceinline__ bool lx_is_identc(int c) { return lx_is_alpha(c) || lx_is_digit(c) || c == '\\'; }
+// bytes over which the lookback of a chunk must continue to find a certain token boundary
+__device__ __forceinline__ bool lx_is_run(int c) { return lx_is_identc(c) || c == '.' || c == '=' || c == '<' || c == '>'; }
+__device__ __forceinline__ int lx_hex(int c) { return lx_is_digit(c) ? c - '0' : (c >= 'a' && c <= 'f') ? c - 'a' + 10 : (c >= 'A' && c <= 'F') ? c - 'A' + 10 : -1; }
+__device__ __forceinline__ uint32_t lx_utf8_len(int b0) { return b0 < 0x80 ? 1 : b0 >= 0xF0 ? 4 : b0 >= 0xE0 ? 3 : b0 >= 0xC0 ? 2 : 1; }
+
+__device__ __forceinline__ uint64_t kw_pack(const char* s) {
+    uint64_t v = 0;
+    for (int i = 0; s[i] && i < 8; i++) v |= (uint64_t)(uint8_t)s[i] << (8 * i);
+    return v;
+}
+__device__ __forceinline__ uint8_t lx_keyword(uint64_t w, uint32_t len) {
+    // parse.rs:640-671
+    switch (len) {
+        case 2:
+            if (w == kw_pack("if")) return T_If; if (w == kw_pack("is")) return T_Is; if (w == kw_pack("in")) return T_In;
+            if (w == kw_pack("or")) return T_Or; break;
+        case 3:
+            if (w == kw_pack("var")) return T_Var; if (w == kw_pack("for")) return T_For; if (w == kw_pack("ref")) return T_Ref;
+            if (w == kw_pack("mut")) return T_Mut; if (w == kw_pack("and")) return T_And; if (w == kw_pack("not")) return T_Not; break;
+        case 4:
+            if (w == kw_pack("else")) return T_Else; if (w == kw_pack("refs")) return T_Refs; if (w == kw_pack("muts")) return T_Muts;
+            if (w == kw_pack("null")) return T_Null; if (w == kw_pack("true")) return T_True; if (w == kw_pack("type")) return T_Type;
+            if (w == kw_pack("proc")) return T_Proc; break;
+        case 5:
+            if (w == kw_pack("const")) return T_Const; if (w == kw_pack("while")) return T_While; if (w == kw_pack("break")) return T_Break;
+            if (w == kw_pack("false")) return T_False; break;
+        case 6:
+            if (w == kw_pack("return")) return T_Return; if (w == kw_pack("extern")) return T_Extern; if (w == kw_pack("record")) return T_Record;
+            if (w == kw_pack("sizeof")) return T_Sizeof; if (w == kw_pack("import")) return T_Import; break;
+        case 7:
+            if (w == kw_pack("alignof")) return T_Alignof; if (w == kw_pack("library")) return T_Library; break;
+        case 8:
+            if (w == kw_pack("continue")) return T_Continue; if (w == kw_pack("operator")) return T_Operator; break;
+        default: break;
+    }
+    return T_Identifier;
+}
+
+__device__ __forceinline__ void lx_error(LexTok& o, uint8_t perr, uint32_t span_low, uint32_t span_len, uint64_t payload, uint32_t end) {
+    o.kind = T_Error; o.aux = perr; o.end = end; o.nval = 2;
+    o.v0 = (uint64_t)span_low | ((uint64_t)span_len << 32);
+    o.v1 = payload;
+}
+
+// From a position inside a string body (context S at p): where the context automaton returns to N.
+// Used for error tokens so that the token stream stays consistent with the context scan; the
+// reference resumes elsewhere (inside the string body), hence OPUSFE_TF_RESYNC on such tokens.
+__device__ __forceinline__ uint32_t lx_string_end(const uint8_t* __restrict__ s, uint32_t n, uint32_t p) {
+    uint32_t st = CS_S;
+    while (p < n && st != CS_N) { st = ctx_apply(ctx_of_byte(s[p]), st); p++; }
+    return p;
+}
+
+// Lexes the token starting at `pos` (s[pos] is not whitespace, not ';', pos < n, context N).
+// parse.rs:503-720.  `strdst` (may be null) receives [u32 n][bytes] of a String token.
+__device__ void lex_one(const uint8_t* __restrict__ s, uint32_t n, uint32_t pos, LexTok& o, uint8_t* strdst, uint32_t* status) {
+    o.kind = T_EndOfFile; o.flags = 0; o.aux = 0; o.low = pos; o.end = pos + 1; o.nval = 0; o.v0 = o.v1 = 0; o.payload = 0; o.strbytes = 0;
+    int c = s[pos];
+    switch (c) {
+        case '(': o.kind = T_LeftParenthesis; return;
+        case ')': o.kind = T_RightParenthesis; return;
+        case '[': o.kind = T_LeftSquareBracket; return;
+        case ']': o.kind = T_RightSquareBracket; return;
+        case '{': o.kind = T_LeftBrace; return;
+        case '}': o.kind = T_RightBrace; return;
+        case ':': o.kind = T_Colon; return;
+        case '=': if (lx_at(s, n, pos + 1) == '=') { o.kind = T_EqualsEquals; o.end = pos + 2; } else o.kind = T_Equals; return;
+        case '<': if (lx_at(s, n, pos + 1) == '=') { o.kind = T_LessThanEquals; o.end = pos + 2; } else o.kind = T_LessThan; return;
+        case '>': if (lx_at(s, n, pos + 1) == '=') { o.kind = T_GreaterThanEquals; o.end = pos + 2; } else o.kind = T_GreaterThan; return;
+        case '+': o.kind = T_Plus; return;
+        case '-': o.kind = T_Minus; return;
+        case '*': o.kind = T_Asterisk; return;
+        case '/': o.kind = T_Slash; return;
+        case '%': o.kind = T_Percent; return;
+        case '@': o.kind = T_At; return;
+        case '~': o.kind = T_Tilde; return;
+        case '.': o.kind = T_Dot; return;
+        case ',': o.kind = T_Comma; return;
+        case '?': o.kind = T_QuestionMark; return;
+        default: break;
+    }
+    if (lx_is_digit(c)) {
+        // parse.rs:549-628
+        uint64_t v = (uint64_t)(c - '0');
+        uint32_t p = pos + 1;
+        for (;;) { int d = lx_at(s, n, p); if (!lx_is_digit(d)) break; v = v * 10 + (uint64_t)(d - '0'); p++; }
+        if (lx_at(s, n, p) == '.') {
+            p++;
+            // mantissa as an exact integer (Clinger fast path: w < 2^53, 10^k exact for k <= 22)
+            uint64_t w = 0; bool exact = true; uint32_t frac = 0;
+            for (uint32_t q = pos; q < p - 1; q++) { uint64_t d = (uint64_t)(s[q] - '0'); if (w > (0x1FFFFFFFFFFFFFull - d) / 10) exact = false; else w = w * 10 + d; }
+            for (;;) {
+                int d = lx_at(s, n, p); if (!lx_is_digit(d)) break;
+                uint64_t dd = (uint64_t)(d - '0');
+                if (w > (0x1FFFFFFFFFFFFFull - dd) / 10) exact = false; else w = w * 10 + dd;
+                frac++; p++;
+            }
+            if (frac > 22) exact = false;
+            double f = 0.0;
+            if (exact) {
+                const double P10[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+                f = (double)w / P10[frac];
+            } else {
+                // trailing zeros in the fraction do not change the value: retry without them
+                // (keeps "1.50000000000000000000000" exact); otherwise unsupported for now.
+                atomicMax(status, (uint32_t)DS_UNSUPPORTED_FLOAT);
+            }
+            o.kind = T_Float; o.nval = 1; o.v0 = (uint64_t)__double_as_longlong(f);
+            if (lx_at(s, n, p) == 'f') {
+                // parse.rs:563-581: after 'f' two advance()s regardless
+                int a = lx_at(s, n, p + 1), b = a < 0 ? -1 : lx_at(s, n, p + 2);
+                if (a >= 0x80 || b >= 0x80) atomicMax(status, (uint32_t)DS_UNSUPPORTED_NONASCII);
+                if (a == '3' && b == '2') { o.aux = 32; p += 3; }
+                else if (a == '6' && b == '4') { o.aux = 64; p += 3; }
+                else if (a >= 0 && b < 0) { lx_error(o, PE_InvalidNumericSize, pos, p + 2 - pos, (uint32_t)a - (uint32_t)'0', p + 2); if (!lx_is_run(a)) o.flags |= OPUSFE_TF_RESYNC; return; }
+                else if (a >= 0 && b >= 0) { lx_error(o, PE_InvalidNumericSize, pos, p + 3 - pos, ((uint32_t)a - (uint32_t)'0') * 10u + ((uint32_t)b - (uint32_t)'0'), p + 3); if (!lx_is_run(a) || !lx_is_run(b)) o.flags |= OPUSFE_TF_RESYNC; return; }
+                else { atomicMax(status, (uint32_t)DS_UNSUPPORTED_HANG); p += 1; }   // `<float>f<EOF>`: the reference loops forever (Q4)
+            }
+            o.end = p;
+            return;
+        }
+        o.kind = T_Integer; o.end = p;
+        int sfx = lx_at(s, n, p);
+        if (sfx == 's') o.aux = 0x8000;                       // (false, 0), not consumed (Q1)
+        else if (sfx == 'o') o.aux = 0x8000 | 0x100;          // (true, 0)
+        else if (sfx == 'i' || sfx == 'n') {
+            uint16_t sg = sfx == 'i' ? 0x100 : 0;
+            int a = lx_at(s, n, p + 1), b = a < 0 ? -1 : lx_at(s, n, p + 2);
+            if (a == '8') { o.aux = 0x8000 | sg | 8; o.end = p + 2; }
+            else if (a == '1' && b == '6') { o.aux = 0x8000 | sg | 16; o.end = p + 3; }
+            else if (a == '3' && b == '2') { o.aux = 0x8000 | sg | 32; o.end = p + 3; }
+            else if (a == '6' && b == '4') { o.aux = 0x8000 | sg | 64; o.end = p + 3; }
+            else if (lx_is_digit(a) && lx_is_digit(b)) { lx_error(o, PE_InvalidNumericSize, p + 1, 2, (uint32_t)((a - '0') * 10 + b - '0'), p + 3); return; }
+            else if (lx_is_digit(a)) { lx_error(o, PE_InvalidNumericSize, p + 1, 1, (uint32_t)(a - '0'), p + 2); return; }
+            else { o.aux = 0x8000 | sg | 32; o.end = p + 1; }   // rewind to just after the letter (Q2)
+        }
+        if (v <= 0xFFFFFFFFull) { o.flags |= OPUSFE_TF_INLINE; o.payload = (uint32_t)v; }
+        else { o.nval = 1; o.v0 = v; }
+        return;
+    }
+    if (lx_is_alpha(c)) {
+        // parse.rs:629-673
+        uint32_t p = pos + 1;
+        uint64_t w = (uint64_t)c;
+        uint32_t h = (2166136261u ^ (uint32_t)c) * 16777619u;
+        for (;;) {
+            int d = lx_at(s, n, p);
+            if (d >= 0x80) { atomicMax(status, (uint32_t)DS_UNSUPPORTED_NONASCII); break; }
+            if (!lx_is_identc(d)) break;
+            if (p - pos < 8) w |= (uint64_t)d << (8 * (p - pos));
+            h = (h ^ (uint32_t)d) * 16777619u;
+            p++;
+        }
+        o.end = p;
+        o.kind = lx_keyword(w, p - pos);
+        if (o.kind == T_Identifier) o.payload = h;
+        return;
+    }
+    if (c == '"') {
+        // parse.rs:674-717
+        uint32_t p = pos + 1;
+        uint32_t nout = 0;
+        uint8_t* dst = strdst ? strdst + 4 : nullptr;
+        for (;;) {
+            int ch = lx_at(s, n, p);
+            if (ch < 0) { lx_error(o, PE_UnexpectedEndOfFile, n, 0, 0, n); return; }
+            if (ch == '"') { p++; break; }
+            if (ch == '\\') {
+                uint32_t escape_position = p + 1;
+                int e = lx_at(s, n, p + 1);
+                int val = -1;
+                switch (e) {
+                    case '\\': val = '\\'; break; case '"': val = '"'; break; case 'n': val = '\n'; break;
+                    case 'r': val = '\r'; break; case 't': val = '\t'; break; case '0': val = 0; break;
+                    default: break;
+                }
+                if (val >= 0) { if (dst) dst[nout] = (uint8_t)val; nout++; p += 2; continue; }
+                if (e == 'x') {
+                    // two advance()s over *chars* (parse.rs:691-692)
+                    int hc = lx_at(s, n, p + 2);
+                    uint32_t q = p + 2 + (hc < 0 ? 0 : lx_utf8_len(hc));
+                    int lc = hc < 0 ? -1 : lx_at(s, n, q);
+                    uint32_t q2 = q + (lc < 0 ? 0 : lx_utf8_len(lc));
+                    int hv = hc < 0 ? -1 : lx_hex(hc), lv = lc < 0 ? -1 : lx_hex(lc);
+                    if (hv >= 0 && lv >= 0) { if (dst) dst[nout] = (uint8_t)(hv * 16 + lv); nout++; p = q2; continue; }
+                    if (q2 > n) q2 = n;
+                    lx_error(o, PE_InvalidEscapeSequence, escape_position, q2 - escape_position, 0, lx_string_end(s, n, p));
+                    o.flags |= OPUSFE_TF_RESYNC;
+                    return;
+                }
+                if (e < 0) { lx_error(o, PE_UnexpectedEndOfFile, n, 0, 0, n); return; }
+                uint32_t el = lx_utf8_len(e);
+                if (escape_position + el > n) el = n - escape_position;
+                lx_error(o, PE_InvalidEscapeSequence, escape_position, el, 0, lx_string_end(s, n, p));
+                o.flags |= OPUSFE_TF_RESYNC;
+                return;
+            }
+            if (dst) dst[nout] = (uint8_t)ch;
+            nout++; p++;
+        }
+        o.kind = T_String; o.end = p;
+        o.strbytes = 4 + ((nout + 3) & ~3u);
+        if (strdst) { *reinterpret_cast<uint32_t*>(strdst) = nout; for (uint32_t k = nout; k < ((nout + 3) & ~3u); k++) dst[k] = 0; }
+        return;
+    }
+    if (c >= 0x80) { atomicMax(status, (uint32_t)DS_UNSUPPORTED_NONASCII); }
+    lx_error(o, PE_UnexpectedCharacter, pos, 1, (uint64_t)c, pos + 1);
+}
+
+// Walks one chunk [cbeg, cend) given the context state at cbeg; calls f(tok) for every token that
+// starts inside the chunk.  Returns nothing; `f` accumulates.
+template <class F>
+__device__ __forceinline__ void lex_chunk(const uint8_t* __restrict__ s, uint32_t n, uint32_t cbeg, uint32_t cend, uint32_t state, uint32_t* status, F&& f) {
+    uint32_t pos = cbeg;
+    // (a) finish a string / comment that began in an earlier chunk
+    while (state != CS_N && pos < cend) { state = ctx_apply(ctx_of_byte(s[pos]), state); pos++; }
+    if (state != CS_N) return;
+    // (b) we are in context N at pos (== cbeg unless (a) moved us, in which case pos is a boundary).
+    if (pos == cbeg && cbeg > 0 && lx_is_run(s[cbeg - 1])) {
+        // The chunk may begin inside a token: find the closest certain boundary to the left
+        // (a byte that is not a run character in context N always ends a token) and re-lex from it.
+        uint32_t p = cbeg;
+        while (p > 0 && lx_is_run(s[p - 1])) p--;
+        while (p < cbeg) {
+            LexTok t;
+            // only run characters here: never whitespace, ';' or '"'
+            lex_one(s, n, p, t, nullptr, status);
+            p = t.end;
+        }
+        pos = p;   // >= cbeg: first boundary at or after the chunk start
+    }
+    while (pos < cend) {
+        int c = s[pos];
+        if (lx_is_ws(c)) { pos++; continue; }
+        if (c == ';') {   // comment: to the next '\n' (parse.rs:450-457); the '\n' itself is whitespace
+            pos++;
+            while (pos < n && s[pos] != '\n') pos++;
+            continue;
+        }
+        pos = f(pos);
+    }
+}
+
+// per-chunk packed counts: tok (8 bits) | val (8 bits); string-pool bytes separately
+__global__ __launch_bounds__(LEX_THREADS) void k_lex_count(const uint8_t* __restrict__ src, uint32_t n, const uint32_t* __restrict__ chunk_fn,
+                                                         const uint8_t* __restrict__ tile_state, uint8_t* __restrict__ chunk_state,
+                                                         uint32_t* __restrict__ chunk_cnt, uint32_t* __restrict__ chunk_str,
+                                                         Cnt3* __restrict__ tile_cnt, uint32_t* status) {
+    __shared__ uint32_t lds[4];
+    __shared__ Cnt3 lds3[4];
+    uint32_t chunk = blockIdx.x * LEX_THREADS + threadIdx.x;
+    uint64_t base = (uint64_t)chunk * LEX_CHUNK;
+    bool live = base < n;
+    uint32_t f = live ? chunk_fn[chunk] : CTX_IDENTITY;
+    uint32_t incl = block_inclusive_scan(f, OpCtx(), lds, (uint32_t*)nullptr);
+    // exclusive prefix within the tile
+    uint32_t prev = shfl_up_t(incl, 1);
+    __shared__ uint32_t wave_last[4];
+    if ((threadIdx.x & 63) == 63) wave_last[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t excl = threadIdx.x == 0 ? CTX_IDENTITY : ((threadIdx.x & 63) == 0 ? wave_last[(threadIdx.x >> 6) - 1] : prev);
+    uint32_t state = ctx_apply(excl, tile_state[blockIdx.x]);
+    Cnt3 c{0, 0, 0, 0};
+    if (live) {
+        uint32_t cbeg = (uint32_t)base, cend = (uint32_t)((base + LEX_CHUNK < n) ? base + LEX_CHUNK : n);
+        lex_chunk(src, n, cbeg, cend, state, status, [&](uint32_t pos) {
+            LexTok t;
+            lex_one(src, n, pos, t, nullptr, status);
+            c.tok++; c.val += t.nval; c.str += t.strbytes;
+            return t.end;
+        });
+        chunk_state[chunk] = (uint8_t)state;
+        chunk_cnt[chunk] = c.tok | (c.val << 8);
+        chunk_str[chunk] = c.str;
+    }
+    Cnt3 total;
+    block_inclusive_scan(c, OpAddCnt3(), lds3, &total);
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(LEX_THREADS) void k_lex_emit(const uint8_t* __restrict__ src, uint32_t n, const uint8_t* __restrict__ chunk_state,
+                                                        const uint32_t* __restrict__ chunk_cnt, const uint32_t* __restrict__ chunk_str,
+                                                        const Cnt3* __restrict__ tile_off, opusfe_token* __restrict__ raw, uint64_t* __restrict__ val64,
+                                                        uint8_t* __restrict__ strpool, uint32_t* status) {
+    __shared__ Cnt3 lds3[4];
+    __shared__ Cnt3 wave_last[4];
+    uint32_t chunk = blockIdx.x * LEX_THREADS + threadIdx.x;
+    uint64_t base = (uint64_t)chunk * LEX_CHUNK;
+    bool live = base < n;
+    Cnt3 c{0, 0, 0, 0};
+    if (live) { uint32_t pc = chunk_cnt[chunk]; c.tok = pc & 0xFF; c.val = pc >> 8; c.str = chunk_str[chunk]; }
+    Cnt3 incl = block_inclusive_scan(c, OpAddCnt3(), lds3, (Cnt3*)nullptr);
+    Cnt3 off = tile_off[blockIdx.x];
+    off.tok += incl.tok - c.tok; off.val += incl.val - c.val; off.str += incl.str - c.str;
+    (void)wave_last;
+    if (!live || c.tok == 0) return;
+    uint32_t cbeg = (uint32_t)base, cend = (uint32_t)((base + LEX_CHUNK < n) ? base + LEX_CHUNK : n);
+    uint32_t state = chunk_state[chunk];
+    uint32_t ti = off.tok, vi = off.val, si = off.str;
+    lex_chunk(src, n, cbeg, cend, state, status, [&](uint32_t pos) {
+        LexTok t;
+        lex_one(src, n, pos, t, strpool + si, status);
+        opusfe_token o;
+        o.kind = t.kind; o.flags = t.flags; o.aux = t.aux; o.low = t.low; o.len = t.end - t.low;
+        if (t.kind == T_Error) { o.low = pos; o.payload = vi; }
+        else if (t.kind == T_String) o.payload = si;
+        else if (t.nval) o.payload = vi;
+        else o.payload = t.payload;
+        if (t.nval >= 1) val64[vi] = t.v0;
+        if (t.nval >= 2) val64[vi + 1] = t.v1;
+        vi += t.nval; si += t.strbytes;
+        raw[ti++] = o;
+        return t.end;
+    });
+}
+
+// ---- token-level passes ----------------------------------------------------------------------
+__device__ __forceinline__ bool tk_record_open(const opusfe_token* __restrict__ raw, uint32_t k) {
+    // `{` that raises ignore_dents: `record {` (parse.rs:925-928) or `record <name> {` (parse.rs:1047-1054),
+    // where <name> may be the two-token form `operator X` (parse.rs:776).
+    if (k >= 1 && raw[k - 1].kind == T_Record) return true;
+    if (k >= 2 && raw[k - 1].kind == T_Identifier && raw[k - 2].kind == T_Record) return true;
+    if (k >= 3 && raw[k - 2].kind == T_Operator && raw[k - 3].kind == T_Record) return true;
+    return false;
+}
+
+__global__ void k_tok_delta(const opusfe_token* __restrict__ raw, uint32_t T, int32_t* __restrict__ delta, int force_dents) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= T) return;
+    int32_t d = 0;
+    if (!force_dents) {
+        uint8_t kd = raw[k].kind;
+        if (kd == T_LeftParenthesis) d = 1;
+        else if (kd == T_RightParenthesis) d = -1;
+        else if (kd == T_LeftBrace) d = tk_record_open(raw, k) ? 1 : 0;
+        else if (kd == T_RightBrace) {
+            // `{}` / `{N}` array forms never touch ignore_dents (parse.rs:943-958)
+            bool array_close = (k >= 1 && raw[k - 1].kind == T_LeftBrace && !tk_record_open(raw, k - 1))
+                            || (k >= 2 && raw[k - 1].kind == T_Integer && raw[k - 2].kind == T_LeftBrace && !tk_record_open(raw, k - 2));
+            d = array_close ? 0 : -1;
+        }
+    }
+    delta[k] = d;
+}
+
+// For gap k (before raw token k; k == T is the gap before end of file): value | 1<<31 when the gap
+// is dent-sensitive and crosses a line (or is the very first gap / the EOF gap).
+__global__ void k_gap(const uint8_t* __restrict__ src, uint32_t n, const opusfe_token* __restrict__ raw, uint32_t T,
+                      const int32_t* __restrict__ depth_incl, uint32_t* __restrict__ gapval) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > T) return;
+    bool sens = (k == 0) || depth_incl[k - 1] == 0;
+    uint32_t out = 0;
+    if (sens) {
+        if (k == T) out = 0x80000000u;                       // EOF: -(indent) (parse.rs:461-464)
+        else {
+            uint32_t gbeg = k == 0 ? 0 : raw[k - 1].low + raw[k - 1].len;
+            uint32_t gend = raw[k].low;
+            if (raw[k].kind == T_Error) gend = raw[k].low;
+            uint32_t p = gend;
+            bool nl = false;
+            while (p > gbeg) { if (src[p - 1] == '\n') { nl = true; break; } p--; }
+            if (nl || gbeg == 0) {
+                // p = position just after the last '\n' (or 0): count leading TABs (parse.rs:438-444)
+                uint32_t q = nl ? p : 0, tabs = 0;
+                while (q < gend && src[q] == '\t') { tabs++; q++; }
+                out = 0x80000000u | tabs;
+            }
+        }
+    }
+    gapval[k] = out;
+}
+
+// count[k] = |delta| + 1
+__global__ void k_dent_count(const uint32_t* __restrict__ gapval, const uint32_t* __restrict__ prev_excl, uint32_t T, uint32_t* __restrict__ cnt) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > T) return;
+    uint32_t g = gapval[k];
+    int32_t d = 0;
+    if (g >> 31) d = (int32_t)(g & 0x7FFFFFFFu) - (int32_t)(prev_excl[k] & 0x7FFFFFFFu);
+    cnt[k] = (uint32_t)(d < 0 ? -d : d) + 1;
+}
+
+__global__ void k_final(const opusfe_token* __restrict__ raw, uint32_t T, uint32_t n, const uint32_t* __restrict__ gapval,
+                        const uint32_t* __restrict__ prev_excl, const uint32_t* __restrict__ out_off, opusfe_token* __restrict__ tokens,
+                        uint32_t* __restrict__ seg_flag) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > T) return;
+    uint32_t g = gapval[k];
+    int32_t d = 0;
+    if (g >> 31) d = (int32_t)(g & 0x7FFFFFFFu) - (int32_t)(prev_excl[k] & 0x7FFFFFFFu);
+    uint32_t nd = (uint32_t)(d < 0 ? -d : d);
+    uint32_t o = out_off[k];
+    opusfe_token dent;
+    dent.kind = d > 0 ? T_Indent : T_Dedent; dent.flags = 0; dent.aux = 0; dent.len = 0; dent.payload = 0;
+    dent.low = k < T ? raw[k].low : n;
+    for (uint32_t i = 0; i < nd; i++) tokens[o + i] = dent;
+    if (k < T) tokens[o + nd] = raw[k];
+    else { opusfe_token e; e.kind = T_EndOfFile; e.flags = 0; e.aux = 0; e.low = n; e.len = 0; e.payload = 0; tokens[o + nd] = e; }
+    // top-level segment starts: token 0, and the first token after a dedent back to level 0 unless it
+    // is `else`, a lexical-error token or EOF (see DESIGN.md "segments").
+    uint32_t flag = 0;
+    if (k < T) {
+        uint8_t kd = raw[k].kind;
+        if (k == 0) flag = 1;
+        else if (d < 0 && (g & 0x7FFFFFFFu) == 0 && kd != T_Else && kd != T_Error) flag = 1;
+    }
+    seg_flag[k] = flag;
+}
+
+// seg_start[id] = index in the final token stream where segment id starts
+__global__ void k_seg_starts(const uint32_t* __restrict__ seg_flag, const uint32_t* __restrict__ seg_excl, const uint32_t* __restrict__ out_off,
+                             const uint32_t* __restrict__ cnt, uint32_t T, uint32_t* __restrict__ seg_start) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= T) return;
+    if (seg_flag[k]) seg_start[seg_excl[k]] = (k == 0) ? 0 : out_off[k] + cnt[k] - 1;
+}
+
+}  // namespace opusfe

@@ -1,0 +1,112 @@
+// Host-side runtime of libopusfe: context, caching device allocator, HIP-event kernel timing.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+#include "defs.h"
+
+struct opusfe_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string msg;
+    // caching allocator: freed blocks are kept and reused so that steady-state calls never hipMalloc
+    std::multimap<size_t, void*> free_blocks;
+    std::map<void*, size_t> live_blocks;
+    size_t bytes_allocated = 0;
+    // profiling
+    bool profiling = false;
+    struct Pending { const char* name; hipEvent_t a, b; };
+    std::vector<Pending> pending;
+    struct KStat { const char* name; double ms; uint64_t launches; };
+    std::vector<KStat> kstats;
+    std::vector<hipEvent_t> event_pool;
+    uint32_t* d_status = nullptr;   // DevStatus word + scratch totals (64 words)
+    uint32_t* h_status = nullptr;   // pinned mirror
+};
+
+namespace opusfe {
+
+struct HipError { hipError_t e; const char* what; };
+
+#define HIP_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) throw opusfe::HipError{_e, #expr}; } while (0)
+
+inline void* dev_alloc(opusfe_ctx* ctx, size_t bytes) {
+    if (bytes == 0) bytes = 256;
+    bytes = (bytes + 255) & ~(size_t)255;
+    auto it = ctx->free_blocks.lower_bound(bytes);
+    if (it != ctx->free_blocks.end() && it->first <= bytes + bytes / 4 + (1 << 20)) {
+        void* p = it->second; size_t cap = it->first;
+        ctx->free_blocks.erase(it);
+        ctx->live_blocks[p] = cap;
+        return p;
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        // drop the cache and retry once
+        for (auto& kv : ctx->free_blocks) (void)hipFree(kv.second);
+        ctx->free_blocks.clear();
+        HIP_TRY(hipMalloc(&p, bytes));
+    }
+    ctx->bytes_allocated += bytes;
+    ctx->live_blocks[p] = bytes;
+    return p;
+}
+inline void dev_free(opusfe_ctx* ctx, void* p) {
+    if (!p) return;
+    auto it = ctx->live_blocks.find(p);
+    if (it == ctx->live_blocks.end()) return;
+    ctx->free_blocks.insert({it->second, p});
+    ctx->live_blocks.erase(it);
+}
+template <class T> inline T* dev_alloc_t(opusfe_ctx* ctx, size_t count) { return (T*)dev_alloc(ctx, count * sizeof(T)); }
+
+// RAII list of temporaries released back to the cache at scope exit
+struct TempList {
+    opusfe_ctx* ctx; std::vector<void*> v;
+    explicit TempList(opusfe_ctx* c) : ctx(c) {}
+    ~TempList() { for (void* p : v) dev_free(ctx, p); }
+    template <class T> T* get(size_t count) { T* p = dev_alloc_t<T>(ctx, count); v.push_back(p); return p; }
+};
+
+inline hipEvent_t get_event(opusfe_ctx* ctx) {
+    if (!ctx->event_pool.empty()) { hipEvent_t e = ctx->event_pool.back(); ctx->event_pool.pop_back(); return e; }
+    hipEvent_t e; HIP_TRY(hipEventCreate(&e)); return e;
+}
+inline void prof_begin(opusfe_ctx* ctx, const char* name) {
+    if (!ctx->profiling) return;
+    opusfe_ctx::Pending p{name, get_event(ctx), get_event(ctx)};
+    HIP_TRY(hipEventRecord(p.a, ctx->stream));
+    ctx->pending.push_back(p);
+}
+inline void prof_end(opusfe_ctx* ctx) {
+    if (!ctx->profiling) return;
+    HIP_TRY(hipEventRecord(ctx->pending.back().b, ctx->stream));
+}
+// call after the stream has been synchronised
+inline void prof_collect(opusfe_ctx* ctx) {
+    for (auto& p : ctx->pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            bool found = false;
+            for (auto& k : ctx->kstats) if (!strcmp(k.name, p.name)) { k.ms += ms; k.launches++; found = true; break; }
+            if (!found) ctx->kstats.push_back({p.name, (double)ms, 1});
+        }
+        ctx->event_pool.push_back(p.a); ctx->event_pool.push_back(p.b);
+    }
+    ctx->pending.clear();
+}
+
+#define LAUNCH(ctx, name, kernel, grid, block, ...) do { \
+        opusfe::prof_begin(ctx, name); \
+        hipLaunchKernelGGL(kernel, dim3((unsigned)(grid)), dim3((unsigned)(block)), 0, (ctx)->stream, __VA_ARGS__); \
+        opusfe::prof_end(ctx); \
+    } while (0)
+
+inline unsigned grid_for(uint64_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
+
+}  // namespace opusfe

@@ -1,0 +1,154 @@
+// Device-wide order-preserving scans for gfx950 (wave64).  Three-kernel formulation
+// (tile reduce -> scan of tile aggregates -> tile scan with carry-in); the operator only has to be
+// associative (function composition and "last defined value" are not commutative).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace opusfe {
+
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
+
+// shuffle of an arbitrary trivially-copyable T, one dword at a time (ds_bpermute underneath)
+template <class T>
+__device__ __forceinline__ T shfl_up_t(T v, int d) {
+    static_assert(sizeof(T) % 4 == 0, "T must be a multiple of 4 bytes");
+    union { T t; uint32_t w[sizeof(T) / 4]; } a, b;
+    a.t = v;
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; i++) b.w[i] = (uint32_t)__shfl_up((int)a.w[i], d, 64);
+    return b.t;
+}
+
+// wave64 inclusive scan; order preserving.
+template <class T, class Op>
+__device__ __forceinline__ T wave_inclusive_scan(T v, Op op) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        T o = shfl_up_t(v, d);
+        if (lane >= d) v = op(o, v);
+    }
+    return v;
+}
+
+// Block inclusive scan (blockDim.x == SCAN_THREADS, 4 waves).  `lds` must hold 4 T's.
+template <class T, class Op>
+__device__ __forceinline__ T block_inclusive_scan(T v, Op op, T* lds, T* block_total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    T incl = wave_inclusive_scan(v, op);
+    if (lane == 63) lds[wave] = incl;
+    __syncthreads();
+    T carry{};
+    bool have = false;
+    for (int w = 0; w < wave; w++) { carry = have ? op(carry, lds[w]) : lds[w]; have = true; }
+    if (have) incl = op(carry, incl);
+    if (block_total) {
+        T tot = lds[0];
+        for (int w = 1; w < SCAN_THREADS / 64; w++) tot = op(tot, lds[w]);
+        *block_total = tot;
+    }
+    __syncthreads();
+    return incl;
+}
+
+template <class T, class Op>
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_reduce(const T* __restrict__ in, T* __restrict__ tile_agg, uint64_t n, Op op, T identity) {
+    __shared__ T lds[4];
+    uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    T acc = identity;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) if (base + i < n) acc = op(acc, in[base + i]);
+    T total;
+    block_inclusive_scan(acc, op, lds, &total);
+    if (threadIdx.x == 0) tile_agg[blockIdx.x] = total;
+}
+
+// single-block exclusive scan of up to any number of aggregates (loops).
+template <class T, class Op>
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_aggregates(T* __restrict__ agg, uint64_t n, Op op, T identity, T* __restrict__ total_out) {
+    __shared__ T lds[4];
+    __shared__ T wave_last[4];
+    __shared__ T carry_s;
+    if (threadIdx.x == 0) carry_s = identity;
+    __syncthreads();
+    for (uint64_t base = 0; base < n; base += SCAN_TILE) {
+        uint64_t b = base + (uint64_t)threadIdx.x * SCAN_ITEMS;
+        T v[SCAN_ITEMS];
+        T acc = identity;
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; i++) { v[i] = (b + i < n) ? agg[b + i] : identity; acc = op(acc, v[i]); }
+        T total;
+        T incl = block_inclusive_scan(acc, op, lds, &total);
+        // exclusive prefix of this thread = carry ∘ (inclusive of previous thread)
+        T prev = shfl_up_t(incl, 1);
+        if ((threadIdx.x & 63) == 63) wave_last[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        T excl;
+        if (threadIdx.x == 0) excl = carry_s;
+        else if ((threadIdx.x & 63) == 0) excl = op(carry_s, wave_last[(threadIdx.x >> 6) - 1]);
+        else excl = op(carry_s, prev);
+        T run = excl;
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; i++) { if (b + i < n) agg[b + i] = run; run = op(run, v[i]); }
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = op(carry_s, total);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && total_out) *total_out = carry_s;
+}
+
+// exclusive (EXCL) or inclusive scan of a tile with carry-in tile_agg[blockIdx.x] (already exclusive).
+template <bool EXCL, class T, class Op>
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const T* __restrict__ in, T* __restrict__ out, const T* __restrict__ tile_excl, uint64_t n, Op op, T identity) {
+    __shared__ T lds[4];
+    __shared__ T wave_last[4];
+    uint64_t b = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    T v[SCAN_ITEMS];
+    T acc = identity;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) { v[i] = (b + i < n) ? in[b + i] : identity; acc = op(acc, v[i]); }
+    T incl = block_inclusive_scan(acc, op, lds, (T*)nullptr);
+    T prev = shfl_up_t(incl, 1);
+    if ((threadIdx.x & 63) == 63) wave_last[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    T carry = tile_excl[blockIdx.x];
+    T excl;
+    if (threadIdx.x == 0) excl = carry;
+    else if ((threadIdx.x & 63) == 0) excl = op(carry, wave_last[(threadIdx.x >> 6) - 1]);
+    else excl = op(carry, prev);
+    T run = excl;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        if (b + i < n) {
+            if (EXCL) { out[b + i] = run; run = op(run, v[i]); }
+            else { run = op(run, v[i]); out[b + i] = run; }
+        }
+    }
+}
+
+// Scans n elements of `in` into `out` (may alias).  `tmp` must hold ceil(n / SCAN_TILE) T's.
+// `total` (device pointer, may be null) receives the reduction of all elements.
+template <bool EXCL, class T, class Op>
+void device_scan(const T* in, T* out, uint64_t n, Op op, T identity, T* tmp, T* total, hipStream_t stream) {
+    if (n == 0) return;   // caller presets *total
+    uint64_t tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    hipLaunchKernelGGL((k_scan_reduce<T, Op>), dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, stream, in, tmp, n, op, identity);
+    hipLaunchKernelGGL((k_scan_aggregates<T, Op>), dim3(1), dim3(SCAN_THREADS), 0, stream, tmp, tiles, op, identity, total);
+    hipLaunchKernelGGL((k_scan_apply<EXCL, T, Op>), dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, stream, in, out, tmp, n, op, identity);
+}
+
+struct OpAddU32 { __host__ __device__ uint32_t operator()(uint32_t a, uint32_t b) const { return a + b; } };
+struct OpAddI32 { __host__ __device__ int32_t operator()(int32_t a, int32_t b) const { return a + b; } };
+struct OpAddU64 { __host__ __device__ uint64_t operator()(uint64_t a, uint64_t b) const { return a + b; } };
+
+// (ntok, nval, nstr) triple sum
+struct Cnt3 { uint32_t tok, val, str; uint32_t pad; };
+struct OpAddCnt3 { __host__ __device__ Cnt3 operator()(Cnt3 a, Cnt3 b) const { return Cnt3{a.tok + b.tok, a.val + b.val, a.str + b.str, 0}; } };
+
+// "last defined value": element = value | (1 << 31) when defined
+struct OpLast { __host__ __device__ uint32_t operator()(uint32_t a, uint32_t b) const { return (b >> 31) ? b : a; } };
+
+}  // namespace opusfe

@@ -1,0 +1,32 @@
+// One translation unit's results (device-resident; host mirrors are filled lazily for dumps).
+#pragma once
+#include "runtime.h"
+
+struct opusfe_unit {
+    opusfe_ctx* ctx = nullptr;
+    int status = OPUSFE_OK;
+    uint32_t dev_status = 0;
+    // source
+    const uint8_t* d_src = nullptr; bool own_src = false; uint64_t len = 0;
+    std::vector<uint8_t> h_src; bool have_h_src = false;
+    // lexer
+    opusfe_token* d_tokens = nullptr; uint64_t n_tokens = 0;
+    uint64_t* d_val64 = nullptr; uint64_t n_val64 = 0;
+    uint8_t* d_strpool = nullptr; uint64_t n_strpool = 0;
+    uint32_t* d_seg_start = nullptr; uint64_t n_segs = 0;
+    // parser
+    opusfe_node* d_nodes = nullptr; uint64_t node_cap = 0;     // sparse: segment s owns [node_base(s), +count)
+    uint32_t* d_seg_info = nullptr;                            // per segment: node_base, node_count, first_def, def_count, err..., 8 words
+    uint64_t n_nodes = 0, n_defs = 0, n_funcs = 0;
+    uint32_t* d_def_nodes = nullptr;                           // definition index -> root node
+    bool parsed = false;
+    bool has_error = false; opusfe_error error{};
+    // IR
+    bool lowered = false;
+    void* ir = nullptr;                                        // opusfe::IrResult (lower.h)
+    uint64_t n_instrs = 0, n_vars = 0, n_bbs = 0, n_types = 0;
+    // host mirrors
+    std::vector<opusfe_token> h_tokens; std::vector<uint64_t> h_val64; std::vector<uint8_t> h_strpool;
+    std::vector<opusfe_node> h_nodes; std::vector<uint32_t> h_def_nodes;
+    bool have_h_lex = false, have_h_ast = false;
+};

@@ -1,0 +1,199 @@
+"""ctypes binding of libopusfe.so mirroring the reference's frontend.rs seam.
+
+``Context.get_definitions(source)``  <-> frontend.rs:120  get_definitions(compiler, source)
+``Unit.compile_source()``            <-> frontend.rs:140  compile_source (finalize + IrGenerator per function)
+``Unit.dump_ir()``                   <-> the text `opus -Z` prints (generate_ir.rs:1201-1283)
+
+There is no CPU fallback: if the HIP library is missing or no GPU is present the calls raise.
+"""
+import ctypes as C
+import os
+
+OK, SYNTAX, UNSUPPORTED, ERR_HIP, ERR_OOM, ERR_ARG, ERR_INTERNAL, SEMANTIC = range(8)
+_NAMES = ["OK", "SYNTAX", "UNSUPPORTED", "ERR_HIP", "ERR_OOM", "ERR_ARG", "ERR_INTERNAL", "SEMANTIC"]
+
+
+class OpusfeError(RuntimeError):
+    def __init__(self, code, msg=""):
+        super().__init__(f"opusfe: {_NAMES[code] if 0 <= code < len(_NAMES) else code}: {msg}")
+        self.code = code
+
+
+class Token(C.Structure):
+    _fields_ = [("kind", C.c_uint8), ("flags", C.c_uint8), ("aux", C.c_uint16), ("low", C.c_uint32),
+                ("len", C.c_uint32), ("payload", C.c_uint32)]
+
+
+class Error(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("tok_kind", C.c_uint32), ("low", C.c_uint64), ("len", C.c_uint32),
+                ("expected", C.c_uint32), ("payload", C.c_uint64), ("line", C.c_uint64), ("tok_index", C.c_uint32),
+                ("_pad", C.c_uint32)]
+
+
+class Counts(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("source_bytes", "tokens", "nodes", "definitions", "functions", "instrs",
+                                          "vars", "bbs", "types")]
+
+
+def library_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "libopusfe.so")
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise OpusfeError(ERR_HIP, f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = C.CDLL(path)
+        vp, u64, i = C.c_void_p, C.c_uint64, C.c_int
+        L.opusfe_create.argtypes = [C.POINTER(vp), i]
+        L.opusfe_destroy.argtypes = [vp]
+        L.opusfe_last_message.argtypes = [vp]; L.opusfe_last_message.restype = C.c_char_p
+        L.opusfe_stream.argtypes = [vp]; L.opusfe_stream.restype = vp
+        for name in ("opusfe_parse", "opusfe_parse_device"):
+            getattr(L, name).argtypes = [vp, vp, u64, C.POINTER(vp)]
+        for name in ("opusfe_lex", "opusfe_lex_device"):
+            getattr(L, name).argtypes = [vp, vp, u64, i, C.POINTER(vp)]
+        L.opusfe_lower.argtypes = [vp, vp]
+        L.opusfe_unit_status.argtypes = [vp]
+        L.opusfe_get_counts.argtypes = [vp, C.POINTER(Counts)]
+        L.opusfe_get_error.argtypes = [vp, C.POINTER(Error)]
+        L.opusfe_copy_tokens.argtypes = [vp, vp, u64, C.POINTER(u64)]
+        L.opusfe_dump.argtypes = [vp, i, C.POINTER(vp), C.POINTER(u64)]
+        L.opusfe_free_text.argtypes = [vp]
+        L.opusfe_free_unit.argtypes = [vp]
+        L.opusfe_set_profiling.argtypes = [vp, i]
+        L.opusfe_kernel_count.argtypes = [vp]
+        L.opusfe_kernel_info.argtypes = [vp, i, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(u64)]
+        _lib = L
+    return _lib
+
+
+class Unit:
+    """Result of get_definitions for one source (tokens + AST; IR after compile_source)."""
+
+    def __init__(self, ctx, handle, status):
+        self.ctx, self.handle, self.status = ctx, handle, status
+
+    def close(self):
+        if self.handle:
+            if self.ctx.handle:          # a destroyed context has already released everything
+                lib().opusfe_free_unit(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def counts(self):
+        c = Counts()
+        lib().opusfe_get_counts(self.handle, C.byref(c))
+        return {n: getattr(c, n) for n, _ in Counts._fields_}
+
+    def error(self):
+        e = Error()
+        if lib().opusfe_get_error(self.handle, C.byref(e)) != OK:
+            return None
+        return e
+
+    def _dump(self, what):
+        out, n = C.c_void_p(), C.c_uint64()
+        rc = lib().opusfe_dump(self.handle, what, C.byref(out), C.byref(n))
+        if rc != OK:
+            raise OpusfeError(rc, self.ctx.message())
+        try:
+            return C.string_at(out, n.value).decode("utf-8", errors="surrogateescape")
+        finally:
+            lib().opusfe_free_text(out)
+
+    def dump_tokens(self):
+        return self._dump(0)
+
+    def dump_ast(self):
+        return self._dump(1)
+
+    def dump_ir(self):
+        return self._dump(2)
+
+    def dump_error(self):
+        return self._dump(3)
+
+    def compile_source(self):
+        """frontend.rs:140-187, IR part.  Returns the status (OK / SEMANTIC / UNSUPPORTED)."""
+        rc = lib().opusfe_lower(self.ctx.handle, self.handle)
+        if rc not in (OK, SEMANTIC, UNSUPPORTED):
+            raise OpusfeError(rc, self.ctx.message())
+        self.status = rc
+        return rc
+
+    def tokens(self):
+        n = C.c_uint64()
+        lib().opusfe_copy_tokens(self.handle, None, 0, C.byref(n))
+        arr = (Token * n.value)()
+        rc = lib().opusfe_copy_tokens(self.handle, arr, n.value, C.byref(n))
+        if rc != OK:
+            raise OpusfeError(rc, self.ctx.message())
+        return arr
+
+
+class Context:
+    def __init__(self, device=0):
+        h = C.c_void_p()
+        rc = lib().opusfe_create(C.byref(h), device)
+        if rc != OK:
+            raise OpusfeError(rc, "opusfe_create failed (no MI355X visible?)")
+        self.handle = h
+
+    def close(self):
+        if self.handle:
+            lib().opusfe_destroy(self.handle)
+            self.handle = None
+
+    def message(self):
+        return (lib().opusfe_last_message(self.handle) or b"").decode()
+
+    def stream(self):
+        return lib().opusfe_stream(self.handle)
+
+    def _finish(self, rc, out):
+        if rc not in (OK, SYNTAX, UNSUPPORTED):
+            if out.value:
+                lib().opusfe_free_unit(out)
+            raise OpusfeError(rc, self.message())
+        return Unit(self, out, rc)
+
+    def get_definitions(self, source: bytes):
+        """frontend.rs:120 — lex + parse one source held in host memory."""
+        out = C.c_void_p()
+        buf = C.c_char_p(source)
+        return self._finish(lib().opusfe_parse(self.handle, C.cast(buf, C.c_void_p), len(source), C.byref(out)), out)
+
+    def get_definitions_device(self, d_ptr: int, length: int):
+        out = C.c_void_p()
+        return self._finish(lib().opusfe_parse_device(self.handle, C.c_void_p(d_ptr), length, C.byref(out)), out)
+
+    def lex(self, source: bytes, force_dents=False):
+        out = C.c_void_p()
+        buf = C.c_char_p(source)
+        return self._finish(lib().opusfe_lex(self.handle, C.cast(buf, C.c_void_p), len(source), int(force_dents), C.byref(out)), out)
+
+    def lex_device(self, d_ptr: int, length: int, force_dents=False):
+        out = C.c_void_p()
+        return self._finish(lib().opusfe_lex_device(self.handle, C.c_void_p(d_ptr), length, int(force_dents), C.byref(out)), out)
+
+    def set_profiling(self, on=True):
+        lib().opusfe_set_profiling(self.handle, int(on))
+
+    def kernel_stats(self):
+        out = []
+        for k in range(lib().opusfe_kernel_count(self.handle)):
+            name, ms, n = C.c_char_p(), C.c_double(), C.c_uint64()
+            lib().opusfe_kernel_info(self.handle, k, C.byref(name), C.byref(ms), C.byref(n))
+            out.append((name.value.decode(), ms.value, n.value))
+        return out
