@@ -1,0 +1,41 @@
+"""CPU: the C-ABI library loads and exports every symbol include/opusfe.h declares; record layouts match."""
+import ctypes as C
+import os
+import re
+
+import opus_amd
+from opus_amd import frontend as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "opusfe.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(opusfe_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = C.CDLL(opus_amd.library_path())
+    names = declared_functions()
+    assert len(names) >= 19
+    for n in names:
+        assert hasattr(lib, n), f"{n} is declared in include/opusfe.h but not exported"
+
+
+def test_record_sizes_match_the_header():
+    assert C.sizeof(F.Token) == 16
+    assert C.sizeof(F.Error) == 48
+    assert C.sizeof(F.Counts) == 9 * 8
+
+
+def test_no_gpu_means_loud_failure_not_a_cpu_path():
+    import torch
+    if torch.cuda.is_available():
+        return
+    try:
+        opus_amd.Context(0)
+    except opus_amd.OpusfeError as e:
+        assert e.code == F.ERR_HIP
+    else:
+        raise AssertionError("opusfe_create succeeded without a GPU")
