@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py — source MB/s of the opusfe hot path (lex + parse + IR generation) on N MI355X.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W     (N>1: launched by torch.distributed.run)
+One "step" = one pass of the hot path over one synthetic source that is already resident in HBM:
+  opusfe_parse_device (lexer kernels + parser kernels) followed by opusfe_lower (tables + IR kernels),
+  all result arrays left complete in HBM.  Result buffers are released between steps (the library's caching
+  allocator keeps the blocks, so steady-state steps do not call hipMalloc).
+
+Workload (config.workload): BASELINE.json configs[2] — ONE synthetic source of --bytes (default 1e9) per GPU
+produced by the seeded generator G (tools/gen), with the three depth-1000 regions injected.  With N>1 every
+rank owns its own equally sized shard made of whole top-level definitions (weak scaling; SURVEY §8e file/segment
+sharding: no data-path collective); `value` = total source bytes of all ranks / max-over-ranks time.
+
+Extra objects on the JSON line:
+  roofline     — the dominant kernel (largest share of HIP-event time, measured by the library on its own
+                 stream with hipEventRecord around every launch while the timed steps run)
+  cpu_baseline — the C++ CPU restatement (oracle, "port") timed on rank 0's host cores on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+# kernel name -> (stage, which compulsory bytes it is priced against)
+#   lex   kernels read the source once and write the token records:  S + 16 T
+#   parse kernels read tokens and write node records:                16 T + 24 N
+#   lower kernels read nodes and write IR records:                   24 N + 24 I + 8 V
+STAGE_OF = {"lex": ("lex_", "tok_", "scan_cnt3", "scan_depth", "scan_indent", "scan_tokoff", "scan_seg"),
+            "parse": ("parse_", "ast_"), "lower": ("sem_", "lower_", "ir_")}
+
+
+def stage_of(name):
+    for st, prefixes in STAGE_OF.items():
+        if name.startswith(prefixes):
+            return st
+    return "other"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--bytes", type=float, default=1e9, help="source bytes per GPU")
+    ap.add_argument("--seed", type=int, default=3)
+    ap.add_argument("--stage", default="ir", choices=["lex", "parse", "ir"], help="deepest stage to run (default: whole path)")
+    ap.add_argument("--cpu-sample-bytes", type=float, default=48e6)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import opus_amd
+    import oracle_lib as O   # generator (and, on rank 0 at N=1, the oracle as the timed CPU baseline)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    dist = None
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    nbytes = int(args.bytes)
+    threads = min(16, os.cpu_count() or 8)
+    t0 = time.time()
+    src = O.generate(args.seed + 1000 * rank, nbytes, flags=1, threads=max(1, threads // max(1, min(world, 8))) if world > 1 else threads)
+    gen_s = time.time() - t0
+    d_src = torch.empty(nbytes + 64, dtype=torch.uint8, device="cuda")
+    d_src[:nbytes].copy_(torch.frombuffer(bytearray(src), dtype=torch.uint8))
+    torch.cuda.synchronize()
+
+    ctx = opus_amd.Context(local_rank)
+
+    def step():
+        if args.stage == "lex":
+            u = ctx.lex_device(d_src.data_ptr(), nbytes)
+        else:
+            u = ctx.get_definitions_device(d_src.data_ptr(), nbytes)
+        if u.status != opus_amd.OK:
+            raise SystemExit(f"rank {rank}: hot path failed: status {u.status}: {ctx.message()} {u.dump_error() if u.status == 1 else ''}")
+        if args.stage == "ir":
+            rc = u.compile_source()
+            if rc != opus_amd.OK:
+                raise SystemExit(f"rank {rank}: lowering failed: status {rc}: {ctx.message()}")
+        c = u.counts()
+        u.close()
+        return c
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    counts = None
+    for _ in range(args.warmup):
+        counts = step()
+    ctx.set_profiling(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        counts = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    kstats = ctx.kernel_stats()
+    ctx.set_profiling(False)
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    S, T, N = counts["source_bytes"], counts["tokens"], counts["nodes"]
+    I, V = counts["instrs"], counts["vars"]
+    alg = {"lex": S + 16 * T, "parse": 16 * T + 24 * N, "lower": 24 * N + 24 * I + 8 * V, "other": S}
+    total_alg = S + 16 * T + 24 * N + 24 * I + 8 * V
+
+    out = None
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = world * nbytes / 1e6 / (dt / args.steps)
+        kstats.sort(key=lambda k: -k[1])
+        roofline = None
+        if kstats:
+            name, ms, launches = kstats[0]
+            avg_ms = ms / max(1, launches)
+            per_step = launches / args.steps
+            a = alg[stage_of(name)] / max(1.0, per_step) / (avg_ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": name, "achieved": round(a, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(a / HBM_PEAK_GBS, 5), "traffic": None, "avg_ms": round(avg_ms, 4),
+                        "launches_per_step": per_step, "algorithmic_bytes_per_launch": int(alg[stage_of(name)] / max(1.0, per_step))}
+        cpu = None
+        if world == 1 and not args.no_cpu:
+            sample = src[:int(min(args.cpu_sample_bytes, nbytes))]
+            # cut the sample at a top-level definition boundary (a line that starts in column 0 after a newline)
+            cut = len(sample)
+            while cut > 0 and not (sample[cut - 1:cut] == b"\n" and cut < len(src) and src[cut:cut + 1] not in (b"\t", b"\n", b" ", b";")):
+                cut -= 1
+            sample = sample[:cut] if cut > 0 else sample
+            tcpu, c2 = O.time_run(sample, lower=(args.stage == "ir"))
+            cpu = {"value": round(len(sample) / 1e6 / tcpu, 3), "unit": "MB/s", "cores": 1, "kind": "port",
+                   "sample": f"first {len(sample)} bytes of the same source (whole definitions), oracle {'lex+parse+IR' if args.stage == 'ir' else 'lex+parse'}, single thread like the reference; status {c2.status}"}
+        stage_name = {"lex": "lex only (PARTIAL path)", "parse": "lex+parse (PARTIAL path)", "ir": "lex+parse+IR"}[args.stage]
+        out = {"metric": f"source MB/s {stage_name} (whole node)", "value": round(value, 2), "unit": "MB/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+               "config": {"workload": f"C3: one synthetic source of {nbytes} B per GPU, generator G(seed={args.seed}), depth-1000 regions, {world} GPU(s)",
+                          "source_bytes_per_gpu": nbytes, "tokens": T, "nodes": N, "instrs": I, "vars": V,
+                          "functions": counts["functions"], "algorithmic_bytes": total_alg, "sharding": "none" if world == 1 else "independent shards, no collective"},
+               "hbm_gbs_whole_path": round(world * total_alg / (dt / args.steps) / 1e9, 2),
+               "hbm_frac_whole_path": round(total_alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 5),
+               "roofline": roofline, "cpu_baseline": cpu,
+               "kernels": [{"name": n, "ms_per_step": round(ms / args.steps, 4), "launches_per_step": l / args.steps} for n, ms, l in kstats[:24]],
+               "gen_seconds": round(gen_s, 1)}
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -280,6 +280,7 @@ struct Unit {
     std::unique_ptr<Compiler> compiler;
     std::vector<DefBox> definitions;
     std::vector<TokenLogEntry> token_log;     // every fresh lex in reference order
+    bool keep_token_log = true;               // false for timed runs (the log is dump infrastructure, not the path)
     bool has_parse_error = false;
     ParseError parse_error;
     bool unsupported = false;
@@ -298,7 +299,7 @@ struct Unit {
 };
 
 // frontend.rs:120-138 (get_definitions) + 140-187 (compile_source, IR part)
-std::unique_ptr<Unit> run(const char* src, size_t len, bool lower);
+std::unique_ptr<Unit> run(const char* src, size_t len, bool lower, bool keep_token_log = true);
 
 std::string dump_tokens(const Unit& u);
 std::string dump_ast(const Unit& u);

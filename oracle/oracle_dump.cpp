@@ -406,7 +406,7 @@ void oracle_free(char* p) { free(p); }
 // Returns seconds.
 double oracle_time(const char* src, uint64_t len, int lower, oracle_counts* counts) {
     auto t0 = std::chrono::steady_clock::now();
-    auto u = oracle::run(src, len, lower != 0);
+    auto u = oracle::run(src, len, lower != 0, false);
     auto t1 = std::chrono::steady_clock::now();
     if (counts) {
         counts->tokens = u->n_tokens; counts->nodes = u->n_nodes; counts->instrs = u->n_instrs; counts->vars = u->n_vars;

@@ -732,14 +732,14 @@ void generate_ir(Unit& u) {
     }
 }
 
-std::unique_ptr<Unit> run(const char* src, size_t len, bool lower) {
+std::unique_ptr<Unit> run(const char* src, size_t len, bool lower, bool keep_token_log) {
     auto u = std::make_unique<Unit>();
+    u->keep_token_log = keep_token_log;
     u->source.assign(src, len);
     u->compiler = std::make_unique<Compiler>();
     u->compiler->src_base = u->source.data();
     u->compiler->src_len = len;
     get_definitions(*u);
-    u->n_tokens = u->token_log.size();
     if (u->has_parse_error || u->unsupported) return u;
     for (auto& d : u->definitions) u->compiler->preload_definition(*d);   // frontend.rs:98
     if (lower) {

@@ -164,7 +164,9 @@ struct Parser {
     // parse.rs:730-733
     Span char_at(size_t pos) const { size_t n; decode(pos, &n); return Span{pos, n}; }
 
+    uint64_t n_tokens = 0;
     void log_token(size_t low, const Token& t) {
+        n_tokens++;
         if (log) { TokenLogEntry e; e.low = low; e.high = real_position; e.is_error = false; e.token = t; log->push_back(std::move(e)); }
     }
 
@@ -248,6 +250,7 @@ Token Parser::parse_token() {
         if (fresh) log_token(token_low, t);
         return t;
     } catch (ParseError& e) {
+        n_tokens++;
         if (log) { TokenLogEntry le; le.low = token_low; le.high = real_position; le.is_error = true; le.error = e; log->push_back(std::move(le)); }
         (void)before;
         throw;
@@ -814,7 +817,7 @@ FunctionSignature Parser::parse_function_signature() {
 // frontend.rs:120-138
 void get_definitions(Unit& u) {
     Parser parser(*u.compiler, std::string_view(u.source));
-    parser.log = &u.token_log;
+    parser.log = u.keep_token_log ? &u.token_log : nullptr;
     try {
         while (!parser.is_at_end_of_file()) {
             u.definitions.push_back(parser.parse_definition());
@@ -826,6 +829,7 @@ void get_definitions(Unit& u) {
         u.unsupported = true; u.unsupported_why = e.why; u.unsupported_at = e.at;
     }
     u.n_nodes = parser.n_nodes;
+    u.n_tokens = parser.n_tokens;
 }
 
 // KAT-L mode: the lexer alone, parse_token called repeatedly with
