@@ -16,7 +16,7 @@ using namespace opusfe;
 namespace {
 
 // status / totals block layout (uint32 words) inside ctx->d_status
-enum { W_STATUS = 0, W_LEXTOT = 4 /* Cnt3: 4 words */, W_FINTOK = 8, W_NSEG = 9, W_PARSE = 16, W_LOWER = 32 };
+enum { W_STATUS = 0, W_UNSUP_POS = 1, W_LEXTOT = 4 /* Cnt3: 4 words */, W_FINTOK = 8, W_NSEG = 9, W_PARSE = 16, W_LOWER = 32 };
 
 int fail(opusfe_ctx* ctx, int code, const std::string& msg) { if (ctx) ctx->msg = msg; return code; }
 
@@ -52,6 +52,7 @@ void run_lexer(opusfe_ctx* ctx, opusfe_unit* u, int force_dents) {
     hipStream_t st = ctx->stream;
     TempList tmp(ctx);
     HIP_TRY(hipMemsetAsync(ctx->d_status, 0, 64 * sizeof(uint32_t), st));
+    HIP_TRY(hipMemsetAsync(ctx->d_status + W_UNSUP_POS, 0xFF, sizeof(uint32_t), st));
     uint32_t* status = ctx->d_status + W_STATUS;
 
     const uint64_t nchunks = ((uint64_t)n + LEX_CHUNK - 1) / LEX_CHUNK;
@@ -120,6 +121,7 @@ void run_lexer(opusfe_ctx* ctx, opusfe_unit* u, int force_dents) {
     fetch_status(ctx);
     u->n_segs = T > 0 ? ctx->h_status[W_NSEG] : 0;
     u->dev_status = ctx->h_status[W_STATUS];
+    u->unsup_pos = ctx->h_status[W_UNSUP_POS];
     u->status = status_to_code(u->dev_status);
     if (u->status != OPUSFE_OK) ctx->msg = status_text(u->dev_status);
 }
@@ -229,8 +231,11 @@ static int with_host_source(opusfe_ctx* ctx, const uint8_t* src, uint64_t len, o
 static int body_lex(opusfe_ctx* ctx, opusfe_unit* u, int force_dents) { run_lexer(ctx, u, force_dents); return u->status; }
 static int body_parse(opusfe_ctx* ctx, opusfe_unit* u, int) {
     run_lexer(ctx, u, 0);
-    if (u->status != OPUSFE_OK) return u->status;
+    if (u->status != OPUSFE_OK && u->status != OPUSFE_UNSUPPORTED) return u->status;
+    // an input the lexer cannot follow the reference on is still parsed: a syntax error that the
+    // reference reports BEFORE reaching that byte wins (run_parser decides with u->unsup_pos)
     run_parser(ctx, u);
+    if (u->status != OPUSFE_OK) ctx->msg = u->status == OPUSFE_UNSUPPORTED ? status_text(u->dev_status) : u->status == OPUSFE_SYNTAX ? "syntax error" : ctx->msg;
     return u->status;
 }
 

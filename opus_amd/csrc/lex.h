@@ -128,6 +128,10 @@ struct LexTok {
     uint32_t strbytes;        // pool bytes incl. the 4-byte length prefix, padded to 4
 };
 
+// records an input the reference cannot be followed on (code: max wins) and where it starts (min wins):
+// the host reports OPUSFE_UNSUPPORTED only if no syntax error is found before that position.
+__device__ __forceinline__ void lx_unsupported(uint32_t* status, uint32_t code, uint32_t pos) { atomicMax(status, code); atomicMin(status + 1, pos); }
+
 __device__ __forceinline__ int lx_at(const uint8_t* __restrict__ s, uint32_t n, uint32_t i) { return i < n ? (int)s[i] : -1; }
 __device__ __forceinline__ bool lx_is_ws(int c) { return c == ' ' || (c >= 9 && c <= 13); }
 __device__ __forceinline__ bool lx_is_digit(int c) { return c >= '0' && c <= '9'; }
@@ -238,18 +242,18 @@ __device__ void lex_one(const uint8_t* __restrict__ s, uint32_t n, uint32_t pos,
             } else {
                 // trailing zeros in the fraction do not change the value: retry without them
                 // (keeps "1.50000000000000000000000" exact); otherwise unsupported for now.
-                atomicMax(status, (uint32_t)DS_UNSUPPORTED_FLOAT);
+                lx_unsupported(status, DS_UNSUPPORTED_FLOAT, pos);
             }
             o.kind = T_Float; o.nval = 1; o.v0 = (uint64_t)__double_as_longlong(f);
             if (lx_at(s, n, p) == 'f') {
                 // parse.rs:563-581: after 'f' two advance()s regardless
                 int a = lx_at(s, n, p + 1), b = a < 0 ? -1 : lx_at(s, n, p + 2);
-                if (a >= 0x80 || b >= 0x80) atomicMax(status, (uint32_t)DS_UNSUPPORTED_NONASCII);
+                if (a >= 0x80 || b >= 0x80) lx_unsupported(status, DS_UNSUPPORTED_NONASCII, pos);
                 if (a == '3' && b == '2') { o.aux = 32; p += 3; }
                 else if (a == '6' && b == '4') { o.aux = 64; p += 3; }
                 else if (a >= 0 && b < 0) { lx_error(o, PE_InvalidNumericSize, pos, p + 2 - pos, (uint32_t)a - (uint32_t)'0', p + 2); if (!lx_is_run(a)) o.flags |= OPUSFE_TF_RESYNC; return; }
                 else if (a >= 0 && b >= 0) { lx_error(o, PE_InvalidNumericSize, pos, p + 3 - pos, ((uint32_t)a - (uint32_t)'0') * 10u + ((uint32_t)b - (uint32_t)'0'), p + 3); if (!lx_is_run(a) || !lx_is_run(b)) o.flags |= OPUSFE_TF_RESYNC; return; }
-                else { atomicMax(status, (uint32_t)DS_UNSUPPORTED_HANG); p += 1; }   // `<float>f<EOF>`: the reference loops forever (Q4)
+                else { lx_unsupported(status, DS_UNSUPPORTED_HANG, pos); p += 1; }   // `<float>f<EOF>`: the reference loops forever (Q4)
             }
             o.end = p;
             return;
@@ -280,7 +284,7 @@ __device__ void lex_one(const uint8_t* __restrict__ s, uint32_t n, uint32_t pos,
         uint32_t h = (2166136261u ^ (uint32_t)c) * 16777619u;
         for (;;) {
             int d = lx_at(s, n, p);
-            if (d >= 0x80) { atomicMax(status, (uint32_t)DS_UNSUPPORTED_NONASCII); break; }
+            if (d >= 0x80) { lx_unsupported(status, DS_UNSUPPORTED_NONASCII, p); break; }
             if (!lx_is_identc(d)) break;
             if (p - pos < 8) w |= (uint64_t)d << (8 * (p - pos));
             h = (h ^ (uint32_t)d) * 16777619u;
@@ -292,13 +296,14 @@ __device__ void lex_one(const uint8_t* __restrict__ s, uint32_t n, uint32_t pos,
         return;
     }
     if (c == '"') {
-        // parse.rs:674-717
+        // parse.rs:674-717.  A string that ends in a lexical error still reserves the pool bytes it wrote
+        // (strbytes) so that the emit pass, which decodes straight into the pool, stays inside its slice.
         uint32_t p = pos + 1;
         uint32_t nout = 0;
         uint8_t* dst = strdst ? strdst + 4 : nullptr;
         for (;;) {
             int ch = lx_at(s, n, p);
-            if (ch < 0) { lx_error(o, PE_UnexpectedEndOfFile, n, 0, 0, n); return; }
+            if (ch < 0) { lx_error(o, PE_UnexpectedEndOfFile, n, 0, 0, n); o.strbytes = 4 + ((nout + 3) & ~3u); return; }
             if (ch == '"') { p++; break; }
             if (ch == '\\') {
                 uint32_t escape_position = p + 1;
@@ -321,13 +326,15 @@ __device__ void lex_one(const uint8_t* __restrict__ s, uint32_t n, uint32_t pos,
                     if (q2 > n) q2 = n;
                     lx_error(o, PE_InvalidEscapeSequence, escape_position, q2 - escape_position, 0, lx_string_end(s, n, p));
                     o.flags |= OPUSFE_TF_RESYNC;
+                    o.strbytes = 4 + ((nout + 3) & ~3u);
                     return;
                 }
-                if (e < 0) { lx_error(o, PE_UnexpectedEndOfFile, n, 0, 0, n); return; }
+                if (e < 0) { lx_error(o, PE_UnexpectedEndOfFile, n, 0, 0, n); o.strbytes = 4 + ((nout + 3) & ~3u); return; }
                 uint32_t el = lx_utf8_len(e);
                 if (escape_position + el > n) el = n - escape_position;
                 lx_error(o, PE_InvalidEscapeSequence, escape_position, el, 0, lx_string_end(s, n, p));
                 o.flags |= OPUSFE_TF_RESYNC;
+                o.strbytes = 4 + ((nout + 3) & ~3u);
                 return;
             }
             if (dst) dst[nout] = (uint8_t)ch;
@@ -338,7 +345,7 @@ __device__ void lex_one(const uint8_t* __restrict__ s, uint32_t n, uint32_t pos,
         if (strdst) { *reinterpret_cast<uint32_t*>(strdst) = nout; for (uint32_t k = nout; k < ((nout + 3) & ~3u); k++) dst[k] = 0; }
         return;
     }
-    if (c >= 0x80) { atomicMax(status, (uint32_t)DS_UNSUPPORTED_NONASCII); }
+    if (c >= 0x80) { lx_unsupported(status, DS_UNSUPPORTED_NONASCII, pos); }
     lx_error(o, PE_UnexpectedCharacter, pos, 1, (uint64_t)c, pos + 1);
 }
 

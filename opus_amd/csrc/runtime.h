@@ -9,6 +9,12 @@
 #include <vector>
 #include "defs.h"
 
+#ifdef OPUSFE_EMU
+// tests/emu: the device code is compiled for the host by g++ (sanitizers, gdb); no HIP runtime exists there
+struct opusfe_ctx { int device = 0; };
+#define HIP_TRY(expr) do { } while (0)
+#else
+
 struct opusfe_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -110,3 +116,4 @@ inline void prof_collect(opusfe_ctx* ctx) {
 inline unsigned grid_for(uint64_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
 
 }  // namespace opusfe
+#endif  // OPUSFE_EMU

@@ -20,7 +20,8 @@ struct opusfe_unit {
     uint64_t n_nodes = 0, n_defs = 0, n_funcs = 0;
     uint32_t* d_def_nodes = nullptr;                           // definition index -> root node
     bool parsed = false;
-    bool has_error = false; opusfe_error error{};
+    bool has_error = false; opusfe_error error{}; uint32_t err_seg = 0;
+    uint32_t unsup_pos = 0xFFFFFFFFu;                          // first byte the reference cannot be followed on (lexer)
     // IR
     bool lowered = false;
     void* ir = nullptr;                                        // opusfe::IrResult (lower.h)

@@ -1,0 +1,209 @@
+// TEST INFRASTRUCTURE: host emulation of the opusfe device code (see fake/hip/hip_runtime.h).
+// Runs the REAL kernel bodies of opus_amd/csrc (lex_one / lex_chunk, the token-level kernels, the
+// segment parser, the lowering kernels) lane by lane on the CPU under AddressSanitizer so that
+// indexing bugs are found here and not as GPU memory faults.  The sequencing below mirrors
+// run_lexer / run_parser / run_lower of the product with every device-wide scan replaced by a
+// sequential loop.  It is never part of the product and is not a CPU fallback.
+#define OPUSFE_EMU 1
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+#include "defs.h"
+#include "runtime.h"
+#include "unit.h"
+#include "scan.h"
+#include "lex.h"
+#include "parse.h"
+#include "dump.h"
+#include "dump_ast.h"
+#ifdef OPUSFE_EMU_LOWER
+#include "lower.h"
+#include "dump_ir.h"
+#endif
+
+using namespace opusfe;
+
+namespace {
+
+inline unsigned grid_for(uint64_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
+
+struct EmuUnit {
+    opusfe_unit u;
+    std::vector<uint8_t> src;
+    std::vector<uint32_t> seg_start;
+    std::vector<uint32_t> seg_info;
+    uint32_t status[64] = {0};
+};
+
+void emu_lex(EmuUnit& E, int force_dents) {
+    const uint8_t* src = E.src.data();
+    const uint32_t n = (uint32_t)E.u.len;
+    uint32_t* status = E.status;
+    memset(status, 0, sizeof E.status);
+    status[1] = 0xFFFFFFFFu;
+    // count pass / emit pass exactly like k_lex_count / k_lex_emit, with exact-size heap blocks so that
+    // AddressSanitizer sees any write outside a token's reserved pool slice
+    std::vector<uint8_t> chunk_state;
+    Cnt3 tot{0, 0, 0, 0};
+    {
+        uint32_t state = CS_N;
+        for (uint64_t cb = 0; cb < n; cb += LEX_CHUNK) {
+            uint32_t cbeg = (uint32_t)cb, cend = (uint32_t)((cb + LEX_CHUNK < n) ? cb + LEX_CHUNK : n);
+            chunk_state.push_back((uint8_t)state);
+            lex_chunk(src, n, cbeg, cend, state, status, [&](uint32_t pos) {
+                LexTok t;
+                lex_one(src, n, pos, t, nullptr, status);
+                tot.tok++; tot.val += t.nval; tot.str += t.strbytes;
+                return t.end;
+            });
+            for (uint32_t p = cbeg; p < cend; p++) state = ctx_apply(ctx_of_byte(src[p]), state);
+        }
+    }
+    opusfe_token* raw_p = (opusfe_token*)malloc(sizeof(opusfe_token) * (tot.tok ? tot.tok : 1));
+    uint64_t* val_p = (uint64_t*)malloc(8 * (tot.val ? tot.val : 1));
+    uint8_t* pool_p = (uint8_t*)malloc(tot.str ? tot.str : 1);
+    {
+        uint32_t ti = 0, vi = 0, si = 0, c = 0;
+        for (uint64_t cb = 0; cb < n; cb += LEX_CHUNK, c++) {
+            uint32_t cbeg = (uint32_t)cb, cend = (uint32_t)((cb + LEX_CHUNK < n) ? cb + LEX_CHUNK : n);
+            lex_chunk(src, n, cbeg, cend, chunk_state[c], status, [&](uint32_t pos) {
+                LexTok t;
+                lex_one(src, n, pos, t, pool_p + si, status);
+                opusfe_token o;
+                o.kind = t.kind; o.flags = t.flags; o.aux = t.aux; o.low = t.low; o.len = t.end - t.low;
+                if (t.kind == T_Error) { o.low = pos; o.payload = vi; }
+                else if (t.kind == T_String) o.payload = si;
+                else if (t.nval) o.payload = vi;
+                else o.payload = t.payload;
+                if (t.nval >= 1) val_p[vi] = t.v0;
+                if (t.nval >= 2) val_p[vi + 1] = t.v1;
+                vi += t.nval; si += t.strbytes;
+                raw_p[ti++] = o;
+                return t.end;
+            });
+        }
+        if (ti != tot.tok || vi != tot.val || si != tot.str) { fprintf(stderr, "emu: count/emit mismatch\n"); abort(); }
+    }
+    std::vector<opusfe_token> raw(raw_p, raw_p + tot.tok);
+    E.u.h_val64.assign(val_p, val_p + tot.val);
+    E.u.h_strpool.assign(pool_p, pool_p + tot.str);
+    free(raw_p); free(val_p); free(pool_p);
+    const uint32_t T = (uint32_t)raw.size();
+    const uint64_t G = (uint64_t)T + 1;
+    std::vector<int32_t> depth(G);
+    std::vector<uint32_t> gapval(G), prev(G), cnt(G), out_off(G), seg_flag(G), seg_excl(G);
+    if (T) {
+        emu_launch(k_tok_delta, grid_for(T, 256), 256, raw.data(), T, depth.data(), force_dents);
+        for (uint32_t k = 1; k < T; k++) depth[k] += depth[k - 1];
+    }
+    emu_launch(k_gap, grid_for(G, 256), 256, src, n, raw.data(), T, depth.data(), gapval.data());
+    { uint32_t run = 0; for (uint64_t k = 0; k < G; k++) { prev[k] = run; run = OpLast()(run, gapval[k]); } }
+    emu_launch(k_dent_count, grid_for(G, 256), 256, gapval.data(), prev.data(), T, cnt.data());
+    uint32_t total = 0;
+    for (uint64_t k = 0; k < G; k++) { out_off[k] = total; total += cnt[k]; }
+    E.u.h_tokens.assign(total, opusfe_token{});
+    emu_launch(k_final, grid_for(G, 256), 256, raw.data(), T, n, gapval.data(), prev.data(), out_off.data(), E.u.h_tokens.data(), seg_flag.data());
+    uint32_t nseg = 0;
+    for (uint32_t k = 0; k < T; k++) { seg_excl[k] = nseg; nseg += seg_flag[k]; }
+    E.seg_start.assign((size_t)T + 1, 0);
+    if (T) emu_launch(k_seg_starts, grid_for(T, 256), 256, seg_flag.data(), seg_excl.data(), out_off.data(), cnt.data(), T, E.seg_start.data());
+    E.u.n_tokens = total; E.u.n_segs = nseg; E.u.n_val64 = E.u.h_val64.size(); E.u.n_strpool = E.u.h_strpool.size();
+    E.u.have_h_lex = true; E.u.have_h_src = true;
+    E.u.dev_status = status[0]; E.u.unsup_pos = status[1];
+    E.u.status = status[0] == DS_OK ? OPUSFE_OK : status[0] >= DS_INTERNAL_CAPACITY ? OPUSFE_ERR_INTERNAL : OPUSFE_UNSUPPORTED;
+}
+
+void emu_parse(EmuUnit& E) {
+    opusfe_unit& u = E.u;
+    const uint32_t n_segs = (uint32_t)u.n_segs, n_tok = (uint32_t)u.n_tokens;
+    u.parsed = true; u.n_nodes = u.n_defs = 0;
+    if (n_segs == 0) { if (u.status == OPUSFE_OK || E.status[0] == DS_OK) u.status = E.status[0] == DS_OK ? OPUSFE_OK : OPUSFE_UNSUPPORTED; return; }
+    // exact-size scratch so that AddressSanitizer sees every overrun
+    std::vector<opusfe_node> sparse(2ull * n_tok + 8ull * n_segs + 8);
+    std::vector<PFrame> frames(2ull * n_tok + 16ull * n_segs + 16);
+    E.seg_info.assign((size_t)n_segs * SI_WORDS, 0);
+    uint32_t first_err = 0xFFFFFFFFu;
+    emu_launch(k_parse_segments, grid_for(n_segs, 64), 64, u.h_tokens.data(), n_tok, E.seg_start.data(), n_segs, sparse.data(), frames.data(),
+               E.seg_info.data(), E.status, &first_err);
+    if (getenv("EMU_VERBOSE")) for (uint32_t s = 0; s < n_segs; s++) { uint32_t k = E.seg_info[(size_t)s * SI_WORDS + SI_ERR_KIND]; if (k != OPUSFE_NONE && (k & 0x200u)) fprintf(stderr, "segment %u of %u: internal condition %u (first error segment %u)\n", s, n_segs, k & 0xFF, first_err); }
+    std::vector<Cnt2> cnt(n_segs);
+    emu_launch(k_ast_counts, grid_for(n_segs, 256), 256, E.seg_info.data(), n_segs, cnt.data());
+    Cnt2 run{0, 0};
+    for (uint32_t s = 0; s < n_segs; s++) { Cnt2 c = cnt[s]; cnt[s] = run; run = OpAddCnt2()(run, c); }
+    u.n_nodes = run.nodes; u.n_defs = run.defs;
+    const uint32_t dev_status = E.status[0];
+    if (first_err != 0xFFFFFFFFu) {
+        const uint32_t* si = E.seg_info.data() + (size_t)first_err * SI_WORDS;
+        const opusfe_token& t = u.h_tokens[si[SI_ERR_TOK]];
+        opusfe_error e{};
+        e.tok_index = si[SI_ERR_TOK];
+        if (si[SI_ERR_KIND] & 0x200u) { u.status = OPUSFE_ERR_INTERNAL; u.dev_status = si[SI_ERR_KIND] & 0xFFu; return; }
+        if (si[SI_ERR_KIND] & 0x100u) {
+            uint64_t v0 = u.h_val64[t.payload], v1 = u.h_val64[t.payload + 1];
+            e.kind = si[SI_ERR_KIND] & 0xFFu; e.low = (uint32_t)v0; e.len = (uint32_t)(v0 >> 32); e.payload = v1; e.tok_kind = T_Error;
+        } else { e.kind = si[SI_ERR_KIND]; e.low = si[SI_ERR_LOW]; e.len = si[SI_ERR_LEN]; e.expected = si[SI_ERR_EXPECTED]; e.tok_kind = t.kind; }
+        const uint32_t unsup_pos = E.status[1];
+        if (unsup_pos < t.low + t.len || (t.kind == T_Error && unsup_pos <= t.low)) { u.status = OPUSFE_UNSUPPORTED; u.dev_status = dev_status; return; }
+        uint32_t lines = 0;
+        for (uint64_t p = 0; p < e.low && p < u.len; p++) lines += E.src[p] == '\n';   // k_count_newlines is a shuffle reduction
+        e.line = 1 + lines;
+        u.error = e; u.has_error = true; u.err_seg = first_err; u.status = OPUSFE_SYNTAX; u.dev_status = DS_OK;
+        return;
+    }
+    if (dev_status != DS_OK) { u.status = OPUSFE_UNSUPPORTED; u.dev_status = dev_status; return; }
+    u.h_nodes.assign(u.n_nodes, opusfe_node{}); u.h_def_nodes.assign(u.n_defs, 0);
+    emu_launch(k_ast_compact, 2, 256, sparse.data(), E.seg_start.data(), n_segs, E.seg_info.data(), cnt.data(), u.h_nodes.data(), u.h_def_nodes.data());
+    u.have_h_ast = true;
+    u.status = OPUSFE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// what: 0 tokens, 1 AST, 3 error line, 5 lexer alone (force_dents).  *status receives the OPUSFE_* code.
+char* emu_dump(const uint8_t* src, uint64_t len, int what, uint64_t* out_len, int* status) {
+    EmuUnit E;
+    E.src.assign(src, src + len);
+    E.src.resize(len + 16, 0);          // the product pads device sources the same way
+    E.u.len = len;
+    E.u.h_src.assign(src, src + len);
+    emu_lex(E, what == 5);
+    if (what != 5 && (E.u.status == OPUSFE_OK || E.u.status == OPUSFE_UNSUPPORTED)) emu_parse(E);
+    std::string s;
+    switch (what) {
+        case 0: case 5: s = dump_tokens(&E.u, E.u.has_error ? (uint64_t)E.u.error.tok_index + 1 : ~0ull); break;
+        case 1: s = E.u.status == OPUSFE_OK ? dump_ast(&E.u) : std::string(); break;
+        case 3: s = E.u.status == OPUSFE_ERR_INTERNAL ? std::string("Internal\n") : dump_error_line(&E.u); break;
+        default: break;
+    }
+    if (status) *status = E.u.status;
+    if (out_len) *out_len = s.size();
+    char* p = (char*)malloc(s.size() + 1);
+    memcpy(p, s.data(), s.size()); p[s.size()] = 0;
+    return p;
+}
+void emu_free(char* p) { free(p); }
+
+}
+
+#ifdef EMU_MAIN
+#include <fstream>
+#include <sstream>
+// emu_cli <what> <file>   -> dump on stdout, "status N" on stderr
+int main(int argc, char** argv) {
+    if (argc < 3) { fprintf(stderr, "usage: emu_cli <what> <file>...\n"); return 2; }
+    int what = atoi(argv[1]);
+    for (int a = 2; a < argc; a++) {
+        std::ifstream f(argv[a], std::ios::binary);
+        std::stringstream ss; ss << f.rdbuf();
+        std::string src = ss.str();
+        uint64_t n; int status;
+        char* s = emu_dump((const uint8_t*)src.data(), src.size(), what, &n, &status);
+        printf("== %s status %d bytes %llu\n", argv[a], status, (unsigned long long)n);
+        fwrite(s, 1, n, stdout);
+        emu_free(s);
+    }
+    return 0;
+}
+#endif

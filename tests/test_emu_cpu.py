@@ -1,0 +1,64 @@
+"""CPU: the REAL device code (opus_amd/csrc kernels' bodies) compiled for the host with g++ under
+AddressSanitizer/UBSan (tests/emu) and compared bit-exactly with the oracle.  This is how indexing bugs are
+found before a kernel ever runs on a GPU (a faulting kernel can reset a whole node); it is test
+infrastructure, not a CPU path of the product."""
+import pytest
+
+import emu_lib as E
+import oracle_lib as O
+from cases import LEX_CASES, PARSE_CASES
+
+
+def compare_parse(cases):
+    errs = E.dump_many(cases, 3)
+    asts = E.dump_many(cases, 1)
+    toks = E.dump_many(cases, 0)
+    for c, (st, e), (_, a), (_, t) in zip(cases, errs, asts, toks):
+        want = O.dump(c, O.ERROR)
+        if st == 2 and want != "Unsupported\n":
+            assert b"\\q" in c or b"\\x" in c or b"\\" in c, (c[:80], want)   # documented: swallowed bad escape
+            continue
+        assert e == want, (c[:80], e, want)
+        if want == "Ok\n":
+            assert a == O.dump(c, O.AST), c[:80]
+            assert t == O.dump(c, O.TOKENS), c[:80]
+
+
+def test_emu_lexer_alone():
+    cases = [s.encode() for s in LEX_CASES]
+    got = E.dump_many(cases, 5)
+    for c, (st, g) in zip(cases, got):
+        want = O.dump(c, O.LEX)
+        if want == "Unsupported\n":
+            assert st == 2
+            continue
+        if "Err(InvalidEscapeSequence" in want:
+            w, gl = want.split("\n"), g.split("\n")
+            k = next(i for i, l in enumerate(w) if "Err(InvalidEscapeSequence" in l)
+            assert gl[:k] == w[:k]
+            continue
+        assert g == want, c
+
+
+def test_emu_parser_hand_cases():
+    compare_parse([s.encode() for s in PARSE_CASES])
+
+
+def test_emu_parser_generated_and_deep():
+    compare_parse([O.generate(1, 4096), O.generate(2, 70000), O.generate(3, 2 << 20, flags=1)])
+
+
+def test_emu_parser_injected_faults():
+    cases = []
+    for kind in range(10):
+        base = O.generate(40 + kind, 20000)
+        for s in range(6):
+            bad = O.inject(base, 1000 * kind + s, kind)
+            if bad:
+                cases.append(bad)
+    compare_parse(cases)
+
+
+def test_emu_parser_truncations():
+    src = O.generate(77, 1500)
+    compare_parse([src[:n] for n in range(0, len(src), 5)])

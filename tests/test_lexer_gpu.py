@@ -5,12 +5,7 @@ import oracle_lib as O
 
 pytestmark = pytest.mark.gpu
 
-KAT_L = ["5s", "5i8", "5n", "5i80", "5in", "7i12", "1.5f32", "2.", "1..2", "a\\b", '"a\\x41\\n"', "x<=y", "; c\n\tfoo",
-         "123abc", "", " ", "\n", "\t", "\tfoo", " \tfoo", "\t; c\n\tfoo", "a\n\tb\n\t\tc\nd", "a\n\tb\n\t\tc", "==== <== >== =<=",
-         "5.foo", "5i7", "5i", "12n16x", "0.5f64+1", "x\n\n\n\ty\n ; c\n\tz\n", '"unterminated', '"bad \\q esc" x', '"\\x4"',
-         "a#b", "#", "foo(\n\tbar,\n\tbaz)\n", "a;b\nc", '"a;b" ; "c"\nd', "a\r\n\tb\r\n", "\x0b\x0cfoo",
-         "18446744073709551616 4294967296 4294967295", "1.25 0.1 123456.789 3.0f32",
-         "x" * 200, "ab " * 100, '"' + "s" * 300 + '" tail', "; " + "c" * 300 + "\nafter", "1" * 70]
+from cases import LEX_CASES as KAT_L
 
 
 @pytest.mark.parametrize("src", KAT_L)
