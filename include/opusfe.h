@@ -112,13 +112,17 @@ int opusfe_lex(opusfe_ctx* ctx, const uint8_t* src, uint64_t len, int force_dent
 /* ---- seam B: AST -> IR (frontend.rs:140 compile_source, IR part) ---- */
 int opusfe_lower(opusfe_ctx* ctx, opusfe_unit* unit);
 
+/* number of semantic errors (compile.rs:124-152) reported by finalize / IR generation of the unit; IR generated while
+   errors were reported contains Error instructions exactly like the reference's (compile.rs:777-780) */
+int opusfe_semantic_error_count(const opusfe_unit* unit, uint64_t* n);
+
 /* ---- results ---- */
 int opusfe_unit_status(const opusfe_unit* unit);           /* OPUSFE_OK / _SYNTAX / _UNSUPPORTED ... of the unit */
 int opusfe_get_counts(const opusfe_unit* unit, opusfe_counts* out);
 int opusfe_get_error(const opusfe_unit* unit, opusfe_error* out);
 /* copies device result arrays to caller-provided host buffers (cap in elements); returns element count via *n */
 int opusfe_copy_tokens(opusfe_unit* unit, opusfe_token* dst, uint64_t cap, uint64_t* n);
-/* canonical text dumps (formats: SURVEY.md §8c).  what: 0 tokens, 1 AST, 2 IR, 3 first-error line.
+/* canonical text dumps (formats: SURVEY.md §8c).  what: 0 tokens, 1 AST, 2 IR, 3 first-error line, 4 semantic errors of IR generation.
    *out is malloc'ed by the library; release with opusfe_free_text. */
 int opusfe_dump(opusfe_unit* unit, int what, char** out, uint64_t* out_len);
 void opusfe_free_text(char* p);

@@ -262,6 +262,12 @@ int opusfe_lower(opusfe_ctx* ctx, opusfe_unit* unit) {
     return guarded(ctx, [&] { run_lower(ctx, unit); return unit->status; });
 }
 
+int opusfe_semantic_error_count(const opusfe_unit* u, uint64_t* n) {
+    if (!u || !n) return OPUSFE_ERR_ARG;
+    *n = u->ir ? ((const IrResult*)u->ir)->n_sem_errors : 0;
+    return OPUSFE_OK;
+}
+
 int opusfe_unit_status(const opusfe_unit* unit) { return unit ? unit->status : OPUSFE_ERR_ARG; }
 
 int opusfe_get_counts(const opusfe_unit* u, opusfe_counts* out) {
@@ -303,7 +309,8 @@ int opusfe_dump(opusfe_unit* u, int what, char** out, uint64_t* out_len) {
                 break;
             }
             case 1: ensure_host_ast(u); s = dump_ast(u); break;
-            case 2: s = dump_ir(u); break;
+            case 2: ensure_host_ast(u); ensure_host_ir(u); s = dump_ir(u); break;
+            case 4: ensure_host_ir(u); s = dump_semantic_errors(u); break;
             case 3: s = dump_error_line(u); break;
             default: return (int)OPUSFE_ERR_ARG;
         }

@@ -1,4 +1,1219 @@
+// IR generation on the GPU.  Restates generate_ir.rs (IrGenerator, :75-1199) as an explicit-stack machine:
+// one lane lowers one function (functions only depend on the global tables of sem.h, SURVEY §7 hard part 3).
+//
+// Emission order is the reference's: variables are numbered in creation order, basic blocks in creation order,
+// and every instruction is tagged (bb, rank-in-bb) at push time — deferred terminators (`bbs[branch].push(..)`,
+// generate_ir.rs:310-312,357-359) simply take the next rank of their block — so that the compaction kernel can
+// scatter instructions into the final bb-major layout in parallel.
+//
+//   k_lower_functions : AST + tables -> per-function sparse regions (variables, instructions, bbs, local types,
+//                       call-argument pool) + counts
+//   scans             : dense bases
+//   k_ir_bb_offsets   : per function, exclusive scan of its bb sizes
+//   k_ir_compact      : one wave per function: sparse -> dense, ids rebased
 #pragma once
-#include "unit.h"
-namespace opusfe { inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) { u->status = OPUSFE_ERR_INTERNAL; ctx->msg = "IR generation not built yet"; }
-inline void free_ir(opusfe_ctx*, opusfe_unit*) {} }
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <vector>
+#include "sem.h"
+
+namespace opusfe {
+
+struct LFrame { uint8_t st; uint8_t aux; uint16_t cnt; uint32_t node; uint32_t a, b, c, d, e, f; };
+static_assert(sizeof(LFrame) == 32, "frame");
+
+// capacity multipliers of the per-function sparse regions (n = nodes of the definition); every push is checked
+enum { CAP_VARS = 5, CAP_INSTRS = 6, CAP_BBS = 3, CAP_TYPES = 3, CAP_CARGS = 1, CAP_LOCALS = 1, CAP_FRAMES = 2, CAP_ERRS = 1, CAP_CONST = 16 };
+__host__ __device__ __forceinline__ uint64_t lower_base(uint32_t mult, uint32_t def_node, uint32_t fidx) { return (uint64_t)mult * def_node + (uint64_t)CAP_CONST * fidx; }
+__host__ __device__ __forceinline__ uint64_t lower_cap(uint32_t mult, uint32_t n_nodes) { return (uint64_t)mult * n_nodes + CAP_CONST; }
+
+struct SemErr { uint32_t kind, low, len; };
+// compile.rs:124-152 order
+enum SErrKind : uint32_t { SE_ParseError, SE_UndefinedVariable, SE_ShadowedName, SE_UndefinedFunction, SE_NoOverloadForFunction, SE_AmbiguousOverload,
+    SE_AmbiguousFunctionReference, SE_UnexpectedType, SE_InvalidType, SE_InvalidOperandType, SE_InvalidOperandTypes, SE_FunctionMightNotReturn,
+    SE_BreakOutsideLoop, SE_ContinueOutsideLoop, SE_InvalidLvalue, SE_ImmutableLvalue, SE_ArrayPointerToNonArray, SE_InvalidCast, SE_UndefinedType,
+    SE_FieldAccessOnNonRecord, SE_FieldDoesNotExist, SE_CallOfNonFunction, SE_ReferenceToBuiltinFunction, SE_AttemptToCallOrIndexConstant,
+    SE_InvalidNumberOfArgs, SE_InvalidConstantExpression };
+
+// per-function result header (sparse counts; dense bases are filled after the scans)
+struct FuncIr { uint32_t def_node, func, n_vars, n_instrs, n_bbs, n_types, n_cargs, n_errs, var_base, instr_base, bb_base, type_base, carg_base, err_base, status, pad; };
+struct IrCnt { uint32_t vars, instrs, bbs, types, cargs, errs; };
+struct OpAddIrCnt { __host__ __device__ IrCnt operator()(IrCnt a, IrCnt b) const { return IrCnt{a.vars + b.vars, a.instrs + b.instrs, a.bbs + b.bbs, a.types + b.types, a.cargs + b.cargs, a.errs + b.errs}; } };
+
+struct LowerBuffers {
+    opusfe_variable* vars; opusfe_instr* instrs; uint32_t* ibb; uint32_t* irank; uint32_t* bbcnt; uint32_t* bblast;
+    uint32_t* cargs; uint32_t* lname; uint32_t* lvar; uint32_t* lstack; LFrame* frames; SemErr* errs;
+    uint32_t type_sparse_base;   // id of the first local type slot (== n_gtypes)
+};
+
+enum LState : uint8_t {
+    LS_BLOCK, LS_BLOCK_LOOP, LS_BLOCK_ITEM,
+    LS_STMT, LS_ST_EXPR_1, LS_ST_VDEF_1, LS_ST_ASG_1, LS_ST_ASG_2, LS_ST_RET_1, LS_ST_IF_1, LS_ST_IF_2, LS_ST_IF_3, LS_ST_WH_1, LS_ST_FOR_1,
+    LS_FL_0, LS_FL_1, LS_FL_2,
+    LS_E, LS_OP_IS_1, LS_OP_IS_2, LS_OP_AND_1, LS_OP_AND_2, LS_OP_NOT_1, LS_OP_BIN_1, LS_OP_BIN_2, LS_CAST_1, LS_NEG_1,
+    LS_P, LS_P_DEFAULT_1, LS_P_DEREF_1, LS_P_FIELD_1, LS_P_NC_LOOP, LS_P_NC_ITEM, LS_P_COI_1, LS_P_IDX_0, LS_P_IDX_LOOP, LS_P_IDX_ITEM,
+    LS_P_REC_LOOP, LS_P_REC_ITEM,
+    LS_DONE
+};
+enum { PF_DEREF = 4, PF_MUSTLV = 8 };                 // flags in LFrame.aux of a P frame (low 2 bits: PtrKind)
+enum { IDX_PTR = 0, IDX_ARR = 1, IDX_FN = 2 };
+
+struct Lowerer {
+    SemView S;
+    uint32_t fidx; FuncRec F;
+    // sparse regions of this function
+    opusfe_variable* vars; uint32_t nvars, vcap;
+    opusfe_instr* instrs; uint32_t* ibb; uint32_t* irank; uint32_t ninstrs, icap;
+    uint32_t* bbcnt; uint32_t* bblast; uint32_t nbbs, bcap;
+    uint32_t tbase, ntypes, tcap;
+    uint32_t* cargs; uint32_t ncargs, ccap;
+    uint32_t* lname; uint32_t* lvar; uint32_t nlocals, lcap;
+    uint32_t* lstack; uint32_t nstack;
+    LFrame* frames; uint32_t sp, fcap;
+    SemErr* errs; uint32_t nerrs, ecap;
+    // generate_ir.rs:75-97 state
+    uint32_t bb_index, break_head, loop_begin;
+    uint32_t dev_status;
+    LFrame cur;
+    uint32_t rv; bool rl; bool rdiv;
+
+    __device__ __forceinline__ void internal() { if (dev_status < DS_INTERNAL_CAPACITY) dev_status = DS_INTERNAL_CAPACITY; }
+    __device__ __forceinline__ void unsupported() { if (dev_status < DS_UNSUPPORTED_SEMANTIC) dev_status = DS_UNSUPPORTED_SEMANTIC; }
+    __device__ __forceinline__ const opusfe_node& N(uint32_t i) const { return S.nodes[i]; }
+    __device__ __forceinline__ TypeOps T() { return TypeOps{S, &dev_status}; }
+
+    // ---- spans / errors -------------------------------------------------------------------------
+    __device__ void report(uint32_t kind, uint32_t low, uint32_t high) {
+        if (nerrs < ecap) errs[nerrs] = SemErr{kind, low, high - low};
+        nerrs++;   // counting past the capacity is fine: has_errors is what matters, the list is clipped
+    }
+    __device__ void report_node(uint32_t kind, uint32_t node) { report(kind, N(node).low, N(node).high); }
+    __device__ void report_tok(uint32_t kind, uint32_t t) { report(kind, S.tok[t].low, S.tok[t].low + S.tok[t].len); }
+
+    // ---- variables / instructions / blocks (generate_ir.rs:118-131) -------------------------------
+    __device__ uint32_t new_var(uint32_t type_id, bool is_temporary) {
+        if (nvars >= vcap) { internal(); return 0; }
+        vars[nvars] = opusfe_variable{type_id, is_temporary ? 1u : 0u};
+        return nvars++;
+    }
+    __device__ __forceinline__ uint32_t vtype(uint32_t v) const { return v < nvars ? vars[v].type_id : (uint32_t)TP_Error; }
+    __device__ uint32_t push_to(uint32_t bb, const opusfe_instr& in) {
+        if (ninstrs >= icap || bb >= nbbs) { internal(); return 0; }
+        uint32_t t = ninstrs++;
+        instrs[t] = in; ibb[t] = bb; irank[t] = bbcnt[bb]++; bblast[bb] = t;
+        return t;
+    }
+    __device__ __forceinline__ uint32_t push(const opusfe_instr& in) { return push_to(bb_index, in); }
+    __device__ static opusfe_instr ins(uint16_t op, uint32_t dst = 0, uint32_t a = 0, uint32_t b = 0, uint32_t c = 0, uint32_t extra = 0, uint16_t sub = 0) {
+        opusfe_instr i; i.opcode = op; i.sub = sub; i.dst = dst; i.a = a; i.b = b; i.c = c; i.extra = extra; return i;
+    }
+    __device__ uint32_t new_bb() {
+        if (nbbs >= bcap) { internal(); return 0; }
+        bbcnt[nbbs] = 0; bblast[nbbs] = OPUSFE_NONE;
+        return nbbs++;
+    }
+    __device__ uint32_t generate_error() { uint32_t v = new_var(TP_Error, true); push(ins(I_Error, v)); return v; }
+    __device__ uint32_t new_type(const TypeRec& r) {
+        if (ntypes >= tcap) { internal(); return TP_Error; }
+        uint32_t id = tbase + ntypes++;
+        S.types[id] = r;
+        return id;
+    }
+    __device__ uint32_t type_pointer(uint8_t pt, uint32_t sub) { TypeRec r{}; r.kind = TY_Pointer; r.ptr = pt; r.sub = sub; r.alias = OPUSFE_NONE; return new_type(r); }
+    __device__ uint32_t type_mut(uint32_t sub) { return type_pointer(PT_Mutable, sub); }
+    __device__ uint32_t reserve_cargs(uint32_t n) { if (ncargs + n > ccap) { internal(); return 0; } uint32_t o = ncargs; ncargs += n; return o; }
+
+    // ---- functions as values --------------------------------------------------------------------
+    __device__ __forceinline__ bool fn_is_builtin(uint32_t f) const { return (f & FN_BUILTIN) != 0; }
+    __device__ uint32_t fn_nargs(uint32_t f) const { return fn_is_builtin(f) ? builtin_nargs((f >> 8) & 0xFF) : S.funcs[f].nargs; }
+    __device__ uint32_t fn_ret(uint32_t f) const { return fn_is_builtin(f) ? builtin_ret_type((f >> 8) & 0xFF, f & 0xFF) : S.funcs[f].ret; }
+    __device__ uint32_t fn_arg_cursor(uint32_t f) const { return fn_is_builtin(f) ? 0u : S.funcs[f].first_arg; }
+    __device__ uint32_t fn_arg_type(uint32_t f, uint32_t& cursor) const {   // returns the type and advances
+        if (fn_is_builtin(f)) return builtin_arg_type((f >> 8) & 0xFF, f & 0xFF);
+        uint32_t t = S.tid_of_node[N(cursor).first_child];
+        cursor = N(cursor).next;
+        return t;
+    }
+    __device__ uint32_t type_function(uint32_t f) { TypeRec r{}; r.kind = TY_Function; r.src = TS_FUNC; r.ref = f; r.sub = S.funcs[f].ret; r.alias = OPUSFE_NONE; return new_type(r); }
+
+    // resolve_type of a parse-tree type node (compile.rs:919-966): precomputed id; UndefinedType errors are raised
+    // here, when the reference would resolve it, in source order (the subtree is a contiguous node range)
+    __device__ uint32_t resolve_type(uint32_t y, const uint8_t* undefined_flag) {
+        uint32_t last = y;
+        while (N(last).nchild > 0) { uint32_t c = N(last).first_child; while (N(c).next != OPUSFE_NONE) c = N(c).next; last = c; }
+        for (uint32_t k = y; k <= last; k++) if (undefined_flag[k]) report_node(SE_UndefinedType, k);
+        return S.tid_of_node[y];
+    }
+    const uint8_t* undefined_flag;
+
+    // ---- scopes / locals (generate_ir.rs:176-185) -------------------------------------------------
+    __device__ uint32_t local_find(NameKey k) const {
+        for (uint32_t j = nlocals; j > 0; j--) if (lvar[j - 1] != OPUSFE_NONE && name_eq(S.src, S.tok, k, key_tok(lname[j - 1]))) return j - 1;
+        return OPUSFE_NONE;
+    }
+    __device__ void local_set(uint32_t name_tok, uint32_t v) {
+        uint32_t j = local_find(key_tok(name_tok));
+        if (j != OPUSFE_NONE) { lvar[j] = v; return; }
+        if (nlocals >= lcap) { internal(); return; }
+        lname[nlocals] = name_tok; lvar[nlocals] = v; nlocals++;
+    }
+    __device__ bool contains_local(uint32_t name_tok) const {
+        for (uint32_t j = 0; j < nstack; j++) if (name_eq(S.src, S.tok, key_tok(name_tok), key_tok(lstack[j]))) return true;
+        return false;
+    }
+    __device__ void stack_push(uint32_t name_tok) { if (nstack >= lcap) { internal(); return; } lstack[nstack++] = name_tok; }
+    __device__ void end_scope(uint32_t n) {
+        while (nstack > n) { uint32_t name = lstack[--nstack]; uint32_t j = local_find(key_tok(name)); if (j != OPUSFE_NONE) lvar[j] = OPUSFE_NONE; }
+    }
+
+    // ---- generate_ir.rs:207-231 -------------------------------------------------------------------
+    __device__ uint32_t autocast(uint32_t variable, uint32_t expected, uint32_t span_node) {
+        uint32_t found = vtype(variable);
+        if (T().types_match(found, expected)) return variable;
+        int ct = T().can_autocast(found, expected);
+        if (ct >= 0) {
+            uint8_t fk = S.types[found].kind;
+            if (fk == TY_GenericInteger || fk == TY_Generic) { if (variable < nvars) vars[variable].type_id = expected; return variable; }
+            uint32_t r = new_var(expected, true);
+            push(ins(I_Cast, r, variable, 0, 0, 0, (uint16_t)ct));
+            return r;
+        }
+        report_node(SE_UnexpectedType, span_node);
+        return generate_error();
+    }
+    // :235-242
+    __device__ uint32_t get_lvalue_type(uint32_t v) {
+        const TypeRec r = S.types[vtype(v)];
+        if (r.kind == TY_Pointer) return r.sub;
+        if (r.kind != TY_Error) unsupported();   // reference: unreachable!()
+        return TP_Error;
+    }
+    // :495-503
+    __device__ uint32_t dereference_pointer(uint32_t p) { uint32_t v = new_var(get_lvalue_type(p), true); push(ins(I_Load, v, p)); return v; }
+
+    // :808-855; `sp_low/sp_high` is the span for errors
+    __device__ uint32_t try_cast_pointer(uint32_t v, uint8_t pt, uint32_t sp_low, uint32_t sp_high) {
+        const TypeRec r = S.types[vtype(v)];
+        if (r.kind == TY_Pointer) {
+            uint8_t pt2 = r.ptr;
+            if (pt2 == pt) return v;
+            if ((pt2 == PT_Mutable && pt == PT_Reference) || (pt2 == PT_ArrayMutable && pt == PT_Array) || (pt2 == PT_Array && pt == PT_Reference)
+                || (pt2 == PT_ArrayMutable && pt == PT_Mutable) || (pt2 == PT_ArrayMutable && pt == PT_Reference)) {
+                uint32_t nv = new_var(type_pointer(pt, r.sub), true);
+                push(ins(I_Cast, nv, v, 0, 0, 0, CT_PointerType));
+                return nv;
+            }
+            if ((pt2 == PT_Reference && pt == PT_Mutable) || (pt2 == PT_Array && pt == PT_ArrayMutable)) { report(SE_ImmutableLvalue, sp_low, sp_high); return generate_error(); }
+            report(SE_ArrayPointerToNonArray, sp_low, sp_high);
+            return generate_error();
+        }
+        if (r.kind == TY_Error) return generate_error();
+        report(SE_InvalidOperandType, sp_low, sp_high);
+        return generate_error();
+    }
+
+    // Compiler::lookup_function (compile.rs:1083-1139) over builtins followed by the user overloads in definition order
+    __device__ bool name_has_functions(NameKey name, uint32_t* slot_out) const {
+        uint8_t sym = name_sym(S.tok, name);
+        uint32_t s = name_find(S, name);
+        *slot_out = s;
+        if (sym != T_Identifier && builtin_count(sym) > 0) return true;
+        if (s == OPUSFE_NONE) return false;
+        const NameSlot sl = S.slots[s];
+        for (uint32_t j = 0; j < sl.count; j++) if ((S.entries[sl.offset + j].kind_index >> 30) == NK_FUNCTION) return true;
+        return false;
+    }
+    __device__ uint32_t candidate(NameKey name, uint32_t slot, uint32_t c, uint32_t* total) const {
+        uint8_t sym = name_sym(S.tok, name);
+        uint32_t nb = sym != T_Identifier ? (uint32_t)builtin_count(sym) : 0u;
+        uint32_t nu = slot != OPUSFE_NONE ? S.slots[slot].count : 0u;
+        *total = nb + nu;
+        if (c < nb) return FN_BUILTIN | ((uint32_t)sym << 8) | c;
+        NameEntry e = S.entries[S.slots[slot].offset + (c - nb)];
+        if ((e.kind_index >> 30) != NK_FUNCTION) return FN_NONE;
+        return e.kind_index & 0x3FFFFFFFu;
+    }
+    __device__ bool candidate_ok(uint32_t f, const uint32_t* arg_types, uint32_t n) {
+        if (fn_nargs(f) != n) return false;
+        uint32_t cur = fn_arg_cursor(f);
+        for (uint32_t i = 0; i < n; i++) if (T().can_autocast(arg_types[i], fn_arg_type(f, cur)) < 0) return false;
+        return true;
+    }
+    // arg types are read through `argv` (variable ids) unless `types` is given (Proc)
+    __device__ uint32_t compiler_lookup_function(uint32_t sp_low, uint32_t sp_high, NameKey name, const uint32_t* argv, const uint32_t* types_in, uint32_t n) {
+        uint32_t slot;
+        if (!name_has_functions(name, &slot)) { report(SE_UndefinedFunction, sp_low, sp_high); return FN_NONE; }
+        if (n > 64) { unsupported(); return FN_NONE; }
+        uint32_t at[64];
+        for (uint32_t i = 0; i < n; i++) at[i] = types_in ? types_in[i] : vtype(argv[i]);
+        uint32_t total = 0; candidate(name, slot, 0, &total);
+        uint32_t first = FN_NONE; uint64_t ignorable = ~0ull;
+        for (uint32_t c = 0; c < total; c++) {
+            uint32_t f = candidate(name, slot, c, &total);
+            if (f == FN_NONE || !candidate_ok(f, at, n)) continue;
+            if (first == FN_NONE) first = f;
+            uint32_t c1 = fn_arg_cursor(first), c2 = fn_arg_cursor(f);
+            for (uint32_t i = 0; i < n; i++) {
+                uint32_t t1 = fn_arg_type(first, c1), t2 = fn_arg_type(f, c2);
+                if ((ignorable >> i) & 1) if (!T().types_match_allow_generic(t2, t1)) ignorable &= ~(1ull << i);
+            }
+        }
+        if (first == FN_NONE) { report(SE_NoOverloadForFunction, sp_low, sp_high); return FN_NONE; }
+        for (uint32_t c = 0; c < total; c++) {
+            uint32_t f = candidate(name, slot, c, &total);
+            if (f == FN_NONE || !candidate_ok(f, at, n)) continue;
+            bool all = true;
+            uint32_t cf = fn_arg_cursor(f);
+            for (uint32_t i = 0; i < n; i++) {
+                uint32_t ft = fn_arg_type(f, cf);
+                if ((ignorable >> i) & 1) continue;
+                if (!T().types_match_default_generic(ft, at[i])) { all = false; break; }
+            }
+            if (all) return f;
+        }
+        report(SE_AmbiguousOverload, sp_low, sp_high);
+        return FN_NONE;
+    }
+
+    // IrGenerator::lookup_function + get_function_call_variables (generate_ir.rs:1151-1198).
+    // argv[0..n) are updated in place by the autocasts; span of argument i = node `span_node` (same for all when
+    // `same_span`) else the i-th node of the sibling chain starting there.  Returns false when there is no callee.
+    struct Callee { uint32_t fv; uint32_t out; bool builtin; };
+    __device__ bool call_variables(uint32_t sp_low, uint32_t sp_high, NameKey name, uint32_t* argv, uint32_t n, uint32_t span_node, bool same_span, Callee* res) {
+        for (uint32_t i = 0; i < n; i++) if (S.types[vtype(argv[i])].kind == TY_Error) return false;
+        // lookup_function: a local of that name shadows the global functions
+        uint32_t fv, ret; bool builtin = false;
+        uint32_t arg_src = 0;        // 0: function id `fid`; 1: members of function type `ftype`
+        uint32_t fid = FN_NONE; TypeRec ftype{};
+        uint32_t lj = local_find(name);
+        if (lj != OPUSFE_NONE) {
+            uint32_t variable = lvar[lj];
+            uint32_t typ = get_lvalue_type(variable);
+            uint32_t nv = new_var(typ, true);
+            push(ins(I_Load, nv, variable));
+            ftype = S.types[typ];
+            if (ftype.kind != TY_Function) { report(SE_CallOfNonFunction, sp_low, sp_high); return false; }
+            fv = nv; ret = ftype.sub; arg_src = 1;
+        } else {
+            fid = compiler_lookup_function(sp_low, sp_high, name, argv, nullptr, n);
+            if (fid == FN_NONE) return false;
+            ret = fn_ret(fid);
+            if (fn_is_builtin(fid)) { fv = OPUSFE_NONE; builtin = true; }
+            else {
+                uint32_t typ = type_function(fid);
+                fv = new_var(typ, true);
+                push(ins(I_Function, fv, 0, 0, fid));
+            }
+        }
+        // zip(arguments, types): the shorter one ends the loop (debug_assert only in debug builds, :1189)
+        uint32_t m = n, cursor = 0;
+        if (arg_src == 1) { uint32_t k = T().member_count(ftype); if (k < m) m = k; cursor = T().member_first(ftype); }
+        else cursor = fn_arg_cursor(fid);
+        uint32_t sn = span_node;
+        for (uint32_t i = 0; i < m; i++) {
+            uint32_t want;
+            if (arg_src == 1) { want = T().member_type(cursor); cursor = T().member_next(cursor); }
+            else want = fn_arg_type(fid, cursor);
+            argv[i] = autocast(argv[i], want, sn);
+            if (!same_span && sn != OPUSFE_NONE && N(sn).next != OPUSFE_NONE) sn = N(sn).next;
+        }
+        res->fv = fv; res->out = new_var(ret, true); res->builtin = builtin;
+        return true;
+    }
+
+    // get_field_type (:1090-1101) -> type id or NONE
+    __device__ uint32_t get_field_type(uint32_t rec, uint32_t field_tok) {
+        const TypeRec r = S.types[get_lvalue_type(rec)];
+        if (r.kind != TY_Record) return OPUSFE_NONE;
+        uint32_t n = T().member_count(r), c = T().member_first(r);
+        for (uint32_t i = 0; i < n; i++) { if (name_eq(S.src, S.tok, key_tok(field_tok), key_tok(T().member_name(c)))) return T().member_type(c); c = T().member_next(c); }
+        return OPUSFE_NONE;
+    }
+    // generate_ir_for_field_access (:1103-1149)
+    __device__ uint32_t field_access(uint32_t rec, uint32_t field_tok, uint8_t pt, uint32_t sp_low, uint32_t sp_high) {
+        if (pt == PT_Array || pt == PT_ArrayMutable) { report(SE_ArrayPointerToNonArray, sp_low, sp_high); return generate_error(); }
+        const TypeRec r = S.types[get_lvalue_type(rec)];
+        if (r.kind == TY_Record) {
+            uint32_t n = T().member_count(r), c = T().member_first(r);
+            for (uint32_t i = 0; i < n; i++) {
+                if (name_eq(S.src, S.tok, key_tok(field_tok), key_tok(T().member_name(c)))) {
+                    uint32_t rvv = new_var(type_pointer(pt, T().member_type(c)), true);
+                    push(ins(I_Field, rvv, rec, 0, field_tok));
+                    return rvv;
+                }
+                c = T().member_next(c);
+            }
+            report(SE_FieldDoesNotExist, sp_low, sp_high);
+            return generate_error();
+        }
+        if (r.kind == TY_String) {
+            uint32_t idx, ft;
+            if (name_is(S.src, S.tok, field_tok, "data", 4)) { idx = 0; ft = type_pointer(PT_Array, TP_Natural8); }
+            else if (name_is(S.src, S.tok, field_tok, "length", 6)) { idx = 1; ft = TP_Size; }
+            else { report(SE_FieldDoesNotExist, sp_low, sp_high); return generate_error(); }
+            uint32_t rvv = new_var(type_pointer(pt, ft), true);
+            push(ins(I_BuiltinField, rvv, rec, 0, idx));
+            return rvv;
+        }
+        report(SE_FieldAccessOnNonRecord, sp_low, sp_high);
+        return generate_error();
+    }
+
+    // lookup_name (:857-893).  Returns false for "None" (the name is a constant global)
+    __device__ bool lookup_name(uint32_t name_tok, uint32_t sp_low, uint32_t sp_high, uint8_t pt, uint32_t* var, bool* is_lvalue) {
+        *is_lvalue = true;
+        NameKey key = key_tok(name_tok);
+        uint32_t lj = local_find(key);
+        if (lj != OPUSFE_NONE) { *var = try_cast_pointer(lvar[lj], pt, sp_low, sp_high); return true; }
+        uint32_t ge = name_last(S, key, NK_GLOBAL);
+        if (ge != OPUSFE_NONE) {
+            uint32_t gid = S.entries[ge].kind_index & 0x3FFFFFFFu;
+            if (S.globals[gid].is_const) return false;
+            uint32_t v = new_var(type_mut(S.globals[gid].type_id), true);
+            push(ins(I_GlobalVariable, v, 0, 0, gid));
+            *var = try_cast_pointer(v, pt, sp_low, sp_high);
+            return true;
+        }
+        uint32_t slot;
+        if (name_has_functions(key, &slot)) {
+            uint32_t total = 0, count = 0, only = FN_NONE;
+            candidate(key, slot, 0, &total);
+            for (uint32_t c = 0; c < total; c++) { uint32_t f = candidate(key, slot, c, &total); if (f != FN_NONE) { count++; only = f; } }
+            if (count > 1) { report_tok(SE_AmbiguousFunctionReference, name_tok); *var = generate_error(); return true; }
+            if (fn_is_builtin(only)) { unsupported(); *var = generate_error(); return true; }   // single builtin (`not`): the reference builds a function value of a builtin
+            *is_lvalue = false;
+            uint32_t v = new_var(type_function(only), true);
+            push(ins(I_Function, v, 0, 0, only));
+            *var = v;
+            return true;
+        }
+        report_tok(SE_UndefinedVariable, name_tok);
+        *var = generate_error();
+        return true;
+    }
+
+    // ---- machine ----------------------------------------------------------------------------------
+    __device__ __forceinline__ bool call(uint8_t entry, uint8_t resume, uint32_t node, uint8_t aux, uint32_t a, uint32_t f = 0) {
+        cur.st = resume;
+        if (sp + 1 >= fcap) { internal(); return false; }
+        frames[sp++] = cur;
+        cur.st = entry; cur.aux = aux; cur.cnt = 0; cur.node = node; cur.a = a; cur.b = cur.c = cur.d = cur.e = 0; cur.f = f;
+        return true;
+    }
+    __device__ __forceinline__ void retn() { if (sp == 0) { cur.st = LS_DONE; return; } cur = frames[--sp]; }
+    __device__ __forceinline__ void push_raw(const LFrame& fr) { if (sp + 1 >= fcap) { internal(); return; } frames[sp++] = fr; }
+    __device__ __forceinline__ LFrame pop_raw() { if (sp == 0) { internal(); return LFrame{}; } return frames[--sp]; }
+
+    __device__ void p_finish(uint32_t var, bool lv) {
+        if ((cur.aux & PF_MUSTLV) && !lv) { report_node(SE_InvalidLvalue, cur.f); var = generate_error(); }   // generate_pointer_from_expression :970-979
+        if (cur.aux & PF_DEREF) var = lv ? dereference_pointer(var) : var;                                   // :577-585
+        rv = var; rl = lv;
+        retn();
+    }
+
+    // generate_ir_from_function (:133-174)
+    __device__ void run(uint32_t body) {
+#define CALL_E(node, exp, resume) do { if (!call(LS_E, resume, node, 0, exp)) return; goto next; } while (0)
+#define CALL_P(node, ptflags, resume) do { if (!call(LS_P, resume, node, ptflags, 0, node)) return; goto next; } while (0)
+#define CALL_BLOCK(node, resume) do { if (!call(LS_BLOCK, resume, node, 0, 0)) return; goto next; } while (0)
+#define CALL_STMT(node, resume) do { if (!call(LS_STMT, resume, node, 0, 0)) return; goto next; } while (0)
+        const uint32_t def = F.def_node;
+        nbbs = 0; new_bb(); bb_index = 0;
+        {   // prologue
+            uint32_t a = F.first_arg;
+            for (uint32_t i = 0; i < F.nargs; i++) { new_var(resolve_type(N(a).first_child, undefined_flag), true); a = N(a).next; }
+            a = F.first_arg;
+            for (uint32_t i = 0; i < F.nargs; i++) {
+                uint32_t v = new_var(type_mut(vtype(i)), false);
+                push(ins(I_Allocate, v));
+                push(ins(I_Store, 0, v, i));
+                local_set(N(a).payload, v);
+                a = N(a).next;
+            }
+        }
+        const bool returns_null = S.types[F.ret].kind == TY_Null;
+        cur.st = LS_BLOCK; cur.aux = 0; cur.cnt = 0; cur.node = body; cur.a = cur.b = cur.c = cur.d = cur.e = cur.f = 0;
+        sp = 0;
+        for (;;) {
+            if (dev_status >= DS_INTERNAL_CAPACITY) return;
+            const opusfe_node nd = cur.node != OPUSFE_NONE ? N(cur.node) : opusfe_node{};
+            switch (cur.st) {
+            case LS_DONE: goto finished;
+            // ---- generate_ir_from_block (:189-203) ----
+            case LS_BLOCK: cur.a = nstack; cur.b = cur.node != OPUSFE_NONE ? nd.first_child : OPUSFE_NONE; cur.aux = 0; cur.st = LS_BLOCK_LOOP; goto next;
+            case LS_BLOCK_LOOP:
+                if (cur.b == OPUSFE_NONE) { end_scope(cur.a); rdiv = cur.aux != 0; retn(); goto next; }
+                CALL_STMT(cur.b, LS_BLOCK_ITEM);
+            case LS_BLOCK_ITEM: if (rdiv) cur.aux = 1; cur.b = N(cur.b).next; cur.st = LS_BLOCK_LOOP; goto next;
+
+            // ---- generate_ir_from_statement (:246-493) ----
+            case LS_STMT:
+                switch (nd.kind) {
+                    case S_Expression: CALL_E(nd.first_child, OPUSFE_NONE, LS_ST_EXPR_1);
+                    case S_VariableDefinition: CALL_E(nd.first_child, OPUSFE_NONE, LS_ST_VDEF_1);
+                    case S_Assignment: CALL_P(nd.first_child, PT_Mutable | PF_MUSTLV, LS_ST_ASG_1);
+                    case S_Return: CALL_E(nd.first_child, F.ret, LS_ST_RET_1);
+                    case S_If: CALL_E(nd.first_child, TP_Bool, LS_ST_IF_1);
+                    case S_While: {
+                        uint32_t loop_start = nbbs;
+                        push(ins(I_Jump, 0, 0, 0, loop_start));
+                        bb_index = loop_start; new_bb();
+                        cur.b = loop_start;
+                        CALL_E(nd.first_child, TP_Bool, LS_ST_WH_1);
+                    }
+                    case S_For: {
+                        uint32_t c = nd.first_child;
+                        if (nd.sub) c = N(c).next;               // skip the optional type
+                        CALL_E(c, OPUSFE_NONE, LS_ST_FOR_1);
+                    }
+                    case S_Break:
+                        if (loop_begin != OPUSFE_NONE) {
+                            uint32_t t = push(ins(I_BreakPlaceholder, 0, break_head));   // chain of this loop's breaks (patched in LS_FL_2)
+                            break_head = t;
+                            bb_index = new_bb();
+                        } else report_node(SE_BreakOutsideLoop, cur.node);
+                        rdiv = false; retn(); goto next;
+                    case S_Continue:
+                        if (loop_begin != OPUSFE_NONE) { push(ins(I_Jump, 0, 0, 0, loop_begin)); bb_index = new_bb(); }
+                        else report_node(SE_ContinueOutsideLoop, cur.node);
+                        rdiv = false; retn(); goto next;
+                    default: internal(); return;
+                }
+            case LS_ST_EXPR_1: rdiv = false; retn(); goto next;
+            case LS_ST_VDEF_1: {
+                uint32_t v = rv, typ = vtype(v);
+                if (contains_local(nd.payload)) report_node(SE_ShadowedName, cur.node);
+                else {
+                    uint32_t nv = new_var(type_mut(typ), false);
+                    push(ins(I_Allocate, nv));
+                    push(ins(I_Store, 0, nv, v));
+                    stack_push(nd.payload);
+                    local_set(nd.payload, nv);
+                }
+                rdiv = false; retn(); goto next;
+            }
+            case LS_ST_ASG_1: {
+                cur.a = rv; cur.b = get_lvalue_type(rv);
+                CALL_E(N(nd.first_child).next, cur.b, LS_ST_ASG_2);
+            }
+            case LS_ST_ASG_2: {
+                uint32_t fin = autocast(rv, cur.b, N(nd.first_child).next);
+                push(ins(I_Store, 0, cur.a, fin));
+                rdiv = false; retn(); goto next;
+            }
+            case LS_ST_RET_1: {
+                uint32_t r = autocast(rv, F.ret, nd.first_child);
+                push(ins(I_Return, 0, r));
+                rdiv = true; retn(); goto next;       // no new bb after `return` (Q12)
+            }
+            case LS_ST_IF_1: {
+                cur.a = autocast(rv, TP_Bool, nd.first_child);
+                cur.b = bb_index;
+                cur.c = new_bb(); bb_index = cur.c;
+                CALL_BLOCK(N(nd.first_child).next, LS_ST_IF_2);
+            }
+            case LS_ST_IF_2: {
+                cur.aux = rdiv ? 1 : 0;
+                cur.d = bb_index;
+                cur.e = new_bb(); bb_index = cur.e;
+                uint32_t else_block = N(N(nd.first_child).next).next;
+                CALL_BLOCK(else_block, LS_ST_IF_3);
+            }
+            case LS_ST_IF_3: {
+                bool div = cur.aux && rdiv;
+                uint32_t else_end = bb_index;
+                uint32_t merge = new_bb(); bb_index = merge;
+                push_to(cur.b, ins(I_Branch, 0, cur.a, cur.c, cur.e));
+                push_to(cur.d, ins(I_Jump, 0, 0, 0, merge));
+                push_to(else_end, ins(I_Jump, 0, 0, 0, merge));
+                rdiv = div; retn(); goto next;
+            }
+            case LS_ST_WH_1: {
+                const opusfe_node cn = N(nd.first_child);
+                cur.a = autocast(rv, TP_Bool, nd.first_child);
+                cur.aux = (cn.kind == E_Bool && cn.sub) ? 1 : 0;      // is_infinite; bit1 = is_for
+                cur.e = 0;                                            // scope (unused for while)
+                cur.d = N(nd.first_child).next;                       // then-block node
+                cur.st = LS_FL_0;
+                goto next;
+            }
+            case LS_ST_FOR_1: {   // :363-431
+                uint32_t tnode = nd.sub ? nd.first_child : OPUSFE_NONE;
+                uint32_t inode = nd.sub ? N(nd.first_child).next : nd.first_child;
+                const uint32_t elow = N(inode).low, ehigh = N(inode).high;
+                uint32_t off = reserve_cargs(1);
+                cargs[off] = rv;
+                Callee cl; uint32_t for_fn, ret_var;
+                if (call_variables(elow, ehigh, key_sym(T_For), cargs + off, 1, inode, true, &cl)) { for_fn = cl.fv; ret_var = cl.out; }
+                else { for_fn = generate_error(); ret_var = generate_error(); }
+                uint32_t iterator_variable = new_var(type_mut(vtype(ret_var)), true);
+                push(ins(I_Call, ret_var, for_fn, 0, off, 0, 1));
+                push(ins(I_Allocate, iterator_variable));
+                push(ins(I_Store, 0, iterator_variable, ret_var));
+                uint32_t loop_start = nbbs;
+                push(ins(I_Jump, 0, 0, 0, loop_start));
+                bb_index = loop_start; new_bb();
+                uint32_t scope = nstack;
+                uint32_t pointer_type = tnode != OPUSFE_NONE ? type_mut(resolve_type(tnode, undefined_flag)) : (uint32_t)TP_Generic;
+                uint32_t iteration_variable;
+                if (contains_local(nd.payload)) { report_node(SE_ShadowedName, cur.node); iteration_variable = generate_error(); }
+                else {
+                    iteration_variable = new_var(pointer_type, false);
+                    push(ins(I_Allocate, iteration_variable));
+                    stack_push(nd.payload);
+                    local_set(nd.payload, iteration_variable);
+                }
+                uint32_t off2 = reserve_cargs(2);
+                cargs[off2] = iterator_variable; cargs[off2 + 1] = iteration_variable;
+                uint32_t cont_fn, cond;
+                if (call_variables(elow, ehigh, key_sym(T_Continue), cargs + off2, 2, inode, true, &cl)) { cont_fn = cl.fv; cond = cl.out; }
+                else { cont_fn = generate_error(); cond = generate_error(); }
+                push(ins(I_Call, cond, cont_fn, 0, off2, 0, 2));
+                cond = autocast(cond, TP_Bool, inode);
+                cur.a = cond; cur.b = loop_start; cur.aux = 2; cur.e = scope;
+                cur.d = N(inode).next;                                // then-block node
+                cur.st = LS_FL_0;
+                goto next;
+            }
+            // ---- shared tail of While (:327-361) and For (:432-468) ----
+            // frame: a cond, b loop_start, c branch, d then-block node -> then bb, e scope, f then_end; aux bit0 infinite, bit1 for
+            case LS_FL_0: {
+                cur.c = bb_index;
+                LFrame save{}; save.a = break_head; save.b = loop_begin;
+                break_head = OPUSFE_NONE; loop_begin = cur.b;
+                uint32_t then_block = cur.d;
+                cur.d = new_bb(); bb_index = cur.d;
+                cur.f = then_block;                                   // remembered to find the else block
+                push_raw(save);
+                CALL_BLOCK(then_block, LS_FL_1);
+            }
+            case LS_FL_1: {
+                LFrame save = pop_raw();
+                uint32_t then_end = bb_index;
+                uint32_t new_head = break_head;
+                break_head = save.a; loop_begin = save.b;
+                if (cur.aux & 2) end_scope(cur.e);
+                uint32_t else_block = N(cur.f).next;
+                uint32_t else_branch = new_bb(); bb_index = else_branch;
+                LFrame keep{}; keep.a = then_end; keep.b = new_head; keep.c = else_branch;
+                push_raw(keep);
+                CALL_BLOCK(else_block, LS_FL_2);
+            }
+            case LS_FL_2: {
+                LFrame keep = pop_raw();
+                bool div = rdiv;
+                if (!(cur.aux & 2)) div = div || ((cur.aux & 1) && keep.b == OPUSFE_NONE);
+                uint32_t else_end = bb_index;
+                uint32_t merge = new_bb(); bb_index = merge;
+                push_to(cur.c, ins(I_Branch, 0, cur.a, cur.d, keep.c));
+                push_to(keep.a, ins(I_Jump, 0, 0, 0, cur.b));
+                push_to(else_end, ins(I_Jump, 0, 0, 0, merge));
+                for (uint32_t t = keep.b; t != OPUSFE_NONE;) {        // patch this loop's break placeholders (:357-359)
+                    if (t >= ninstrs) { internal(); break; }
+                    uint32_t nx = instrs[t].a;
+                    instrs[t] = ins(I_Jump, 0, 0, 0, merge);
+                    t = nx;
+                }
+                rdiv = div; retn(); goto next;
+            }
+
+            // ---- generate_ir_from_expression (:510-806); frame.a = expected type or NONE ----
+            case LS_E:
+                switch (nd.kind) {
+                    case E_Integer: {
+                        const opusfe_token t = S.tok[nd.payload];
+                        uint32_t typ;
+                        if (t.aux & 0x8000) {
+                            uint32_t size = t.aux & 0xFF; bool sg = (t.aux & 0x100) != 0;
+                            if (!sg) typ = size == 8 ? TP_Natural8 : size == 16 ? TP_Natural16 : size == 32 ? TP_Natural32 : size == 64 ? TP_Natural64 : TP_Size;
+                            else typ = size == 8 ? TP_Integer8 : size == 16 ? TP_Integer16 : size == 32 ? TP_Integer32 : size == 64 ? TP_Integer64 : TP_Offset;
+                        } else if (cur.a != OPUSFE_NONE && (kind_is_integral(S.types[cur.a].kind) || S.types[cur.a].kind == TY_GenericInteger)) typ = cur.a;
+                        else typ = TP_Integer32;
+                        uint64_t val = (t.flags & OPUSFE_TF_INLINE) ? (uint64_t)t.payload : S.val64[t.payload];
+                        uint32_t v = new_var(typ, true);
+                        push(ins(I_Integer, v, 0, 0, (uint32_t)val, (uint32_t)(val >> 32)));
+                        rv = v; retn(); goto next;
+                    }
+                    case E_Float: {
+                        const opusfe_token t = S.tok[nd.payload];
+                        uint64_t bits = S.val64[t.payload];
+                        uint32_t v = new_var(t.aux == 32 ? TP_Float32 : TP_Float64, true);
+                        push(ins(I_Float, v, 0, 0, (uint32_t)bits, (uint32_t)(bits >> 32)));
+                        rv = v; retn(); goto next;
+                    }
+                    case E_Null: { uint32_t v = new_var(TP_Null, true); push(ins(I_Null, v)); rv = v; retn(); goto next; }
+                    case E_Bool: { uint32_t v = new_var(TP_Bool, true); push(ins(I_Bool, v, 0, 0, 0, 0, nd.sub)); rv = v; retn(); goto next; }
+                    case E_String: { uint32_t v = new_var(TP_String, true); push(ins(I_String, v, 0, 0, nd.payload)); rv = v; retn(); goto next; }
+                    case E_Variable: case E_Dereference: case E_VariableDefinition: case E_Field: case E_NamedCall: case E_CallOrIndex: case E_Record:
+                        cur.st = LS_P; cur.aux = PT_Reference | PF_DEREF; cur.f = cur.node; goto next;
+                    case E_Proc: {   // :586-602
+                        uint32_t types[64];
+                        if (nd.nchild > 64) { unsupported(); rv = generate_error(); retn(); goto next; }
+                        uint32_t c = nd.first_child;
+                        for (uint32_t i = 0; i < nd.nchild; i++) { types[i] = resolve_type(c, undefined_flag); c = N(c).next; }
+                        uint32_t f = compiler_lookup_function(nd.low, nd.high, key_tok(nd.payload), nullptr, types, nd.nchild);
+                        if (f == FN_NONE) { rv = generate_error(); retn(); goto next; }
+                        if (fn_is_builtin(f)) { report_node(SE_ReferenceToBuiltinFunction, cur.node); rv = generate_error(); retn(); goto next; }
+                        uint32_t v = new_var(type_function(f), true);
+                        push(ins(I_Function, v, 0, 0, f));
+                        rv = v; retn(); goto next;
+                    }
+                    case E_Operator: {
+                        uint32_t left = nd.first_child, right = N(left).next;
+                        switch (nd.sub) {
+                            case OP_Is: CALL_E(left, OPUSFE_NONE, LS_OP_IS_1);
+                            case OP_And: case OP_Or: CALL_E(left, TP_Bool, LS_OP_AND_1);
+                            case OP_Not: CALL_E(right, TP_GenericInteger, LS_OP_NOT_1);      // the left operand is never evaluated (Q9)
+                            default: CALL_E(left, TP_GenericInteger, LS_OP_BIN_1);
+                        }
+                    }
+                    case E_Cast: CALL_E(nd.first_child, OPUSFE_NONE, LS_CAST_1);
+                    case E_Reference: case E_MutableReference: case E_ArrayReference: case E_MutableArrayReference: {
+                        uint8_t pt = nd.kind == E_Reference ? PT_Reference : nd.kind == E_MutableReference ? PT_Mutable : nd.kind == E_ArrayReference ? PT_Array : PT_ArrayMutable;
+                        cur.node = nd.first_child; cur.f = cur.node; cur.aux = pt | PF_MUSTLV; cur.st = LS_P;
+                        goto next;
+                    }
+                    case E_Negate: CALL_E(nd.first_child, cur.a, LS_NEG_1);
+                    case E_Sizeof: case E_Alignof: {
+                        uint32_t v = new_var(TP_Size, true);
+                        uint32_t typ = resolve_type(nd.first_child, undefined_flag);
+                        push(ins(nd.kind == E_Sizeof ? I_Sizeof : I_Alignof, v, 0, 0, typ));
+                        rv = v; retn(); goto next;
+                    }
+                    case E_Parentheses: cur.node = nd.first_child; goto next;
+                    default: internal(); return;
+                }
+            case LS_OP_IS_1: cur.b = rv; CALL_E(N(nd.first_child).next, OPUSFE_NONE, LS_OP_IS_2);
+            case LS_OP_IS_2: {
+                uint32_t l = cur.b, r = rv;
+                const TypeRec lt = S.types[vtype(l)], rt = S.types[vtype(r)];
+                if (lt.kind == TY_Pointer && rt.kind == TY_Pointer && lt.ptr == rt.ptr && T().types_match(lt.sub, rt.sub)) {
+                    uint32_t v = new_var(TP_Bool, true);
+                    push(ins(I_Equals, v, l, r));
+                    rv = v;
+                } else { report_node(SE_InvalidOperandTypes, cur.node); rv = generate_error(); }
+                retn(); goto next;
+            }
+            case LS_OP_AND_1: {
+                cur.b = autocast(rv, TP_Bool, nd.first_child);
+                cur.c = bb_index;
+                cur.d = new_bb(); bb_index = cur.d;
+                CALL_E(N(nd.first_child).next, TP_Bool, LS_OP_AND_2);
+            }
+            case LS_OP_AND_2: {
+                uint32_t then_var = rv;
+                if (!T().types_match(vtype(then_var), TP_Bool)) {       // Q15: returns with bb_index left in the RHS block, no Branch
+                    report_node(SE_InvalidOperandType, N(nd.first_child).next);
+                    rv = generate_error(); retn(); goto next;
+                }
+                uint32_t then_end = bb_index;
+                uint32_t merge = new_bb();
+                push(ins(I_Jump, 0, 0, 0, merge));
+                if (nd.sub == OP_And) push_to(cur.c, ins(I_Branch, 0, cur.b, cur.d, merge));
+                else push_to(cur.c, ins(I_Branch, 0, cur.b, merge, cur.d));
+                bb_index = merge;
+                uint32_t out = new_var(TP_Bool, true);
+                push(ins(I_Phi, out, cur.b, then_var, cur.c, then_end));
+                rv = out; retn(); goto next;
+            }
+            case LS_OP_NOT_1: {
+                uint32_t argv[1] = {rv};
+                uint32_t right = N(nd.first_child).next;
+                Callee cl;
+                if (call_variables(nd.low, nd.high, key_sym(T_Not), argv, 1, right, true, &cl)) {
+                    if (cl.builtin) push(ins(I_Not, cl.out, argv[0]));
+                    else { uint32_t off = reserve_cargs(1); cargs[off] = argv[0]; push(ins(I_Call, cl.out, cl.fv, 0, off, 0, 1)); }
+                    rv = cl.out;
+                } else rv = generate_error();
+                retn(); goto next;
+            }
+            case LS_OP_BIN_1: cur.b = rv; CALL_E(N(nd.first_child).next, TP_GenericInteger, LS_OP_BIN_2);
+            case LS_OP_BIN_2: {
+                uint32_t argv[2] = {cur.b, rv};
+                Callee cl;
+                if (call_variables(nd.low, nd.high, key_sym(sym_of_op(nd.sub)), argv, 2, nd.first_child, false, &cl)) {
+                    if (cl.builtin) {
+                        uint16_t op;
+                        switch (nd.sub) {
+                            case OP_Plus: op = I_Add; break; case OP_Minus: op = I_Subtract; break; case OP_Times: op = I_Multiply; break;
+                            case OP_Divide: op = I_Divide; break; case OP_Modulo: op = I_Modulo; break; case OP_Equals: op = I_Equals; break;
+                            case OP_LessThan: op = I_LessThan; break; case OP_GreaterThan: op = I_GreaterThan; break;
+                            case OP_LessThanEquals: op = I_LessThanEquals; break; default: op = I_GreaterThanEquals; break;
+                        }
+                        push(ins(op, cl.out, argv[0], argv[1]));
+                    } else { uint32_t off = reserve_cargs(2); cargs[off] = argv[0]; cargs[off + 1] = argv[1]; push(ins(I_Call, cl.out, cl.fv, 0, off, 0, 2)); }
+                    rv = cl.out;
+                } else rv = generate_error();
+                retn(); goto next;
+            }
+            case LS_CAST_1: {
+                uint32_t v = rv, old_type = vtype(v);
+                uint32_t typ = resolve_type(N(nd.first_child).next, undefined_flag);
+                int ct = T().can_cast(old_type, typ);
+                if (ct >= 0) { uint32_t nv = new_var(typ, true); push(ins(I_Cast, nv, v, 0, 0, 0, (uint16_t)ct)); rv = nv; }
+                else { report_node(SE_InvalidCast, cur.node); rv = generate_error(); }
+                retn(); goto next;
+            }
+            case LS_NEG_1: {   // :749-789
+                uint32_t sub = rv, st = vtype(sub);
+                uint8_t k = S.types[st].kind;
+                if (k == TY_Integer8 || k == TY_Integer16 || k == TY_Integer32 || k == TY_Integer64 || k == TY_Offset) {
+                    uint32_t out = new_var(st, true);
+                    push(ins(I_Negate, out, sub));
+                    rv = out;
+                } else if (k == TY_GenericInteger) {
+                    uint32_t t = bb_index < nbbs ? bblast[bb_index] : OPUSFE_NONE;
+                    if (t != OPUSFE_NONE && instrs[t].opcode == I_Integer) {
+                        uint64_t val = (uint64_t)instrs[t].c | ((uint64_t)instrs[t].extra << 32);
+                        val = 0 - val;
+                        instrs[t].c = (uint32_t)val; instrs[t].extra = (uint32_t)(val >> 32);
+                        rv = instrs[t].dst;
+                    } else { unsupported(); rv = generate_error(); }   // reference: unreachable!()
+                } else if (k == TY_Error) rv = generate_error();
+                else { report_node(SE_InvalidOperandType, cur.node); rv = generate_error(); }
+                retn(); goto next;
+            }
+
+            // ---- try_generate_pointer_from_expression (:985-1088); aux = PtrKind | flags, f = node for InvalidLvalue ----
+            case LS_P: {
+                const uint8_t pt = cur.aux & 3;
+                switch (nd.kind) {
+                    case E_Variable: {
+                        uint32_t var; bool lv;
+                        if (lookup_name(nd.payload, nd.low, nd.high, pt, &var, &lv)) { p_finish(var, lv); goto next; }
+                        // constant global (:993-998)
+                        uint32_t ge = name_last(S, key_tok(nd.payload), NK_GLOBAL);
+                        uint32_t gid = S.entries[ge].kind_index & 0x3FFFFFFFu;
+                        uint32_t v = new_var(S.globals[gid].type_id, true);
+                        push(ins(I_GlobalConstant, v, 0, 0, gid));
+                        p_finish(v, false); goto next;
+                    }
+                    case E_VariableDefinition: {
+                        uint32_t var;
+                        if (contains_local(nd.payload)) { report_node(SE_ShadowedName, cur.node); var = generate_error(); }
+                        else {
+                            uint32_t typ = resolve_type(nd.first_child, undefined_flag);
+                            uint32_t v = new_var(type_mut(typ), false);
+                            push(ins(I_Allocate, v));
+                            stack_push(nd.payload);
+                            local_set(nd.payload, v);
+                            var = try_cast_pointer(v, pt, nd.low, nd.high);
+                        }
+                        p_finish(var, true); goto next;
+                    }
+                    case E_Dereference: CALL_E(nd.first_child, OPUSFE_NONE, LS_P_DEREF_1);
+                    case E_Field: CALL_P(nd.first_child, pt | PF_MUSTLV, LS_P_FIELD_1);
+                    case E_NamedCall: {
+                        uint32_t slot;
+                        if (name_has_functions(key_tok(nd.payload), &slot)) {
+                            cur.a = reserve_cargs(nd.nchild);          // arguments are evaluated straight into the call-argument pool
+                            cur.b = nd.first_child; cur.c = 0;
+                            cur.st = LS_P_NC_LOOP;
+                            goto next;
+                        }
+                        uint32_t var; bool lv;
+                        if (!lookup_name(nd.payload, nd.low, nd.high, pt, &var, &lv)) {
+                            report_node(SE_AttemptToCallOrIndexConstant, cur.node);
+                            p_finish(generate_error(), true); goto next;
+                        }
+                        cur.a = var; cur.b = lv ? 1 : 0; cur.c = nd.first_child;
+                        cur.st = LS_P_IDX_0;
+                        goto next;
+                    }
+                    case E_CallOrIndex: {
+                        uint8_t pt2 = (pt == PT_Array || pt == PT_Reference) ? PT_Reference : PT_Mutable;
+                        CALL_P(nd.first_child, pt2, LS_P_COI_1);
+                    }
+                    case E_Record: {
+                        uint32_t typ = type_mut(resolve_type(nd.first_child, undefined_flag));
+                        uint32_t out = new_var(typ, true);
+                        push(ins(I_Allocate, out));
+                        cur.a = out; cur.b = N(nd.first_child).next;
+                        cur.st = LS_P_REC_LOOP;
+                        goto next;
+                    }
+                    case E_Parentheses: cur.node = nd.first_child; goto next;
+                    default: CALL_E(cur.node, OPUSFE_NONE, LS_P_DEFAULT_1);
+                }
+            }
+            case LS_P_DEFAULT_1: p_finish(rv, false); goto next;
+            case LS_P_DEREF_1: {
+                const opusfe_node c = N(nd.first_child);
+                uint32_t var = try_cast_pointer(rv, cur.aux & 3, c.low, c.high);
+                p_finish(var, true); goto next;
+            }
+            case LS_P_FIELD_1: { uint32_t var = field_access(rv, nd.payload, cur.aux & 3, nd.low, nd.high); p_finish(var, true); goto next; }
+            case LS_P_NC_LOOP:
+                if (cur.b != OPUSFE_NONE) CALL_E(cur.b, TP_GenericInteger, LS_P_NC_ITEM);
+                {
+                    Callee cl; uint32_t var;
+                    if (call_variables(nd.low, nd.high, key_tok(nd.payload), cargs + cur.a, nd.nchild, nd.first_child, false, &cl)) {
+                        push(ins(I_Call, cl.out, cl.fv, 0, cur.a, 0, nd.nchild));
+                        var = cl.out;
+                    } else var = generate_error();
+                    p_finish(var, false); goto next;
+                }
+            case LS_P_NC_ITEM: cargs[cur.a + cur.c] = rv; cur.c++; cur.b = N(cur.b).next; cur.st = LS_P_NC_LOOP; goto next;
+            case LS_P_COI_1: cur.a = rv; cur.b = rl ? 1 : 0; cur.c = N(nd.first_child).next; cur.st = LS_P_IDX_0; goto next;
+            // ---- generate_ir_for_index (:895-967): a indexee, b is_lvalue | mode << 1, c argument cursor, d last value / pool offset, e count ----
+            case LS_P_IDX_0: {
+                bool il = cur.b & 1;
+                uint32_t it = vtype(cur.a);
+                uint32_t indexee_type = it;
+                if (il) { const TypeRec r = S.types[it]; if (r.kind == TY_Pointer) indexee_type = r.sub; else { if (r.kind != TY_Error) unsupported(); indexee_type = TP_Error; } }
+                const TypeRec r = S.types[indexee_type];
+                uint32_t isl, ish;
+                if (nd.kind == E_NamedCall) { isl = S.tok[nd.payload].low; ish = isl + S.tok[nd.payload].len; } else { isl = N(nd.first_child).low; ish = N(nd.first_child).high; }
+                if (r.kind == TY_Pointer) { if (il) cur.a = dereference_pointer(cur.a); cur.b = (IDX_PTR << 1); }
+                else if (r.kind == TY_Array) {
+                    if (!il) { report_node(SE_InvalidLvalue, cur.node); p_finish(generate_error(), true); goto next; }
+                    cur.b = (IDX_ARR << 1);
+                } else if (r.kind == TY_Function) {
+                    if (il) cur.a = dereference_pointer(cur.a);
+                    uint32_t n = 0; for (uint32_t c = cur.c; c != OPUSFE_NONE; c = N(c).next) n++;
+                    cur.b = (IDX_FN << 1);
+                    cur.d = reserve_cargs(n);
+                } else { report(SE_InvalidOperandType, isl, ish); p_finish(generate_error(), true); goto next; }
+                cur.e = 0;
+                cur.st = LS_P_IDX_LOOP;
+                goto next;
+            }
+            case LS_P_IDX_LOOP: {
+                uint32_t mode = cur.b >> 1;
+                if (cur.c != OPUSFE_NONE) CALL_E(cur.c, mode == IDX_FN ? OPUSFE_NONE : (uint32_t)TP_Size, LS_P_IDX_ITEM);
+                const uint8_t pt = cur.aux & 3;
+                uint32_t isl, ish;
+                if (nd.kind == E_NamedCall) { isl = S.tok[nd.payload].low; ish = isl + S.tok[nd.payload].len; } else { isl = N(nd.first_child).low; ish = N(nd.first_child).high; }
+                if (mode == IDX_FN) {
+                    const TypeRec r = S.types[vtype(cur.a)];
+                    uint32_t out = new_var(r.sub, true);
+                    push(ins(I_Call, out, cur.a, 0, cur.d, 0, (uint16_t)cur.e));
+                    if (cur.e > 0xFFFF) unsupported();
+                    p_finish(out, false); goto next;
+                }
+                if (cur.e != 1) report_node(SE_InvalidNumberOfArgs, cur.node);
+                if (cur.e == 0) { unsupported(); p_finish(generate_error(), true); goto next; }   // reference: pop().unwrap() panics
+                const TypeRec r = S.types[vtype(cur.a)];
+                if (mode == IDX_PTR) {
+                    uint32_t result_type;
+                    if (r.ptr == PT_Array) result_type = type_pointer(PT_Array, r.sub);
+                    else if (r.ptr == PT_ArrayMutable) result_type = type_pointer(PT_ArrayMutable, r.sub);
+                    else { report(SE_InvalidOperandType, isl, ish); p_finish(generate_error(), true); goto next; }
+                    uint32_t v = new_var(result_type, true);
+                    push(ins(I_IndexPointer, v, cur.a, cur.d));
+                    p_finish(try_cast_pointer(v, pt, isl, ish), true); goto next;
+                }
+                // array: the indexee is an lvalue pointer to the array
+                if (r.kind != TY_Pointer) { unsupported(); p_finish(generate_error(), true); goto next; }
+                uint32_t result_type = type_pointer(r.ptr, S.types[r.sub].sub);
+                uint32_t v = new_var(result_type, true);
+                push(ins(I_IndexArray, v, cur.a, cur.d));
+                p_finish(try_cast_pointer(v, pt, isl, ish), true); goto next;
+            }
+            case LS_P_IDX_ITEM:
+                if ((cur.b >> 1) == IDX_FN) cargs[cur.d + cur.e] = rv; else cur.d = rv;
+                cur.e++; cur.c = N(cur.c).next; cur.st = LS_P_IDX_LOOP; goto next;
+            // ---- record literal (:1064-1078): a out, b field-init cursor, c value ----
+            case LS_P_REC_LOOP: {
+                if (cur.b == OPUSFE_NONE) { p_finish(cur.a, true); goto next; }
+                uint32_t ft = get_field_type(cur.a, N(cur.b).payload);
+                CALL_E(N(cur.b).first_child, ft, LS_P_REC_ITEM);
+            }
+            case LS_P_REC_ITEM: {
+                const opusfe_node val = N(N(cur.b).first_child);
+                uint32_t fv = field_access(cur.a, N(cur.b).payload, PT_Mutable, val.low, val.high);
+                push(ins(I_Store, 0, fv, rv));
+                cur.b = N(cur.b).next; cur.st = LS_P_REC_LOOP; goto next;
+            }
+            default: internal(); return;
+            }
+        next:;
+        }
+    finished:
+        // epilogue (:151-171)
+        if (rdiv || returns_null) {
+            uint32_t t = bblast[bb_index];
+            bool term = false;
+            if (t != OPUSFE_NONE) { uint16_t op = instrs[t].opcode; term = op == I_Return || op == I_Jump || op == I_Branch || op == I_Unreachable; }
+            if (!term) {
+                if (returns_null) { uint32_t v = new_var(TP_Null, true); push(ins(I_Null, v)); push(ins(I_Return, 0, v)); }
+                else push(ins(I_Unreachable));
+            }
+        } else report_node(SE_FunctionMightNotReturn, def);
+#undef CALL_E
+#undef CALL_P
+#undef CALL_BLOCK
+#undef CALL_STMT
+    }
+};
+
+// one lane per function definition
+__global__ __launch_bounds__(64) void k_lower_functions(SemView S, LowerBuffers B, const uint8_t* __restrict__ undefined_flag, const uint32_t* __restrict__ def_nodes,
+                                                         uint32_t n_defs, uint32_t n_nodes, const DefCnt* __restrict__ def_excl, FuncIr* __restrict__ out,
+                                                         uint32_t* __restrict__ status) {
+    uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= n_defs) return;
+    const uint32_t dn = def_nodes[d];
+    if (S.nodes[dn].kind != D_Function) return;
+    const uint32_t fidx = def_excl[d].funcs;
+    // functions-with-bodies index == position in `out`: computed by the host from a second scan; here we use fidx and
+    // externs simply leave their slot empty (n_instrs == 0, func == NONE)
+    const uint32_t dn_end = d + 1 < n_defs ? def_nodes[d + 1] : n_nodes;
+    const uint32_t nn = dn_end - dn;
+    Lowerer L;
+    L.S = S; L.fidx = fidx; L.F = S.funcs[fidx]; L.undefined_flag = undefined_flag;
+    L.vars = B.vars + lower_base(CAP_VARS, dn, fidx); L.nvars = 0; L.vcap = (uint32_t)lower_cap(CAP_VARS, nn);
+    uint64_t ib = lower_base(CAP_INSTRS, dn, fidx);
+    L.instrs = B.instrs + ib; L.ibb = B.ibb + ib; L.irank = B.irank + ib; L.ninstrs = 0; L.icap = (uint32_t)lower_cap(CAP_INSTRS, nn);
+    uint64_t bbb = lower_base(CAP_BBS, dn, fidx);
+    L.bbcnt = B.bbcnt + bbb; L.bblast = B.bblast + bbb; L.nbbs = 0; L.bcap = (uint32_t)lower_cap(CAP_BBS, nn);
+    L.tbase = B.type_sparse_base + (uint32_t)lower_base(CAP_TYPES, dn, fidx); L.ntypes = 0; L.tcap = (uint32_t)lower_cap(CAP_TYPES, nn);
+    L.cargs = B.cargs + lower_base(CAP_CARGS, dn, fidx); L.ncargs = 0; L.ccap = (uint32_t)lower_cap(CAP_CARGS, nn);
+    uint64_t lb = lower_base(CAP_LOCALS, dn, fidx);
+    L.lname = B.lname + lb; L.lvar = B.lvar + lb; L.nlocals = 0; L.lcap = (uint32_t)lower_cap(CAP_LOCALS, nn);
+    L.lstack = B.lstack + lb; L.nstack = 0;
+    L.frames = B.frames + lower_base(CAP_FRAMES, dn, fidx); L.sp = 0; L.fcap = (uint32_t)lower_cap(CAP_FRAMES, nn);
+    L.errs = B.errs + lower_base(CAP_ERRS, dn, fidx); L.nerrs = 0; L.ecap = (uint32_t)lower_cap(CAP_ERRS, nn);
+    L.bb_index = 0; L.break_head = OPUSFE_NONE; L.loop_begin = OPUSFE_NONE; L.dev_status = DS_OK;
+    L.rv = 0; L.rl = false; L.rdiv = false;
+    // body = last child of the definition
+    uint32_t c = S.nodes[dn].first_child;
+    while (S.nodes[c].next != OPUSFE_NONE) c = S.nodes[c].next;
+    L.run(c);
+    FuncIr r{};
+    r.def_node = dn; r.func = fidx; r.n_vars = L.nvars; r.n_instrs = L.ninstrs; r.n_bbs = L.nbbs; r.n_types = L.ntypes; r.n_cargs = L.ncargs;
+    r.n_errs = L.nerrs < L.ecap ? L.nerrs : L.ecap; r.status = L.dev_status;
+    out[fidx] = r;
+    if (L.dev_status != DS_OK) atomicMax(status, L.dev_status);      // status = {max lane status, number of semantic errors}
+    if (L.nerrs) atomicAdd(status + 1, L.nerrs);
+}
+
+__global__ void k_ir_counts(const FuncIr* __restrict__ f, uint32_t n, IrCnt* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = IrCnt{f[i].n_vars, f[i].n_instrs, f[i].n_bbs, f[i].n_types, f[i].n_cargs, f[i].n_errs};
+}
+
+// per function: dense bases + exclusive scan of its bb sizes into bb_offsets (global instruction indices)
+__global__ void k_ir_bb_offsets(FuncIr* __restrict__ f, uint32_t n, const IrCnt* __restrict__ base, LowerBuffers B, uint32_t* __restrict__ bb_offsets, IrCnt totals_hint) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    FuncIr r = f[i];
+    r.var_base = base[i].vars; r.instr_base = base[i].instrs; r.bb_base = base[i].bbs; r.type_base = base[i].types; r.carg_base = base[i].cargs; r.err_base = base[i].errs;
+    f[i] = r;
+    if (r.n_bbs == 0) return;
+    const uint32_t* cnt = B.bbcnt + lower_base(CAP_BBS, r.def_node, r.func);
+    uint32_t run = r.instr_base;
+    for (uint32_t b = 0; b < r.n_bbs; b++) { bb_offsets[r.bb_base + b] = run; run += cnt[b]; }
+    if (i + 1 == n) bb_offsets[r.bb_base + r.n_bbs] = run;   // sentinel after the last function (filled again below for safety)
+    (void)totals_hint;
+}
+
+struct IrOut { opusfe_variable* vars; opusfe_instr* instrs; uint32_t* cargs; TypeRec* types; SemErr* errs; const uint32_t* bb_offsets; uint32_t n_gtypes; };
+
+// one wave per function (grid-stride)
+__global__ __launch_bounds__(256) void k_ir_compact(const FuncIr* __restrict__ f, uint32_t n, LowerBuffers B, const TypeRec* __restrict__ sparse_types, IrOut O) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t i = wave; i < n; i += nwaves) {
+        const FuncIr r = f[i];
+        if (r.n_bbs == 0) continue;
+        const uint32_t tsb = B.type_sparse_base + (uint32_t)lower_base(CAP_TYPES, r.def_node, r.func);   // first sparse local type id
+        const uint32_t tdb = O.n_gtypes + r.type_base;                                                   // first dense local type id
+        #define REMAP_TYPE(x) ((x) < O.n_gtypes ? (x) : (x) - tsb + tdb)
+        const opusfe_variable* sv = B.vars + lower_base(CAP_VARS, r.def_node, r.func);
+        for (uint32_t j = lane; j < r.n_vars; j += 64) { opusfe_variable v = sv[j]; v.type_id = REMAP_TYPE(v.type_id); O.vars[r.var_base + j] = v; }
+        for (uint32_t j = lane; j < r.n_types; j += 64) {
+            TypeRec t = sparse_types[tsb + j];
+            if (t.kind == TY_Pointer || t.kind == TY_Array || t.kind == TY_Function) t.sub = REMAP_TYPE(t.sub);
+            O.types[tdb + j] = t;
+        }
+        const uint32_t* sc = B.cargs + lower_base(CAP_CARGS, r.def_node, r.func);
+        for (uint32_t j = lane; j < r.n_cargs; j += 64) O.cargs[r.carg_base + j] = sc[j];
+        const SemErr* se = B.errs + lower_base(CAP_ERRS, r.def_node, r.func);
+        for (uint32_t j = lane; j < r.n_errs; j += 64) O.errs[r.err_base + j] = se[j];
+        const uint64_t ib = lower_base(CAP_INSTRS, r.def_node, r.func);
+        for (uint32_t j = lane; j < r.n_instrs; j += 64) {
+            opusfe_instr in = B.instrs[ib + j];
+            if (in.opcode == I_Sizeof || in.opcode == I_Alignof) in.c = REMAP_TYPE(in.c);
+            else if (in.opcode == I_Call) in.c += r.carg_base;
+            O.instrs[O.bb_offsets[r.bb_base + B.ibb[ib + j]] + B.irank[ib + j]] = in;
+        }
+        #undef REMAP_TYPE
+    }
+}
+
+
+// ---- results ------------------------------------------------------------------------------------
+// Dense IR of one unit (device resident; host mirrors are filled lazily for the text dump).
+struct IrResult {
+    // device
+    FuncIr* d_funcs = nullptr; opusfe_variable* d_vars = nullptr; opusfe_instr* d_instrs = nullptr; uint32_t* d_bb_offsets = nullptr;
+    uint32_t* d_cargs = nullptr; TypeRec* d_types = nullptr; SemErr* d_errs = nullptr; FuncRec* d_funcrecs = nullptr; GlobalRec* d_globals = nullptr;
+    uint32_t* d_tid_of_node = nullptr;
+    uint64_t n_funcs = 0, n_globals = 0, n_vars = 0, n_instrs = 0, n_bbs = 0, n_types = 0, n_gtypes = 0, n_cargs = 0, n_errs = 0, n_sem_errors = 0;
+    // host mirrors
+    bool have_host = false;
+    std::vector<FuncIr> funcs; std::vector<opusfe_variable> vars; std::vector<opusfe_instr> instrs; std::vector<uint32_t> bb_offsets, cargs, tid_of_node;
+    std::vector<TypeRec> types; std::vector<SemErr> errs; std::vector<FuncRec> funcrecs; std::vector<GlobalRec> globals;
+};
+
+#ifndef OPUSFE_EMU
+inline void free_ir(opusfe_ctx* ctx, opusfe_unit* u) {
+    IrResult* r = (IrResult*)u->ir;
+    if (!r) return;
+    dev_free(ctx, r->d_funcs); dev_free(ctx, r->d_vars); dev_free(ctx, r->d_instrs); dev_free(ctx, r->d_bb_offsets); dev_free(ctx, r->d_cargs);
+    dev_free(ctx, r->d_types); dev_free(ctx, r->d_errs); dev_free(ctx, r->d_funcrecs); dev_free(ctx, r->d_globals); dev_free(ctx, r->d_tid_of_node);
+    delete r;
+    u->ir = nullptr;
+}
+
+enum { WL_STATUS = 32, WL_ERRS = 33, WL_DEFTOT = 36 /* DefCnt: 4 */, WL_GT = 40, WL_FINERR = 41, WL_IRTOT = 44 /* IrCnt: 6 */, WL_SLOTTOT = 50 };
+
+inline uint32_t next_pow2(uint64_t v) { uint32_t p = 16; while (p < v) p <<= 1; return p; }
+
+// frontend.rs:140-187 (IR part): finalize every definition, then one IrGenerator per Definition::Function
+inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
+    hipStream_t st = ctx->stream;
+    TempList tmp(ctx);
+    free_ir(ctx, u);
+    IrResult* R = new IrResult();
+    u->ir = R;
+    u->lowered = true;
+    u->n_funcs = u->n_instrs = u->n_vars = u->n_bbs = u->n_types = 0;
+    const uint32_t n_defs = (uint32_t)u->n_defs, n_nodes = (uint32_t)u->n_nodes;
+    if (n_defs == 0) { u->status = OPUSFE_OK; R->have_host = true; return; }
+    HIP_TRY(hipMemsetAsync(ctx->d_status + 32, 0, 32 * sizeof(uint32_t), st));
+    uint32_t* scan_tmp = tmp.get<uint32_t>(8 * ((std::max<uint64_t>(n_nodes, n_defs) + SCAN_TILE - 1) / SCAN_TILE + 2));
+
+    // A. classify definitions, number functions / globals / type definitions
+    DefCnt* def_excl = tmp.get<DefCnt>(n_defs);
+    LAUNCH(ctx, "sem_classify", k_sem_classify, grid_for(n_defs, 256), 256, u->d_nodes, u->d_def_nodes, n_defs, def_excl);
+    prof_begin(ctx, "sem_scan_defs");
+    device_scan<true>(def_excl, def_excl, n_defs, OpAddDefCnt(), DefCnt{0, 0, 0, 0}, (DefCnt*)scan_tmp, (DefCnt*)(ctx->d_status + WL_DEFTOT), st);
+    prof_end(ctx);
+    // C1. type slots
+    uint32_t* slot_of_node = tmp.get<uint32_t>(n_nodes);
+    LAUNCH(ctx, "sem_type_flags", k_sem_type_flags, grid_for(n_nodes, 256), 256, u->d_nodes, n_nodes, slot_of_node);
+    prof_begin(ctx, "sem_scan_types");
+    device_scan<true>(slot_of_node, slot_of_node, n_nodes, OpAddU32(), (uint32_t)0, scan_tmp, ctx->d_status + WL_GT, st);
+    prof_end(ctx);
+    HIP_TRY(hipMemcpyAsync(ctx->h_status, ctx->d_status, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    prof_collect(ctx);
+    const uint32_t n_funcs = ctx->h_status[WL_DEFTOT], n_globals = ctx->h_status[WL_DEFTOT + 1], n_named = ctx->h_status[WL_DEFTOT + 3];
+    const uint32_t n_gtypes = TP_COUNT + ctx->h_status[WL_GT];
+
+    // B. name table
+    const uint32_t n_slots = next_pow2(2ull * n_named + 16);
+    NameSlot* slots = tmp.get<NameSlot>(n_slots);
+    NameEntry* entries = tmp.get<NameEntry>(n_named + 1);
+    uint32_t* def_slot = tmp.get<uint32_t>(n_defs);
+    uint32_t* slot_off = tmp.get<uint32_t>(n_slots);
+    LAUNCH(ctx, "sem_slots_init", k_sem_slots_init, grid_for(n_slots, 256), 256, slots, n_slots);
+    LAUNCH(ctx, "sem_table_insert", k_sem_table_insert, grid_for(n_defs, 256), 256, u->d_src, u->d_tokens, u->d_nodes, u->d_def_nodes, n_defs, slots, n_slots - 1, def_slot);
+    LAUNCH(ctx, "sem_slot_counts", k_sem_slot_counts, grid_for(n_slots, 256), 256, slots, n_slots, slot_off);
+    uint32_t* scan_tmp2 = tmp.get<uint32_t>((n_slots + SCAN_TILE - 1) / SCAN_TILE + 2);
+    prof_begin(ctx, "sem_scan_slots");
+    device_scan<true>(slot_off, slot_off, n_slots, OpAddU32(), (uint32_t)0, scan_tmp2, ctx->d_status + WL_SLOTTOT, st);
+    prof_end(ctx);
+    LAUNCH(ctx, "sem_table_fill", k_sem_table_fill, grid_for(n_defs, 256), 256, u->d_nodes, u->d_def_nodes, n_defs, def_excl, def_slot, slot_off, slots, entries);
+    LAUNCH(ctx, "sem_table_sort", k_sem_table_sort, grid_for(n_slots, 256), 256, slots, n_slots, slot_off, entries);
+
+    // C2. resolve every parse-tree type node; D. finalize
+    const uint64_t type_cap = (uint64_t)n_gtypes + (uint64_t)CAP_TYPES * n_nodes + (uint64_t)CAP_CONST * n_funcs + CAP_CONST;
+    if (type_cap >= 0xFFFFFFF0ull) { u->status = OPUSFE_ERR_ARG; ctx->msg = "unit too large for 32-bit type ids: shard it"; return; }
+    TypeRec* types = tmp.get<TypeRec>(type_cap);
+    R->d_tid_of_node = dev_alloc_t<uint32_t>(ctx, n_nodes);
+    uint8_t* undefined_flag = tmp.get<uint8_t>(n_nodes);
+    uint32_t* ph_def = tmp.get<uint32_t>(n_gtypes);
+    R->d_funcrecs = dev_alloc_t<FuncRec>(ctx, n_funcs);
+    R->d_globals = dev_alloc_t<GlobalRec>(ctx, n_globals);
+    LAUNCH(ctx, "sem_resolve_types", k_sem_resolve_types, grid_for(std::max<uint32_t>(n_nodes, TP_COUNT), 256), 256, u->d_src, u->d_tokens, u->d_nodes, n_nodes,
+           slot_of_node, slots, n_slots - 1, entries, R->d_tid_of_node, types, undefined_flag, ph_def);
+    LAUNCH(ctx, "sem_finalize", k_sem_finalize, grid_for(n_defs, 256), 256, u->d_nodes, u->d_def_nodes, n_defs, def_excl, R->d_tid_of_node, undefined_flag,
+           ph_def, n_nodes, types, R->d_funcrecs, R->d_globals, ctx->d_status + WL_FINERR);
+
+    // E. lowering into sparse per-function regions
+    LowerBuffers B{};
+    B.vars = tmp.get<opusfe_variable>(lower_base(CAP_VARS, n_nodes, n_funcs) + CAP_CONST);
+    const uint64_t icap = lower_base(CAP_INSTRS, n_nodes, n_funcs) + CAP_CONST;
+    B.instrs = tmp.get<opusfe_instr>(icap); B.ibb = tmp.get<uint32_t>(icap); B.irank = tmp.get<uint32_t>(icap);
+    const uint64_t bcap = lower_base(CAP_BBS, n_nodes, n_funcs) + CAP_CONST;
+    B.bbcnt = tmp.get<uint32_t>(bcap); B.bblast = tmp.get<uint32_t>(bcap);
+    B.cargs = tmp.get<uint32_t>(lower_base(CAP_CARGS, n_nodes, n_funcs) + CAP_CONST);
+    const uint64_t lcap = lower_base(CAP_LOCALS, n_nodes, n_funcs) + CAP_CONST;
+    B.lname = tmp.get<uint32_t>(lcap); B.lvar = tmp.get<uint32_t>(lcap); B.lstack = tmp.get<uint32_t>(lcap);
+    B.frames = tmp.get<LFrame>(lower_base(CAP_FRAMES, n_nodes, n_funcs) + CAP_CONST);
+    B.errs = tmp.get<SemErr>(lower_base(CAP_ERRS, n_nodes, n_funcs) + CAP_CONST);
+    B.type_sparse_base = n_gtypes;
+    SemView S{u->d_src, u->d_tokens, u->d_val64, u->d_nodes, R->d_tid_of_node, types, slots, n_slots - 1, entries, R->d_funcrecs, R->d_globals, n_gtypes};
+    R->d_funcs = dev_alloc_t<FuncIr>(ctx, n_funcs);
+    HIP_TRY(hipMemsetAsync(R->d_funcs, 0, (size_t)n_funcs * sizeof(FuncIr), st));
+    HIP_TRY(hipMemcpyAsync(ctx->h_status, ctx->d_status, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    prof_collect(ctx);
+    R->n_funcs = n_funcs; R->n_globals = n_globals; R->n_gtypes = n_gtypes;
+    if (ctx->h_status[WL_FINERR] != 0) {   // frontend.rs:145: semantic errors while finalizing -> no IR
+        R->n_sem_errors = ctx->h_status[WL_FINERR];
+        u->status = OPUSFE_SEMANTIC;
+        ctx->msg = "finalize_definition reported semantic errors; IR generation skipped (frontend.rs:145)";
+        return;
+    }
+    if (n_funcs == 0) { u->status = OPUSFE_OK; R->have_host = true; return; }
+    LAUNCH(ctx, "lower_functions", k_lower_functions, grid_for(n_defs, 64), 64, S, B, undefined_flag, u->d_def_nodes, n_defs, n_nodes, def_excl, R->d_funcs,
+           ctx->d_status + WL_STATUS);
+    IrCnt* cnt = tmp.get<IrCnt>(n_funcs);
+    LAUNCH(ctx, "ir_counts", k_ir_counts, grid_for(n_funcs, 256), 256, R->d_funcs, n_funcs, cnt);
+    prof_begin(ctx, "ir_scan");
+    device_scan<true>(cnt, cnt, n_funcs, OpAddIrCnt(), IrCnt{0, 0, 0, 0, 0, 0}, (IrCnt*)scan_tmp, (IrCnt*)(ctx->d_status + WL_IRTOT), st);
+    prof_end(ctx);
+    HIP_TRY(hipMemcpyAsync(ctx->h_status, ctx->d_status, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    prof_collect(ctx);
+    const uint32_t lst = ctx->h_status[WL_STATUS];
+    if (lst >= DS_INTERNAL_CAPACITY) { u->status = OPUSFE_ERR_INTERNAL; ctx->msg = "lowering: internal capacity check failed"; return; }
+    if (lst != DS_OK) { u->status = OPUSFE_UNSUPPORTED; u->dev_status = lst; ctx->msg = "construct on which the reference panics (unreachable!/unwrap) or overflows its stack"; return; }
+    R->n_sem_errors = ctx->h_status[WL_ERRS];
+    const uint32_t* tot = ctx->h_status + WL_IRTOT;
+    R->n_vars = tot[0]; R->n_instrs = tot[1]; R->n_bbs = tot[2]; R->n_types = (uint64_t)n_gtypes + tot[3]; R->n_cargs = tot[4]; R->n_errs = tot[5];
+    // F. dense output
+    R->d_vars = dev_alloc_t<opusfe_variable>(ctx, R->n_vars);
+    R->d_instrs = dev_alloc_t<opusfe_instr>(ctx, R->n_instrs);
+    R->d_bb_offsets = dev_alloc_t<uint32_t>(ctx, R->n_bbs + 1);
+    R->d_cargs = dev_alloc_t<uint32_t>(ctx, R->n_cargs);
+    R->d_types = dev_alloc_t<TypeRec>(ctx, R->n_types);
+    R->d_errs = dev_alloc_t<SemErr>(ctx, R->n_errs);
+    HIP_TRY(hipMemcpyAsync(R->d_types, types, (size_t)n_gtypes * sizeof(TypeRec), hipMemcpyDeviceToDevice, st));
+    const uint32_t n_instrs32 = (uint32_t)R->n_instrs;
+    HIP_TRY(hipMemcpyAsync(R->d_bb_offsets + R->n_bbs, &n_instrs32, 4, hipMemcpyHostToDevice, st));
+    LAUNCH(ctx, "ir_bb_offsets", k_ir_bb_offsets, grid_for(n_funcs, 64), 64, R->d_funcs, n_funcs, cnt, B, R->d_bb_offsets, IrCnt{});
+    IrOut O{R->d_vars, R->d_instrs, R->d_cargs, R->d_types, R->d_errs, R->d_bb_offsets, n_gtypes};
+    unsigned grid = (unsigned)((n_funcs + 3) / 4);
+    if (grid > 8192) grid = 8192;
+    LAUNCH(ctx, "ir_compact", k_ir_compact, grid, 256, R->d_funcs, n_funcs, B, types, O);
+    HIP_TRY(hipStreamSynchronize(st));
+    prof_collect(ctx);
+    u->n_funcs = n_funcs; u->n_instrs = R->n_instrs; u->n_vars = R->n_vars; u->n_bbs = R->n_bbs; u->n_types = R->n_types;
+    u->status = OPUSFE_OK;
+}
+
+inline void ensure_host_ir(opusfe_unit* u) {
+    IrResult* R = (IrResult*)u->ir;
+    if (!R || R->have_host) return;
+    hipStream_t st = u->ctx->stream;
+    auto pull = [&](auto& vec, const auto* dptr, uint64_t n) {
+        vec.resize(n);
+        if (n && dptr) HIP_TRY(hipMemcpyAsync(vec.data(), dptr, n * sizeof(vec[0]), hipMemcpyDeviceToHost, st));
+    };
+    pull(R->funcs, R->d_funcs, R->n_funcs); pull(R->vars, R->d_vars, R->n_vars); pull(R->instrs, R->d_instrs, R->n_instrs);
+    pull(R->bb_offsets, R->d_bb_offsets, R->d_bb_offsets ? R->n_bbs + 1 : 0); pull(R->cargs, R->d_cargs, R->n_cargs); pull(R->types, R->d_types, R->d_types ? R->n_types : 0);
+    pull(R->errs, R->d_errs, R->n_errs); pull(R->funcrecs, R->d_funcrecs, R->n_funcs); pull(R->globals, R->d_globals, R->n_globals);
+    pull(R->tid_of_node, R->d_tid_of_node, u->n_nodes);
+    HIP_TRY(hipStreamSynchronize(st));
+    R->have_host = true;
+}
+#endif  // OPUSFE_EMU
+
+}  // namespace opusfe

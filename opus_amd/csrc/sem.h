@@ -1,0 +1,533 @@
+// Semantic tables on the GPU (restates the parts of compile.rs that IR generation leans on):
+//   names       : open-addressing table  name -> definitions of that name in definition order
+//                 (name_resolution_map / global_resolution_map / type_resolution_map, compile.rs:12-16,30-31)
+//   types       : one 16-byte record per type.  resolve_type (compile.rs:919-966) is a pure function of
+//                 the parse-tree type node, so it is evaluated for EVERY Y_* node of the AST in one
+//                 node-parallel kernel; `type X` placeholders (preload_definition, compile.rs:968-981)
+//                 are filled by finalize (compile.rs:1055-1062) with the Q14 "copy the current contents" rule.
+//   functions   : user functions / externs in definition order; the 131 builtin overloads
+//                 (compile.rs:404-500) are encoded arithmetically in the function id.
+//   type algebra: types_match*, can_autocast, can_cast (compile.rs:599-775) as device functions.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "unit.h"
+#include "scan.h"
+
+namespace opusfe {
+
+// PrimitiveType order of compile.rs:324-344 == type ids 0..17
+enum : uint32_t { TP_Integer8 = 0, TP_Integer16, TP_Integer32, TP_Integer64, TP_Natural8, TP_Natural16, TP_Natural32, TP_Natural64,
+                  TP_Bool, TP_Null, TP_Error, TP_GenericInteger, TP_Generic, TP_String, TP_Size, TP_Offset, TP_Float32, TP_Float64,
+                  TP_COUNT };
+enum TypeSrc : uint8_t { TS_NONE = 0, TS_NODE = 1, TS_FUNC = 2 };
+
+struct TypeRec {
+    uint8_t kind;      // TyKind
+    uint8_t ptr;       // PtrKind (Pointer)
+    uint8_t src;       // Record / Function: where the member list lives
+    uint8_t pad;
+    uint32_t sub;      // Pointer / Array: element type; Function: return type
+    uint32_t ref;      // Record: Y_Record node; Function: Y_Proc node (TS_NODE) or function index (TS_FUNC); Array: Integer token
+    uint32_t alias;    // name token of the `type` definition this id is the placeholder of, else NONE
+};
+static_assert(sizeof(TypeRec) == 16, "type record");
+
+struct FuncRec { uint32_t def_node; uint32_t name_tok; uint32_t nargs; uint32_t ret; uint32_t first_arg; uint32_t flags; };   // flags bit0 = extern
+struct GlobalRec { uint32_t def_node; uint32_t type_id; uint32_t is_const; uint32_t name_tok; };
+struct NameSlot { uint32_t rep; uint32_t count; uint32_t offset; uint32_t fill; };   // rep = representative name token (NONE = empty)
+struct NameEntry { uint32_t def_node; uint32_t kind_index; };                          // kind in the top 2 bits: 0 function, 1 global, 2 type
+enum { NK_FUNCTION = 0u, NK_GLOBAL = 1u, NK_TYPE = 2u };
+
+// builtin function ids: 0x80000000 | sym-token-kind << 8 | index into the overload list of that symbol
+#define FN_BUILTIN 0x80000000u
+#define FN_NONE 0xFFFFFFFFu
+
+// Everything device code needs to look things up; passed by value to kernels.
+struct SemView {
+    const uint8_t* src;
+    const opusfe_token* tok;
+    const uint64_t* val64;
+    const opusfe_node* nodes;
+    const uint32_t* tid_of_node;     // Y_* nodes: resolved type id; D_Type: placeholder id
+    TypeRec* types;                  // global records [0, n_gtypes), then per-function local regions
+    const NameSlot* slots; uint32_t slot_mask;
+    const NameEntry* entries;
+    const FuncRec* funcs;
+    const GlobalRec* globals;
+    uint32_t n_gtypes;
+};
+
+// ---- names ------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint32_t fnv1a(const char* s, int n) { uint32_t h = 2166136261u; for (int i = 0; i < n; i++) h = (h ^ (uint8_t)s[i]) * 16777619u; return h; }
+// symbol text of the token that may follow `operator` (parse.rs:224-243, 773-801)
+__host__ __device__ __forceinline__ const char* sym_text(uint8_t k, int* n) {
+    switch (k) {
+        case T_Plus: *n = 1; return "+"; case T_Minus: *n = 1; return "-"; case T_Asterisk: *n = 1; return "*"; case T_Slash: *n = 1; return "/";
+        case T_Percent: *n = 1; return "%"; case T_EqualsEquals: *n = 1; return "="; case T_LessThan: *n = 1; return "<";
+        case T_GreaterThan: *n = 1; return ">"; case T_LessThanEquals: *n = 2; return "<="; case T_GreaterThanEquals: *n = 2; return ">=";
+        case T_Is: *n = 2; return "is"; case T_Not: *n = 3; return "not"; case T_For: *n = 3; return "for"; case T_Continue: *n = 8; return "continue";
+        default: *n = 0; return "";
+    }
+}
+__host__ __device__ __forceinline__ uint8_t sym_of_op(uint8_t op) {
+    switch (op) {
+        case OP_Plus: return T_Plus; case OP_Minus: return T_Minus; case OP_Times: return T_Asterisk; case OP_Divide: return T_Slash;
+        case OP_Modulo: return T_Percent; case OP_Equals: return T_EqualsEquals; case OP_LessThan: return T_LessThan;
+        case OP_GreaterThan: return T_GreaterThan; case OP_LessThanEquals: return T_LessThanEquals;
+        case OP_GreaterThanEquals: return T_GreaterThanEquals; case OP_Is: return T_Is; case OP_Not: return T_Not;
+        default: return T_EndOfFile;
+    }
+}
+// A name is either an identifier token or the symbol of an operator-ish token kind.
+struct NameKey { uint32_t tok; uint8_t sym; };   // tok != NONE: identifier/operator token in the source; else symbol kind
+__host__ __device__ __forceinline__ uint8_t name_sym(const opusfe_token* tok, NameKey k) { return k.tok != OPUSFE_NONE ? (tok[k.tok].kind == T_Identifier ? (uint8_t)T_Identifier : tok[k.tok].kind) : k.sym; }
+__host__ __device__ __forceinline__ uint32_t name_hash(const opusfe_token* tok, NameKey k) {
+    uint8_t s = name_sym(tok, k);
+    if (s == T_Identifier) return tok[k.tok].payload;
+    int n; const char* t = sym_text(s, &n);
+    return fnv1a(t, n);
+}
+__host__ __device__ __forceinline__ bool name_eq(const uint8_t* src, const opusfe_token* tok, NameKey a, NameKey b) {
+    uint8_t sa = name_sym(tok, a), sb = name_sym(tok, b);
+    if (sa != sb) return false;
+    if (sa != T_Identifier) return true;
+    const opusfe_token& x = tok[a.tok]; const opusfe_token& y = tok[b.tok];
+    if (x.len != y.len || x.payload != y.payload) return false;
+    if (x.low == y.low) return true;
+    for (uint32_t i = 0; i < x.len; i++) if (src[x.low + i] != src[y.low + i]) return false;
+    return true;
+}
+__host__ __device__ __forceinline__ bool name_is(const uint8_t* src, const opusfe_token* tok, uint32_t t, const char* lit, uint32_t n) {
+    const opusfe_token& x = tok[t];
+    if (x.kind != T_Identifier || x.len != n) return false;
+    for (uint32_t i = 0; i < n; i++) if (src[x.low + i] != (uint8_t)lit[i]) return false;
+    return true;
+}
+__host__ __device__ __forceinline__ NameKey key_tok(uint32_t t) { return NameKey{t, 0}; }
+__host__ __device__ __forceinline__ NameKey key_sym(uint8_t s) { return NameKey{OPUSFE_NONE, s}; }
+
+// slot of a name, or NONE
+__device__ __forceinline__ uint32_t name_find(const SemView& S, NameKey k) {
+    uint32_t h = name_hash(S.tok, k) & S.slot_mask;
+    for (uint32_t probe = 0; probe <= S.slot_mask; probe++) {
+        uint32_t rep = S.slots[h].rep;
+        if (rep == OPUSFE_NONE) return OPUSFE_NONE;
+        if (name_eq(S.src, S.tok, k, key_tok(rep))) return h;
+        h = (h + 1) & S.slot_mask;
+    }
+    return OPUSFE_NONE;
+}
+// last entry of the given kind for a name (HashMap::insert overwrites: the last definition wins), or NONE
+__device__ __forceinline__ uint32_t name_last(const SemView& S, NameKey k, uint32_t kind) {
+    uint32_t s = name_find(S, k);
+    if (s == OPUSFE_NONE) return OPUSFE_NONE;
+    const NameSlot sl = S.slots[s];
+    for (uint32_t j = sl.count; j > 0; j--) {
+        NameEntry e = S.entries[sl.offset + j - 1];
+        if ((e.kind_index >> 30) == kind) return sl.offset + j - 1;
+    }
+    return OPUSFE_NONE;
+}
+
+// ---- builtin overloads (compile.rs:404-500) -----------------------------------------------------
+__host__ __device__ __forceinline__ int builtin_count(uint8_t sym) {
+    switch (sym) {
+        case T_Plus: case T_Minus: case T_Asterisk: case T_Slash: case T_Percent: return 12;
+        case T_EqualsEquals: case T_LessThan: case T_GreaterThan: case T_LessThanEquals: case T_GreaterThanEquals: return 14;
+        case T_Not: return 1;
+        default: return 0;
+    }
+}
+__host__ __device__ __forceinline__ uint32_t builtin_arg_type(uint8_t sym, int idx) {
+    const uint32_t ARITH[12] = {TP_Integer8, TP_Integer16, TP_Integer32, TP_Integer64, TP_Natural8, TP_Natural16, TP_Natural32, TP_Natural64,
+                                TP_Size, TP_Offset, TP_Float32, TP_Float64};
+    const uint32_t CMP[14] = {TP_Integer8, TP_Integer16, TP_Integer32, TP_Integer64, TP_Natural8, TP_Natural16, TP_Natural32, TP_Natural64,
+                              TP_Size, TP_Offset, TP_Bool, TP_Null, TP_Float32, TP_Float64};
+    int n = builtin_count(sym);
+    if (n == 12) return ARITH[idx];
+    if (n == 14) return CMP[idx];
+    return TP_Bool;
+}
+__host__ __device__ __forceinline__ uint32_t builtin_ret_type(uint8_t sym, int idx) { return builtin_count(sym) == 12 ? builtin_arg_type(sym, idx) : (uint32_t)TP_Bool; }
+__host__ __device__ __forceinline__ uint32_t builtin_nargs(uint8_t sym) { return sym == T_Not ? 1u : 2u; }
+
+// ---- type algebra -------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint8_t prim_kind(uint32_t p) {
+    const uint8_t K[TP_COUNT] = {TY_Integer8, TY_Integer16, TY_Integer32, TY_Integer64, TY_Natural8, TY_Natural16, TY_Natural32, TY_Natural64,
+                                 TY_Bool, TY_Null, TY_Error, TY_GenericInteger, TY_Generic, TY_String, TY_Size, TY_Offset, TY_Float32, TY_Float64};
+    return K[p];
+}
+__host__ __device__ __forceinline__ bool kind_is_integral(uint8_t k) {   // compile.rs:172-180
+    return k <= TY_Natural64 || k == TY_Size || k == TY_Offset;
+}
+
+struct TypeOps {
+    const SemView& S;
+    uint32_t* dev_status;   // lane-local status word (DS_UNSUPPORTED_SEMANTIC when the reference would overflow its stack)
+    __device__ __forceinline__ TypeRec rec(uint32_t t) const { return S.types[t]; }
+    __device__ __forceinline__ uint8_t kind(uint32_t t) const { return S.types[t].kind; }
+    __device__ __forceinline__ bool is_integral(uint32_t t) const { return kind_is_integral(kind(t)); }
+
+    // member lists of Record / Function types
+    __device__ uint32_t member_count(const TypeRec& r) const {
+        if (r.kind == TY_Record) return S.nodes[r.ref].nchild;
+        if (r.kind == TY_Function) return r.src == TS_FUNC ? S.funcs[r.ref].nargs : (uint32_t)S.nodes[r.ref].nchild - 1u;
+        return 0;
+    }
+    // iterator over members: cursor is an AST node (X_NamedType for records and functions from definitions; Y_* for Proc types)
+    __device__ uint32_t member_first(const TypeRec& r) const {
+        if (r.kind == TY_Function && r.src == TS_FUNC) return S.funcs[r.ref].first_arg;
+        return S.nodes[r.ref].first_child;
+    }
+    __device__ uint32_t member_next(uint32_t cur) const { return S.nodes[cur].next; }
+    __device__ uint32_t member_type(uint32_t cur) const {
+        const opusfe_node& n = S.nodes[cur];
+        return n.kind == X_NamedType ? S.tid_of_node[n.first_child] : S.tid_of_node[cur];
+    }
+    __device__ uint32_t member_name(uint32_t cur) const { return S.nodes[cur].payload; }
+    __device__ uint64_t array_size(const TypeRec& r) const {
+        const opusfe_token& t = S.tok[r.ref];
+        return (t.flags & OPUSFE_TF_INLINE) ? (uint64_t)t.payload : S.val64[t.payload];
+    }
+
+    // compile.rs:698-751, recursion replaced by a bounded work list (the reference recurses without a
+    // cycle check: on a self-referential record it overflows its stack; we report UNSUPPORTED instead)
+    __device__ bool types_match(uint32_t a0, uint32_t b0) const {
+        uint32_t stack_a[48], stack_b[48];
+        int sp = 0;
+        uint32_t a = a0, b = b0;
+        uint32_t budget = 1u << 20;
+        for (;;) {
+            if (--budget == 0) { *dev_status = DS_UNSUPPORTED_SEMANTIC; return false; }
+            bool descend = false;
+            {
+                const TypeRec ra = S.types[a], rb = S.types[b];
+                if (ra.kind != rb.kind) return false;
+                switch (ra.kind) {
+                    case TY_Pointer: if (ra.ptr != rb.ptr) return false; a = ra.sub; b = rb.sub; descend = true; break;
+                    case TY_Array: if (array_size(ra) != array_size(rb)) return false; a = ra.sub; b = rb.sub; descend = true; break;
+                    case TY_Record: {
+                        uint32_t n = member_count(ra);
+                        if (n != member_count(rb)) return false;
+                        uint32_t ca = member_first(ra), cb = member_first(rb);
+                        for (uint32_t i = 0; i < n; i++) {
+                            if (!name_eq(S.src, S.tok, key_tok(member_name(ca)), key_tok(member_name(cb)))) return false;
+                            if (sp >= 48) { *dev_status = DS_UNSUPPORTED_SEMANTIC; return false; }
+                            stack_a[sp] = member_type(ca); stack_b[sp] = member_type(cb); sp++;
+                            ca = member_next(ca); cb = member_next(cb);
+                        }
+                        break;
+                    }
+                    case TY_Function: {
+                        uint32_t n = member_count(ra);
+                        if (n != member_count(rb)) return false;
+                        if (sp >= 48) { *dev_status = DS_UNSUPPORTED_SEMANTIC; return false; }
+                        stack_a[sp] = ra.sub; stack_b[sp] = rb.sub; sp++;
+                        uint32_t ca = member_first(ra), cb = member_first(rb);
+                        for (uint32_t i = 0; i < n; i++) {
+                            if (sp >= 48) { *dev_status = DS_UNSUPPORTED_SEMANTIC; return false; }
+                            stack_a[sp] = member_type(ca); stack_b[sp] = member_type(cb); sp++;
+                            ca = member_next(ca); cb = member_next(cb);
+                        }
+                        break;
+                    }
+                    default: break;   // payload-free kinds, including (Error, Error)
+                }
+            }
+            if (descend) continue;
+            if (sp == 0) return true;
+            sp--; a = stack_a[sp]; b = stack_b[sp];
+        }
+    }
+    // compile.rs:753-763
+    __device__ bool types_match_allow_generic(uint32_t a, uint32_t b) const {
+        uint8_t ka = kind(a), kb = kind(b);
+        if ((ka == TY_GenericInteger && kind_is_integral(kb)) || (kb == TY_GenericInteger && kind_is_integral(ka))) return true;
+        if (ka == TY_Generic || kb == TY_Generic) return true;
+        return types_match(a, b);
+    }
+    // compile.rs:765-775
+    __device__ bool types_match_default_generic(uint32_t a, uint32_t b) const {
+        uint8_t ka = kind(a), kb = kind(b);
+        if ((ka == TY_GenericInteger && kb == TY_Integer32) || (ka == TY_Integer32 && kb == TY_GenericInteger)) return true;
+        if (ka == TY_Generic || kb == TY_Generic) return false;
+        return types_match(a, b);
+    }
+    // compile.rs:672-680
+    __device__ static bool can_autocast_pointer_type(uint8_t from, uint8_t to) {
+        return from == to || (from == PT_Mutable && to == PT_Reference) || (from == PT_ArrayMutable && to == PT_Array);
+    }
+    // compile.rs:624-670; returns CastKind or -1
+    __device__ int can_autocast(uint32_t from, uint32_t to) const {
+        if (types_match(from, to)) return CT_None;
+        const TypeRec t1 = S.types[from], t2 = S.types[to];
+        if (t1.kind == TY_Error || t2.kind == TY_Error) return CT_Error;
+        if (t1.kind == TY_GenericInteger && kind_is_integral(t2.kind)) return CT_Error;
+        if (t1.kind == TY_Generic) return CT_Error;
+        if (t1.kind == TY_Pointer && t2.kind == TY_Pointer) {
+            uint8_t p1 = t1.ptr, p2 = t2.ptr;
+            if (can_autocast_pointer_type(p1, p2) && types_match(t1.sub, t2.sub)) return CT_PointerType;
+            if (((p1 == PT_Mutable && p2 == PT_ArrayMutable) || (p1 == PT_Mutable && p2 == PT_Array) || (p1 == PT_Reference && p2 == PT_Array))
+                && types_match(t2.sub, TP_Natural8)) return CT_PointerType;
+            if (((p1 == PT_ArrayMutable && p2 == PT_Mutable) || (p1 == PT_ArrayMutable && p2 == PT_Reference) || (p1 == PT_Array && p2 == PT_Reference))
+                && types_match(t1.sub, TP_Natural8)) return CT_PointerType;
+            const TypeRec s1 = S.types[t1.sub];
+            if (s1.kind == TY_Array && types_match(s1.sub, t2.sub)) {
+                if ((p1 == PT_Reference && p2 == PT_Array) || (p1 == PT_Mutable && p2 == PT_ArrayMutable) || (p1 == PT_Mutable && p2 == PT_Array)) return CT_PointerToArray;
+                return -1;
+            }
+            return -1;
+        }
+        return -1;
+    }
+    // compile.rs:682-696
+    __device__ int can_cast(uint32_t from, uint32_t to) const {
+        int c = can_autocast(from, to);
+        if (c >= 0) return c;
+        const TypeRec t1 = S.types[from], t2 = S.types[to];
+        if (kind_is_integral(t1.kind) && kind_is_integral(t2.kind)) return CT_Integer;
+        if (t1.kind == TY_Pointer && t2.kind == TY_Pointer && t1.ptr == t2.ptr) return CT_Pointer;
+        if ((t1.kind == TY_Pointer || t1.kind == TY_Function) && kind_is_integral(t2.kind)) return CT_PointerToInteger;
+        if ((t2.kind == TY_Pointer || t2.kind == TY_Function) && kind_is_integral(t1.kind)) return CT_IntegerToPointer;
+        return -1;
+    }
+};
+
+// ---- table construction kernels -----------------------------------------------------------------
+struct DefCnt { uint32_t funcs, globals, types, named; };
+struct OpAddDefCnt { __host__ __device__ DefCnt operator()(DefCnt a, DefCnt b) const { return DefCnt{a.funcs + b.funcs, a.globals + b.globals, a.types + b.types, a.named + b.named}; } };
+
+__global__ void k_sem_classify(const opusfe_node* __restrict__ nodes, const uint32_t* __restrict__ def_nodes, uint32_t n_defs, DefCnt* __restrict__ out) {
+    uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= n_defs) return;
+    uint8_t k = nodes[def_nodes[d]].kind;
+    DefCnt c{0, 0, 0, 0};
+    if (k == D_Function || k == D_Extern) c.funcs = 1;
+    else if (k == D_Variable || k == D_Constant) c.globals = 1;
+    else if (k == D_Type) c.types = 1;
+    c.named = c.funcs + c.globals + c.types;
+    out[d] = c;
+}
+
+__device__ __forceinline__ uint32_t def_entry_kind(uint8_t k) { return (k == D_Function || k == D_Extern) ? NK_FUNCTION : (k == D_Type ? NK_TYPE : NK_GLOBAL); }
+
+// claims / finds the slot of the definition's name and counts it
+__global__ void k_sem_table_insert(const uint8_t* __restrict__ src, const opusfe_token* __restrict__ tok, const opusfe_node* __restrict__ nodes,
+                                   const uint32_t* __restrict__ def_nodes, uint32_t n_defs, NameSlot* __restrict__ slots, uint32_t slot_mask,
+                                   uint32_t* __restrict__ def_slot) {
+    uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= n_defs) return;
+    const opusfe_node& n = nodes[def_nodes[d]];
+    if (n.kind == D_Import || n.kind == D_Library) { def_slot[d] = OPUSFE_NONE; return; }
+    NameKey key = key_tok(n.payload);
+    uint32_t h = name_hash(tok, key) & slot_mask;
+    for (uint32_t probe = 0; probe <= slot_mask; probe++) {
+        uint32_t rep = atomicCAS(&slots[h].rep, OPUSFE_NONE, n.payload);
+        if (rep == OPUSFE_NONE || name_eq(src, tok, key, key_tok(rep))) { atomicAdd(&slots[h].count, 1u); def_slot[d] = h; return; }
+        h = (h + 1) & slot_mask;
+    }
+    def_slot[d] = OPUSFE_NONE;   // cannot happen: the table has more slots than definitions
+}
+
+__global__ void k_sem_slot_counts(const NameSlot* __restrict__ slots, uint32_t n_slots, uint32_t* __restrict__ counts) {
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n_slots) counts[s] = slots[s].count;
+}
+
+__global__ void k_sem_table_fill(const opusfe_node* __restrict__ nodes, const uint32_t* __restrict__ def_nodes, uint32_t n_defs,
+                                 const DefCnt* __restrict__ def_excl, const uint32_t* __restrict__ def_slot, const uint32_t* __restrict__ slot_off,
+                                 NameSlot* __restrict__ slots, NameEntry* __restrict__ entries) {
+    uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= n_defs) return;
+    uint32_t s = def_slot[d];
+    if (s == OPUSFE_NONE) return;
+    uint8_t k = nodes[def_nodes[d]].kind;
+    uint32_t kind = def_entry_kind(k);
+    uint32_t index = kind == NK_FUNCTION ? def_excl[d].funcs : kind == NK_GLOBAL ? def_excl[d].globals : def_excl[d].types;
+    uint32_t pos = slot_off[s] + atomicAdd(&slots[s].fill, 1u);
+    entries[pos] = NameEntry{def_nodes[d], (kind << 30) | index};
+}
+
+// one lane per slot: writes the offset and orders the slot's entries by definition (insertion sort; groups are tiny)
+__global__ void k_sem_table_sort(NameSlot* __restrict__ slots, uint32_t n_slots, const uint32_t* __restrict__ slot_off, NameEntry* __restrict__ entries) {
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_slots) return;
+    uint32_t off = slot_off[s], n = slots[s].count;
+    slots[s].offset = off;
+    for (uint32_t i = 1; i < n; i++) {
+        NameEntry e = entries[off + i];
+        uint32_t j = i;
+        while (j > 0 && entries[off + j - 1].def_node > e.def_node) { entries[off + j] = entries[off + j - 1]; j--; }
+        entries[off + j] = e;
+    }
+}
+
+__global__ void k_sem_slots_init(NameSlot* __restrict__ slots, uint32_t n_slots) {
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n_slots) slots[s] = NameSlot{OPUSFE_NONE, 0, 0, 0};
+}
+
+// nodes that own a fresh type record: structured parse-tree types and `type` definitions (their placeholder)
+__global__ void k_sem_type_flags(const opusfe_node* __restrict__ nodes, uint32_t n_nodes, uint32_t* __restrict__ flag) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    uint8_t k = nodes[i].kind;
+    flag[i] = (k == D_Type || (k >= Y_Reference && k <= Y_Array)) ? 1u : 0u;
+}
+
+// resolve_type for every parse-tree type node (compile.rs:919-966).  The id of a child is a pure function of the
+// child node, so no ordering between lanes is needed.
+__device__ __forceinline__ uint32_t sem_type_id_of(const uint8_t* src, const opusfe_token* tok, const opusfe_node* nodes, const uint32_t* slot_of_node,
+                                                   const NameSlot* slots, uint32_t slot_mask, const NameEntry* entries, uint32_t y, bool* undefined) {
+    const opusfe_node& n = nodes[y];
+    if (n.kind == Y_Null) return TP_Null;
+    if (n.kind != Y_Name) return TP_COUNT + slot_of_node[y];
+    uint32_t t = n.payload;
+    if (tok[t].kind == T_Identifier) {
+        struct { const char* s; uint32_t n; uint32_t id; } const B[14] = {
+            {"int8", 4, TP_Integer8}, {"int16", 5, TP_Integer16}, {"int32", 5, TP_Integer32}, {"int64", 5, TP_Integer64},
+            {"nat8", 4, TP_Natural8}, {"nat16", 5, TP_Natural16}, {"nat32", 5, TP_Natural32}, {"nat64", 5, TP_Natural64},
+            {"size", 4, TP_Size}, {"offset", 6, TP_Offset}, {"float32", 7, TP_Float32}, {"float64", 7, TP_Float64},
+            {"bool", 4, TP_Bool}, {"string", 6, TP_String}};
+        uint32_t len = tok[t].len;
+        if (len >= 4 && len <= 7)
+            for (int i = 0; i < 14; i++) if (name_is(src, tok, t, B[i].s, B[i].n)) return B[i].id;
+    }
+    // type_resolution_map: the last `type` definition of that name
+    NameKey key = key_tok(t);
+    uint32_t h = name_hash(tok, key) & slot_mask;
+    for (uint32_t probe = 0; probe <= slot_mask; probe++) {
+        uint32_t rep = slots[h].rep;
+        if (rep == OPUSFE_NONE) break;
+        if (name_eq(src, tok, key, key_tok(rep))) {
+            const NameSlot sl = slots[h];
+            for (uint32_t j = sl.count; j > 0; j--) {
+                NameEntry e = entries[sl.offset + j - 1];
+                if ((e.kind_index >> 30) == NK_TYPE) return TP_COUNT + slot_of_node[e.def_node];
+            }
+            break;
+        }
+        h = (h + 1) & slot_mask;
+    }
+    *undefined = true;
+    return TP_Error;
+}
+
+__global__ void k_sem_resolve_types(const uint8_t* __restrict__ src, const opusfe_token* __restrict__ tok, const opusfe_node* __restrict__ nodes, uint32_t n_nodes,
+                                    const uint32_t* __restrict__ slot_of_node, const NameSlot* __restrict__ slots, uint32_t slot_mask,
+                                    const NameEntry* __restrict__ entries, uint32_t* __restrict__ tid_of_node, TypeRec* __restrict__ types,
+                                    uint8_t* __restrict__ undefined_flag, uint32_t* __restrict__ ph_def) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < TP_COUNT) { TypeRec p{}; p.kind = prim_kind(i); p.alias = OPUSFE_NONE; types[i] = p; }   // launched with >= TP_COUNT lanes
+    if (i >= n_nodes) return;
+    const opusfe_node n = nodes[i];
+    undefined_flag[i] = 0;
+    if (n.kind == D_Type) {
+        uint32_t id = TP_COUNT + slot_of_node[i];
+        TypeRec r{}; r.kind = TY_Error; r.alias = n.payload;      // preload_definition: placeholder (compile.rs:968-981)
+        types[id] = r;
+        tid_of_node[i] = id;
+        ph_def[slot_of_node[i]] = i;
+        return;
+    }
+    if (n.kind < Y_Name || n.kind > Y_Array) { tid_of_node[i] = OPUSFE_NONE; return; }
+    bool undef = false;
+    uint32_t id = sem_type_id_of(src, tok, nodes, slot_of_node, slots, slot_mask, entries, i, &undef);
+    tid_of_node[i] = id;
+    undefined_flag[i] = undef ? 1 : 0;
+    if (n.kind == Y_Name || n.kind == Y_Null) return;
+    ph_def[slot_of_node[i]] = OPUSFE_NONE;
+    TypeRec r{}; r.alias = OPUSFE_NONE;
+    bool u2 = false;
+    switch (n.kind) {
+        case Y_Reference: r.kind = TY_Pointer; r.ptr = PT_Reference; break;
+        case Y_MutableReference: r.kind = TY_Pointer; r.ptr = PT_Mutable; break;
+        case Y_ArrayReference: r.kind = TY_Pointer; r.ptr = PT_Array; break;
+        case Y_MutableArrayReference: r.kind = TY_Pointer; r.ptr = PT_ArrayMutable; break;
+        case Y_Array: r.kind = TY_Array; r.ref = n.payload; break;
+        case Y_Record: r.kind = TY_Record; r.src = TS_NODE; r.ref = i; break;
+        default: r.kind = TY_Function; r.src = TS_NODE; r.ref = i; break;   // Y_Proc
+    }
+    if (n.kind == Y_Proc) {
+        uint32_t c = n.first_child;
+        for (uint32_t k = 0; k + 1 < n.nchild; k++) c = nodes[c].next;
+        r.sub = sem_type_id_of(src, tok, nodes, slot_of_node, slots, slot_mask, entries, c, &u2);   // return type = last child
+    } else if (n.kind != Y_Record) {
+        r.sub = sem_type_id_of(src, tok, nodes, slot_of_node, slots, slot_mask, entries, n.first_child, &u2);
+    }
+    types[id] = r;
+}
+
+// Contents of a type id as finalize_definition of the definition at node `at_def` sees them (compile.rs:1055-1062,
+// Q14): a `type` placeholder holds Type::Error until its own definition has been finalized, and an alias of an
+// alias captures whatever the target held at that moment.  Decided from the AST alone (placeholders are written
+// concurrently by other lanes of k_sem_finalize), returns the record and whether it is final.
+__device__ __forceinline__ TypeRec sem_contents_at(const opusfe_node* nodes, const uint32_t* tid_of_node, const TypeRec* types,
+                                                   const uint32_t* ph_def, uint32_t tid, uint32_t at_def, uint32_t n_defs) {
+    TypeRec content{}; content.kind = TY_Error; content.alias = OPUSFE_NONE;
+    for (uint32_t guard = 0; guard < n_defs + 2; guard++) {
+        if (tid < TP_COUNT) { content.kind = prim_kind(tid); return content; }
+        uint32_t def = ph_def[tid - TP_COUNT];
+        if (def == OPUSFE_NONE) return types[tid];               // structured type: its record never changes
+        if (def >= at_def) { content.kind = TY_Error; return content; }   // not finalized yet (or itself)
+        at_def = def;
+        tid = tid_of_node[nodes[def].first_child];               // what that definition copied from
+    }
+    return content;
+}
+
+// finalize_definition (compile.rs:1002-1065), one lane per definition.  err[0] counts semantic errors
+// (has_errors): with any, frontend.rs:145 skips IR generation.
+__global__ void k_sem_finalize(const opusfe_node* __restrict__ nodes, const uint32_t* __restrict__ def_nodes, uint32_t n_defs,
+                               const DefCnt* __restrict__ def_excl, const uint32_t* __restrict__ tid_of_node, const uint8_t* __restrict__ undefined_flag,
+                               const uint32_t* __restrict__ ph_def, uint32_t n_nodes, TypeRec* __restrict__ types, FuncRec* __restrict__ funcs,
+                               GlobalRec* __restrict__ globals, uint32_t* __restrict__ err) {
+    uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= n_defs) return;
+    const uint32_t dn = def_nodes[d];
+    const uint32_t dn_end = d + 1 < n_defs ? def_nodes[d + 1] : n_nodes;
+    const opusfe_node n = nodes[dn];
+    uint32_t nerr = 0;
+    switch (n.kind) {
+        case D_Function: case D_Extern: {
+            FuncRec f{}; f.def_node = dn; f.name_tok = n.payload; f.flags = n.kind == D_Extern ? 1u : 0u;
+            uint32_t c = n.first_child;
+            f.first_arg = OPUSFE_NONE;
+            while (nodes[c].kind == X_NamedType) { if (f.nargs == 0) f.first_arg = c; f.nargs++; c = nodes[c].next; }
+            f.ret = tid_of_node[c];
+            // UndefinedType errors of the signature: its nodes are the contiguous range up to the body
+            uint32_t sig_end = nodes[c].next != OPUSFE_NONE ? nodes[c].next : dn_end;
+            for (uint32_t y = dn + 1; y < sig_end; y++) nerr += undefined_flag[y];
+            funcs[def_excl[d].funcs] = f;
+            break;
+        }
+        case D_Variable: case D_Constant: {
+            uint32_t ty = n.first_child;
+            uint32_t tid = tid_of_node[ty];
+            uint32_t val = nodes[ty].next;
+            uint32_t ty_end = val != OPUSFE_NONE ? val : dn_end;
+            for (uint32_t y = ty; y < ty_end; y++) nerr += undefined_flag[y];
+            if (val != OPUSFE_NONE) {
+                // make_value (compile.rs:983-1000): Integer or Negate(Integer) only; type_is_valid (compile.rs:154-170)
+                const opusfe_node v = nodes[val];
+                bool is_int = v.kind == E_Integer || (v.kind == E_Negate && nodes[v.first_child].kind == E_Integer);
+                if (!is_int) nerr++;
+                else if (!kind_is_integral(sem_contents_at(nodes, tid_of_node, types, ph_def, tid, dn, n_defs).kind)) nerr++;
+            }
+            GlobalRec g{dn, tid, n.kind == D_Constant ? 1u : 0u, n.payload};
+            globals[def_excl[d].globals] = g;
+            break;
+        }
+        case D_Type: {
+            for (uint32_t y = n.first_child; y < dn_end; y++) nerr += undefined_flag[y];
+            TypeRec content = sem_contents_at(nodes, tid_of_node, types, ph_def, tid_of_node[n.first_child], dn, n_defs);
+            content.alias = n.payload;
+            types[tid_of_node[dn]] = content;
+            break;
+        }
+        default: break;
+    }
+    if (nerr) atomicAdd(err, nerr);
+}
+
+}  // namespace opusfe

@@ -40,3 +40,56 @@ PARSE_CASES = [
     "f() null\n\tx = g(\na,\nb)\n\ty = 1\n", "var x @ @mut @ {} {} mut {3} (int32) null\n",
     "f() null\n\tx = 1 +\n", "f() null\n\tx = 1 + )\n", "f() null\n\tx = \"bad \\q esc\"\n", "f() null\n\tif a\n\t\tb\n\t\"bad \\q esc\" c\n\td\n",
 ]
+
+# IR generation inputs (all parse): well-typed programs exercising every lowering path, then ill-typed ones whose IR
+# contains Error instructions and whose semantic diagnostics are compared too.
+IR_CASES = [
+    "main() int32\n\treturn 1 + 2 * 3\n",
+    "f() null\n\tvar s = \"hi\\n\"\n\tvar d = s.data\n\tvar l = s.length\n",
+    "var g int32 = 5\nconst c int64 = -7\nf() int64\n\tg = g + 1\n\treturn c\n",
+    "f(p @mut int32, q @int32) int32\n\tp@ = q@ + 1\n\treturn p@\n",
+    "f(a {} nat8, b mut {} nat8) nat8\n\tb(1) = a(0)\n\treturn b(2)\n",
+    "f() int32\n\tvar arr {4} int32\n\tarr(0) = 1\n\tvar p = ref arr\n\tvar q {} int32 = p\n\treturn arr(1) + q(0)\n",
+    "g(x int32) int32 return x\nf() int32\n\tvar h = proc g(int32)\n\tvar k = g\n\treturn h(1) + k(2) + g(3)\n",
+    "type P = record { x int32 y float64 }\nf() float64\n\tvar p = record P { x = 1 y = 2.5 }\n\tp.x = 3\n\tvar q = mut p\n\tq@.y = 1.0\n\treturn p.y\n",
+    "f(a int32, b int64) bool\n\treturn a:int64 < b and not (a == 3) or a >= 2\n",
+    "f(a @int32, b @int32) bool return a is b\n",
+    "f(a int8) int8 return -a\nh() int32 return -5\nk() int64\n\tvar z int64 = -9\n\treturn z\n",
+    "f() size return sizeof int32 + alignof @int64\n",
+    "f(a int32) int32\n\twhile true\n\t\tif a > 3\n\t\t\tbreak\n\t\ta = a + 1\n\t\tcontinue\n\treturn a\n",
+    "f(a int32) int32\n\twhile a < 3\n\t\ta = a + 1\n\telse\n\t\treturn 0\n\treturn a\n",
+    "f(a bool) null\n\tif a\n\t\treturn null\n",
+    "f(a bool) int32\n\tif a\n\t\treturn 1\n\telse\n\t\treturn 2\n",
+    "f(a bool) int32\n\twhile true\n\t\ta = a\n",
+    "type R = record { lo int32 hi int32 }\ntype I = record { cur int32 hi int32 }\noperator for(r R) I\n\treturn record I { cur = r.lo hi = r.hi }\n"
+    "operator continue(it @mut I, x @mut int32) bool\n\tif it@.cur < it@.hi\n\t\tx@ = it@.cur\n\t\tit@.cur = it@.cur + 1\n\t\treturn true\n\treturn false\n"
+    "f(r R) int32\n\tvar s = 0\n\tfor i in r\n\t\ts = s + i\n\tfor j int32 in r\n\t\tif j > 2\n\t\t\tbreak\n\telse\n\t\ts = 0\n\treturn s\n",
+    "type V = record { x int32 }\noperator +(a V, b V) V return a\noperator ==(a V, b V) bool return true\noperator not(a V) bool return false\n"
+    "f(a V, b V) bool\n\tvar c = a + b\n\treturn c == a and not b\n",
+    "f(a int32) int32\n\tvar a = 3\n\treturn a\n",
+    "f() int32\n\tvar x nat8 = 200\n\tvar y = x + 5\n\tvar z int64 = 1 + 2\n\treturn 1\n",
+    "f(p @mut @mut int32) int32 return p@@\n",
+    "type T = @@@@@@@@int32\nf(t T) int32 return t@@@@@@@@\n",
+    "f() int32\n\tvar f2 (int32) int32\n\treturn f2(1)\n",
+    "extern puts(s {} nat8) int32\nf() int32\n\treturn puts(\"x\".data)\n",
+    "f(x int32) int32\n\treturn ((x)) + (1)\n",
+    "f() float32 return 1.5f32\ng() float64 return 2.5 * 2.0\n",
+    "f(a int32) int32\n\tvar b = a\n\tif a > 0\n\t\tvar c = b\n\t\tb = c\n\tvar c = 1\n\treturn b + c\n",
+    "f(a nat8, b nat8) nat8 return a % b / 2n8\n",
+    "type A = B\ntype B = int32\nf(a A, b B) int32 return b\n",
+    "f(s string) size return s.length\n",
+    "f(p mut {} int32) @mut int32\n\treturn mut p(3)\n",
+    "f(r @mut {3} int32) int32\n\treturn r@(1)\n",
+    "f() int32\n\tvar i = 0\n\twhile i < 10 and true\n\t\ti = i + 1\n\t\tbreak\n\treturn i\n",
+    # ill-typed / erroneous programs (semantic errors; IR still generated)
+    "f() int32\n\treturn x\n", "f() int32\n\tvar a = 1\n\tvar a = 2\n\treturn a\n", "f() int32\n\treturn g(1)\n",
+    "g(a bool) int32 return 1\nf() int32\n\treturn g(1)\n", "f() int32\n\treturn true\n", "f() int32\n\tvar x = 1\n", "f() null\n\tbreak\n\tcontinue\n",
+    "f() null\n\t1 = 2\n", "f(a @int32) null\n\ta@ = 1\n", "f(a int32) null\n\tvar b = a:bool\n", "f(a int32) null\n\tvar b = a.x\n",
+    "type P = record { x int32 }\nf(p P) null\n\tvar b = p.y\n", "f(a int32) null\n\tvar b = a(1)\n", "f() null\n\tvar b = proc +(int32, int32)\n",
+    "const c int32 = 1\nf() null\n\tvar b = c(1)\n", "f(a {} int32) null\n\tvar b = a(1, 2)\n", "f(a float64) float64 return -a\n",
+    "f(a int32, b bool) null\n\tvar c = a and b\n\tvar d = b and a\n", "f(a int32, b bool) null\n\tvar c = a is b\n", "f() null\n\tvar a Undefined\n",
+    "g(a int32) int32 return a\ng(a int64) int32 return 1\nf() null\n\tvar a = g\n\tvar b = g(1)\n", "f() null\n\tvar a = ref 1\n",
+    "f(a int32) null\n\tvar b = refs a\n",
+    # finalize errors: no IR
+    "f(a Undefined) null\n\treturn null\n", "var g int32 = 1 + 2\n", "var g bool = 1\n", "type A = Undefined\n",
+]

@@ -16,10 +16,8 @@
 #include "parse.h"
 #include "dump.h"
 #include "dump_ast.h"
-#ifdef OPUSFE_EMU_LOWER
 #include "lower.h"
 #include "dump_ir.h"
-#endif
 
 using namespace opusfe;
 
@@ -157,11 +155,111 @@ void emu_parse(EmuUnit& E) {
     u.status = OPUSFE_OK;
 }
 
+
+template <class T> T* exact(size_t n) { return (T*)calloc(n ? n : 1, sizeof(T)); }   // exact-size heap blocks: ASan sees overruns
+
+void emu_lower(EmuUnit& E) {
+    opusfe_unit& u = E.u;
+    IrResult* R = new IrResult();
+    u.ir = R; u.lowered = true;
+    const uint32_t n_defs = (uint32_t)u.n_defs, n_nodes = (uint32_t)u.n_nodes;
+    R->have_host = true;
+    if (n_defs == 0) return;
+    const opusfe_node* nodes = u.h_nodes.data();
+    const opusfe_token* tok = u.h_tokens.data();
+    const uint32_t* def_nodes = u.h_def_nodes.data();
+    std::vector<DefCnt> def_excl(n_defs);
+    emu_launch(k_sem_classify, grid_for(n_defs, 256), 256, nodes, def_nodes, n_defs, def_excl.data());
+    DefCnt dt{0, 0, 0, 0};
+    for (uint32_t d = 0; d < n_defs; d++) { DefCnt c = def_excl[d]; def_excl[d] = dt; dt = OpAddDefCnt()(dt, c); }
+    std::vector<uint32_t> slot_of_node(n_nodes);
+    emu_launch(k_sem_type_flags, grid_for(n_nodes, 256), 256, nodes, n_nodes, slot_of_node.data());
+    uint32_t gt = 0;
+    for (uint32_t i = 0; i < n_nodes; i++) { uint32_t f = slot_of_node[i]; slot_of_node[i] = gt; gt += f; }
+    const uint32_t n_funcs = dt.funcs, n_globals = dt.globals, n_named = dt.named, n_gtypes = TP_COUNT + gt;
+    uint32_t n_slots = 16; while (n_slots < 2ull * n_named + 16) n_slots <<= 1;
+    NameSlot* slots = exact<NameSlot>(n_slots);
+    NameEntry* entries = exact<NameEntry>(n_named + 1);
+    std::vector<uint32_t> def_slot(n_defs), slot_off(n_slots);
+    emu_launch(k_sem_slots_init, grid_for(n_slots, 256), 256, slots, n_slots);
+    emu_launch(k_sem_table_insert, grid_for(n_defs, 256), 256, E.src.data(), tok, nodes, def_nodes, n_defs, slots, n_slots - 1, def_slot.data());
+    emu_launch(k_sem_slot_counts, grid_for(n_slots, 256), 256, slots, n_slots, slot_off.data());
+    { uint32_t run = 0; for (uint32_t i = 0; i < n_slots; i++) { uint32_t c = slot_off[i]; slot_off[i] = run; run += c; } }
+    emu_launch(k_sem_table_fill, grid_for(n_defs, 256), 256, nodes, def_nodes, n_defs, def_excl.data(), def_slot.data(), slot_off.data(), slots, entries);
+    emu_launch(k_sem_table_sort, grid_for(n_slots, 256), 256, slots, n_slots, slot_off.data(), entries);
+    const uint64_t type_cap = (uint64_t)n_gtypes + (uint64_t)CAP_TYPES * n_nodes + (uint64_t)CAP_CONST * n_funcs + CAP_CONST;
+    TypeRec* types = exact<TypeRec>(type_cap);
+    R->tid_of_node.assign(n_nodes, 0);
+    std::vector<uint8_t> undefined_flag(n_nodes);
+    std::vector<uint32_t> ph_def(n_gtypes);
+    R->funcrecs.assign(n_funcs, FuncRec{}); R->globals.assign(n_globals, GlobalRec{});
+    emu_launch(k_sem_resolve_types, grid_for(std::max<uint32_t>(n_nodes, TP_COUNT), 256), 256, E.src.data(), tok, nodes, n_nodes, slot_of_node.data(), slots, n_slots - 1,
+               entries, R->tid_of_node.data(), types, undefined_flag.data(), ph_def.data());
+    uint32_t finerr = 0;
+    emu_launch(k_sem_finalize, grid_for(n_defs, 256), 256, nodes, def_nodes, n_defs, def_excl.data(), R->tid_of_node.data(), undefined_flag.data(), ph_def.data(), n_nodes,
+               types, R->funcrecs.data(), R->globals.data(), &finerr);
+    R->n_funcs = n_funcs; R->n_globals = n_globals; R->n_gtypes = n_gtypes;
+    if (finerr) { R->n_sem_errors = finerr; u.status = OPUSFE_SEMANTIC; free(slots); free(entries); free(types); return; }
+    if (n_funcs == 0) { free(slots); free(entries); free(types); return; }
+    LowerBuffers B{};
+    B.vars = exact<opusfe_variable>(lower_base(CAP_VARS, n_nodes, n_funcs) + CAP_CONST);
+    const uint64_t icap = lower_base(CAP_INSTRS, n_nodes, n_funcs) + CAP_CONST;
+    B.instrs = exact<opusfe_instr>(icap); B.ibb = exact<uint32_t>(icap); B.irank = exact<uint32_t>(icap);
+    const uint64_t bcap = lower_base(CAP_BBS, n_nodes, n_funcs) + CAP_CONST;
+    B.bbcnt = exact<uint32_t>(bcap); B.bblast = exact<uint32_t>(bcap);
+    B.cargs = exact<uint32_t>(lower_base(CAP_CARGS, n_nodes, n_funcs) + CAP_CONST);
+    const uint64_t lcap = lower_base(CAP_LOCALS, n_nodes, n_funcs) + CAP_CONST;
+    B.lname = exact<uint32_t>(lcap); B.lvar = exact<uint32_t>(lcap); B.lstack = exact<uint32_t>(lcap);
+    B.frames = exact<LFrame>(lower_base(CAP_FRAMES, n_nodes, n_funcs) + CAP_CONST);
+    B.errs = exact<SemErr>(lower_base(CAP_ERRS, n_nodes, n_funcs) + CAP_CONST);
+    B.type_sparse_base = n_gtypes;
+    SemView S{E.src.data(), tok, u.h_val64.data(), nodes, R->tid_of_node.data(), types, slots, n_slots - 1, entries, R->funcrecs.data(), R->globals.data(), n_gtypes};
+    R->funcs.assign(n_funcs, FuncIr{});
+    uint32_t lstatus[2] = {0, 0};
+    emu_launch(k_lower_functions, grid_for(n_defs, 64), 64, S, B, (const uint8_t*)undefined_flag.data(), def_nodes, n_defs, n_nodes, (const DefCnt*)def_excl.data(),
+               R->funcs.data(), lstatus);
+    std::vector<IrCnt> cnt(n_funcs);
+    emu_launch(k_ir_counts, grid_for(n_funcs, 256), 256, (const FuncIr*)R->funcs.data(), n_funcs, cnt.data());
+    IrCnt tot{0, 0, 0, 0, 0, 0};
+    for (uint32_t i = 0; i < n_funcs; i++) { IrCnt c = cnt[i]; cnt[i] = tot; tot = OpAddIrCnt()(tot, c); }
+    if (getenv("EMU_VERBOSE")) {
+        double mv = 0, mi = 0, mb = 0, mt = 0;
+        for (auto& f : R->funcs) if (f.n_bbs) {
+            uint32_t d = 0; while (def_nodes[d] != f.def_node) d++;
+            double nn = (d + 1 < n_defs ? def_nodes[d + 1] : n_nodes) - f.def_node;
+            mv = std::max(mv, f.n_vars / nn); mi = std::max(mi, f.n_instrs / nn); mb = std::max(mb, f.n_bbs / nn); mt = std::max(mt, f.n_types / nn);
+        }
+        fprintf(stderr, "max per-node ratios: vars %.2f instrs %.2f bbs %.2f types %.2f\n", mv, mi, mb, mt);
+    }
+    bool cleanup_only = false;
+    if (lstatus[0] >= DS_INTERNAL_CAPACITY) { u.status = OPUSFE_ERR_INTERNAL; cleanup_only = true; }
+    else if (lstatus[0] != DS_OK) { u.status = OPUSFE_UNSUPPORTED; u.dev_status = lstatus[0]; cleanup_only = true; }
+    if (!cleanup_only) {
+        R->n_sem_errors = lstatus[1];
+        R->n_vars = tot.vars; R->n_instrs = tot.instrs; R->n_bbs = tot.bbs; R->n_types = (uint64_t)n_gtypes + tot.types; R->n_cargs = tot.cargs; R->n_errs = tot.errs;
+        opusfe_variable* dv = exact<opusfe_variable>(R->n_vars); opusfe_instr* di = exact<opusfe_instr>(R->n_instrs);
+        uint32_t* dbo = exact<uint32_t>(R->n_bbs + 1); uint32_t* dc = exact<uint32_t>(R->n_cargs);
+        TypeRec* dty = exact<TypeRec>(R->n_types); SemErr* de = exact<SemErr>(R->n_errs);
+        memcpy(dty, types, (size_t)n_gtypes * sizeof(TypeRec));
+        dbo[R->n_bbs] = (uint32_t)R->n_instrs;
+        emu_launch(k_ir_bb_offsets, grid_for(n_funcs, 64), 64, R->funcs.data(), n_funcs, (const IrCnt*)cnt.data(), B, dbo, IrCnt{});
+        IrOut O{dv, di, dc, dty, de, dbo, n_gtypes};
+        emu_launch(k_ir_compact, 2, 256, (const FuncIr*)R->funcs.data(), n_funcs, B, (const TypeRec*)types, O);
+        R->vars.assign(dv, dv + R->n_vars); R->instrs.assign(di, di + R->n_instrs); R->bb_offsets.assign(dbo, dbo + R->n_bbs + 1);
+        R->cargs.assign(dc, dc + R->n_cargs); R->types.assign(dty, dty + R->n_types); R->errs.assign(de, de + R->n_errs);
+        free(dv); free(di); free(dbo); free(dc); free(dty); free(de);
+        u.n_funcs = n_funcs; u.n_instrs = R->n_instrs; u.n_vars = R->n_vars;
+    }
+    free(slots); free(entries); free(types);
+    free(B.vars); free(B.instrs); free(B.ibb); free(B.irank); free(B.bbcnt); free(B.bblast); free(B.cargs); free(B.lname); free(B.lvar); free(B.lstack);
+    free(B.frames); free(B.errs);
+}
+
 }  // namespace
 
 extern "C" {
 
-// what: 0 tokens, 1 AST, 3 error line, 5 lexer alone (force_dents).  *status receives the OPUSFE_* code.
+// what: 0 tokens, 1 AST, 2 IR, 3 error line, 4 semantic errors, 5 lexer alone (force_dents).  *status receives the OPUSFE_* code.
 char* emu_dump(const uint8_t* src, uint64_t len, int what, uint64_t* out_len, int* status) {
     EmuUnit E;
     E.src.assign(src, src + len);
@@ -170,14 +268,18 @@ char* emu_dump(const uint8_t* src, uint64_t len, int what, uint64_t* out_len, in
     E.u.h_src.assign(src, src + len);
     emu_lex(E, what == 5);
     if (what != 5 && (E.u.status == OPUSFE_OK || E.u.status == OPUSFE_UNSUPPORTED)) emu_parse(E);
+    if ((what == 2 || what == 4) && E.u.status == OPUSFE_OK) emu_lower(E);
     std::string s;
     switch (what) {
         case 0: case 5: s = dump_tokens(&E.u, E.u.has_error ? (uint64_t)E.u.error.tok_index + 1 : ~0ull); break;
         case 1: s = E.u.status == OPUSFE_OK ? dump_ast(&E.u) : std::string(); break;
+        case 2: s = dump_ir(&E.u); break;
+        case 4: s = dump_semantic_errors(&E.u); break;
         case 3: s = E.u.status == OPUSFE_ERR_INTERNAL ? std::string("Internal\n") : dump_error_line(&E.u); break;
         default: break;
     }
     if (status) *status = E.u.status;
+    delete (IrResult*)E.u.ir;
     if (out_len) *out_len = s.size();
     char* p = (char*)malloc(s.size() + 1);
     memcpy(p, s.data(), s.size()); p[s.size()] = 0;

@@ -21,9 +21,10 @@ struct uint2 { unsigned x, y; };
 struct EmuDim3 { unsigned x = 0, y = 0, z = 0; };
 inline thread_local EmuDim3 threadIdx, blockIdx, blockDim, gridDim;
 
-template <class T> inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
-template <class T> inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
-template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
+template <class T, class U> inline T atomicMax(T* p, U v) { T o = *p; if ((T)v > o) *p = (T)v; return o; }
+template <class T, class U> inline T atomicMin(T* p, U v) { T o = *p; if ((T)v < o) *p = (T)v; return o; }
+template <class T, class U, class V> inline T atomicCAS(T* p, U cmp, V val) { T o = *p; if (o == (T)cmp) *p = (T)val; return o; }
+template <class T, class U> inline T atomicAdd(T* p, U v) { T o = *p; *p = o + (T)v; return o; }
 [[noreturn]] inline void emu_collective() { fprintf(stderr, "emu: cross-lane primitive executed\n"); abort(); }
 inline int __shfl_up(int, int, int) { emu_collective(); }
 inline int __shfl_down(int, int, int) { emu_collective(); }

@@ -6,7 +6,7 @@ import pytest
 
 import emu_lib as E
 import oracle_lib as O
-from cases import LEX_CASES, PARSE_CASES
+from cases import IR_CASES, LEX_CASES, PARSE_CASES
 
 
 def compare_parse(cases):
@@ -62,3 +62,25 @@ def test_emu_parser_injected_faults():
 def test_emu_parser_truncations():
     src = O.generate(77, 1500)
     compare_parse([src[:n] for n in range(0, len(src), 5)])
+
+
+def compare_ir(cases):
+    cases = [c for c in cases if O.dump(c, O.ERROR) == "Ok\n"]
+    irs = E.dump_many(cases, 2)
+    sems = E.dump_many(cases, 4)
+    for c, (st, ir), (_, sem) in zip(cases, irs, sems):
+        want_ir, want_sem = O.dump(c, O.IR), O.dump(c, O.SEM)
+        if want_ir == "" and want_sem != "":
+            assert st == 7, c[:80]
+            continue
+        assert st == 0, (st, c[:80])
+        assert ir == want_ir, c[:80]
+        assert sem == want_sem, c[:80]
+
+
+def test_emu_ir_hand_cases():
+    compare_ir([s.encode() for s in IR_CASES] + [s.encode() for s in PARSE_CASES])
+
+
+def test_emu_ir_generated_and_deep():
+    compare_ir([O.generate(1, 4096), O.generate(2, 70000), O.generate(3, 2 << 20, flags=1)])

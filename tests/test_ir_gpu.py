@@ -1,0 +1,88 @@
+"""GPU IR-generation parity: the `opus -Z` text (impl Display for IrGenerator) and the semantic diagnostics of IR generation
+vs the CPU oracle, bit-exact."""
+import json
+import os
+
+import pytest
+
+import oracle_lib as O
+from cases import IR_CASES, PARSE_CASES
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+with open(os.path.join(HERE, "golden", "kats.json")) as f:
+    KATS = json.load(f)
+
+
+def first_diff(got, want):
+    g, w = got.split("\n"), want.split("\n")
+    for i, (a, b) in enumerate(zip(g, w)):
+        if a != b:
+            return f"line {i}: got {a[:200]!r} want {b[:200]!r}; context {w[max(0, i - 8):i + 2]}"
+    return f"length differs: got {len(g)} want {len(w)}"
+
+
+def check_ir(fe, src: bytes):
+    if O.dump(src, O.ERROR) != "Ok\n":
+        return None
+    want_ir, want_sem = O.dump(src, O.IR), O.dump(src, O.SEM)
+    u = fe.get_definitions(src)
+    assert u.status == 0
+    rc = u.compile_source()
+    if want_ir == "" and want_sem != "":
+        assert rc == 7, "finalize errors: the reference generates no IR (frontend.rs:145)"
+        return u
+    assert rc == 0, (rc, fe.message())
+    got = u.dump_ir()
+    assert got == want_ir, first_diff(got, want_ir)
+    assert u._dump(4) == want_sem
+    return u
+
+
+def test_kat_ir_matches_hand_derived_fixtures(fe):
+    for k in ("kat1", "kat2", "kat3"):
+        u = fe.get_definitions(KATS[k]["src"].encode())
+        assert u.compile_source() == 0
+        assert u.dump_ir() == KATS[k]["ir"]
+    e2 = KATS["kat_e"][1]
+    u = fe.get_definitions(e2["src"].encode())
+    assert u.compile_source() == 0 and u.dump_ir() == e2["ir"]
+
+
+@pytest.mark.parametrize("src", IR_CASES, ids=[f"ir{i}" for i in range(len(IR_CASES))])
+def test_ir_hand_cases(fe, src):
+    check_ir(fe, src.encode())
+
+
+def test_ir_of_parser_cases(fe):
+    for s in PARSE_CASES:
+        check_ir(fe, s.encode())
+
+
+@pytest.mark.parametrize("seed,size", [(1, 4096), (2, 70000), (3, 1 << 20), (11, 3 << 20)])
+def test_generated_ir(fe, seed, size):
+    u = check_ir(fe, O.generate(seed, size))
+    c = u.counts()
+    assert c["functions"] > 0 and c["instrs"] > 0 and c["vars"] > 0
+
+
+def test_deep_regions_ir(fe):
+    check_ir(fe, O.generate(3, 2 << 20, flags=1))
+
+
+def test_c1_ten_thousand_lines_all_dumps(fe):
+    """BASELINE config 1: the 10k-line source, every dump compared."""
+    src = O.generate_lines(1, 10000)
+    u = check_ir(fe, src)
+    assert u.dump_tokens() == O.dump(src, O.TOKENS)
+    assert u.dump_ast() == O.dump(src, O.AST)
+
+
+def test_lowering_twice_is_idempotent(fe):
+    src = O.generate(21, 50000)
+    u = fe.get_definitions(src)
+    assert u.compile_source() == 0
+    a = u.dump_ir()
+    assert u.compile_source() == 0
+    assert u.dump_ir() == a == O.dump(src, O.IR)
