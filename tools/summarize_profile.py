@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Condenses gpurun_out/prof_<tag>/ (tools/profile.sh) into profiles/<tag>_summary.md + the raw kernel_stats.csv."""
+import collections
+import csv
+import os
+import shutil
+import sys
+
+tag = sys.argv[1]
+src = os.path.join("gpurun_out", f"prof_{tag}")
+os.makedirs("profiles", exist_ok=True)
+stats = list(csv.DictReader(open(os.path.join(src, "trace", "t_kernel_stats.csv"))))
+shutil.copy(os.path.join(src, "trace", "t_kernel_stats.csv"), os.path.join("profiles", f"{tag}_kernel_stats.csv"))
+
+
+def short(name):
+    return name.split("(")[0].replace("void ", "").replace("opusfe::", "")
+
+
+def pmc(path, counter):
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    if not os.path.exists(path):
+        return agg
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            k = short(r["Kernel_Name"])
+            agg[k][0] += 1
+            agg[k][1] += float(r["Counter_Value"])
+    return agg
+
+
+fetch = pmc(os.path.join(src, "pmc_fetch", "f_counter_collection.csv"), "FETCH_SIZE")
+write = pmc(os.path.join(src, "pmc_write", "w_counter_collection.csv"), "WRITE_SIZE")
+with open(os.path.join("profiles", f"{tag}_summary.md"), "w") as f:
+    f.write(f"# rocprofv3 summary `{tag}`\n\nCommand: `tools/profile.sh {tag} {' '.join(sys.argv[2:])}` "
+            "(kernel-trace --stats; FETCH_SIZE and WRITE_SIZE in separate --pmc passes).\n"
+            "FETCH_SIZE / WRITE_SIZE are rocprofv3's KB figures per launch; on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x "
+            "and is uncalibrated for the narrow per-lane accesses of the parser / lowering kernels (MI355X_MICROARCH.md, HBM section): "
+            "read them as relative evidence of over-fetch, not as absolutes.\n\n"
+            "| kernel | calls | avg ms | % time | FETCH_SIZE MB/launch | WRITE_SIZE MB/launch |\n|---|---|---|---|---|---|\n")
+    for r in stats[:28]:
+        k = short(r["Name"])
+        fs = fetch[k][1] / fetch[k][0] / 1e3 if fetch[k][0] else float("nan")
+        ws = write[k][1] / write[k][0] / 1e3 if write[k][0] else float("nan")
+        f.write(f"| {k} | {r['Calls']} | {float(r['AverageNs']) / 1e6:.4f} | {float(r['Percentage']):.2f} | {fs:.1f} | {ws:.1f} |\n")
+print(open(os.path.join("profiles", f"{tag}_summary.md")).read())
