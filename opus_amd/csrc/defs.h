@@ -5,6 +5,15 @@
 
 #define OPUSFE_NONE 0xFFFFFFFFu
 
+// Lanes that work on one unit (segment / function) in the sequential-machine kernels.  On the GPU a whole wave runs
+// ONE unit with wave-uniform control flow: no divergence, and every memory instruction touches one cache line
+// instead of 64.  The host emulation (tests/emu) runs one lane per unit.
+#ifdef OPUSFE_EMU
+#define UNIT_LANES 1u
+#else
+#define UNIT_LANES 64u
+#endif
+
 // parse.rs:5-67, same order as the reference's enum Token.
 enum TokKind : uint8_t {
     T_LeftParenthesis, T_RightParenthesis, T_LeftSquareBracket, T_RightSquareBracket, T_LeftBrace, T_RightBrace,

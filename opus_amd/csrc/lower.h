@@ -46,6 +46,48 @@ struct LowerBuffers {
     uint32_t type_sparse_base;   // id of the first local type slot (== n_gtypes)
 };
 
+// Per-unit working set kept in LDS (one wave == one function): the first entries of every table live here and only
+// larger functions spill to the sparse global regions.  All lanes execute the same instruction stream on the same
+// addresses, so an LDS read is a broadcast and a global access touches one cache line.
+enum { LDS_FRAMES = 32, LDS_VARS = 1024, LDS_BBS = 256, LDS_LOCALS = 64, LDS_TYPES = 192 };
+struct LowerLds {
+    LFrame frames[LDS_FRAMES];
+    uint32_t vtype[LDS_VARS];
+    uint32_t bbcnt[LDS_BBS], bblast[LDS_BBS];
+    uint32_t lname[LDS_LOCALS], lvar[LDS_LOCALS], lhash[LDS_LOCALS], lstack[LDS_LOCALS];
+    TypeRec types[LDS_TYPES];
+};
+
+#ifdef OPUSFE_EMU
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return v; }
+#else
+// value known to be identical in every lane -> SGPR (scalar branches, fewer VGPRs)
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+#endif
+__device__ __forceinline__ LFrame uni(const LFrame& f) {
+    union { LFrame f; uint32_t w[8]; } a, b;
+    a.f = f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) b.w[i] = uni(a.w[i]);
+    return b.f;
+}
+__device__ __forceinline__ opusfe_node uni(const opusfe_node& n) {
+    union { opusfe_node n; uint32_t w[6]; } a, b;
+    a.n = n;
+#pragma unroll
+    for (int i = 0; i < 6; i++) b.w[i] = uni(a.w[i]);
+    return b.n;
+}
+
+// optional cycle accounting of the lowering machine (build with -DOPUSFE_LOWER_PROF; bench prints the table)
+#ifdef OPUSFE_LOWER_PROF
+#define LPROF(id) ProfScope _ps_##id{prof, id}
+struct ProfScope { uint64_t* p; int id; uint64_t t0; __device__ ProfScope(uint64_t* p_, int i) : p(p_), id(i), t0(__builtin_readcyclecounter()) {} __device__ ~ProfScope() { p[id] += __builtin_readcyclecounter() - t0; } };
+#else
+#define LPROF(id) do { } while (0)
+#endif
+enum { LP_TOTAL = 0, LP_NODE, LP_LOCALFIND, LP_CALLVARS, LP_AUTOCAST, LP_TRYCAST, LP_LOOKUPNAME, LP_FIELD, LP_PUSH, LP_NEWVAR, LP_FRAMES, LP_LOOKUPFN, LP_COUNT };
+
 enum LState : uint8_t {
     LS_BLOCK, LS_BLOCK_LOOP, LS_BLOCK_ITEM,
     LS_STMT, LS_ST_EXPR_1, LS_ST_VDEF_1, LS_ST_ASG_1, LS_ST_ASG_2, LS_ST_RET_1, LS_ST_IF_1, LS_ST_IF_2, LS_ST_IF_3, LS_ST_WH_1, LS_ST_FOR_1,
@@ -60,6 +102,7 @@ enum { IDX_PTR = 0, IDX_ARR = 1, IDX_FN = 2 };
 
 struct Lowerer {
     SemView S;
+    LowerLds* lds;
     uint32_t fidx; FuncRec F;
     // sparse regions of this function
     opusfe_variable* vars; uint32_t nvars, vcap;
@@ -76,11 +119,59 @@ struct Lowerer {
     uint32_t dev_status;
     LFrame cur;
     uint32_t rv; bool rl; bool rdiv;
+#ifdef OPUSFE_LOWER_PROF
+    mutable uint64_t prof[LP_COUNT];
+#endif
 
     __device__ __forceinline__ void internal() { if (dev_status < DS_INTERNAL_CAPACITY) dev_status = DS_INTERNAL_CAPACITY; }
     __device__ __forceinline__ void unsupported() { if (dev_status < DS_UNSUPPORTED_SEMANTIC) dev_status = DS_UNSUPPORTED_SEMANTIC; }
-    __device__ __forceinline__ const opusfe_node& N(uint32_t i) const { return S.nodes[i]; }
-    __device__ __forceinline__ TypeOps T() { return TypeOps{S, &dev_status}; }
+    __device__ __forceinline__ opusfe_node N(uint32_t i) const { LPROF(LP_NODE); return uni(S.nodes[i]); }
+    __device__ __forceinline__ TypeOps T() { return TypeOps{S, &dev_status, lds->types, tbase, ntypes < LDS_TYPES ? ntypes : (uint32_t)LDS_TYPES}; }
+    __device__ __forceinline__ TypeRec trec(uint32_t t) { return T().rec(t); }
+
+    // ---- names (wave-cooperative byte compare: one memory round trip instead of one per character) ----
+    uint32_t lane;
+    __device__ bool neq(NameKey a, NameKey b) const {
+        uint8_t sa = name_sym(S.tok, a), sb = name_sym(S.tok, b);
+        if (sa != sb) return false;
+        if (sa != T_Identifier) return true;
+        const opusfe_token x = S.tok[a.tok], y = S.tok[b.tok];
+        if (x.len != y.len || x.payload != y.payload) return false;
+        if (x.low == y.low) return true;
+#ifdef OPUSFE_EMU
+        for (uint32_t i = 0; i < x.len; i++) if (S.src[x.low + i] != S.src[y.low + i]) return false;
+        return true;
+#else
+        const uint32_t len = uni(x.len), xl = uni(x.low), yl = uni(y.low);
+        for (uint32_t base = 0; base < len; base += 64) {
+            uint32_t i = base + lane;
+            bool ne = i < len && S.src[xl + i] != S.src[yl + i];
+            if (__ballot(ne)) return false;
+        }
+        return true;
+#endif
+    }
+    __device__ uint32_t find_slot(NameKey k) const {
+        uint32_t h = name_hash(S.tok, k) & S.slot_mask;
+        for (uint32_t probe = 0; probe <= S.slot_mask; probe++) {
+            uint32_t rep = uni(S.slots[h].rep);
+            if (rep == OPUSFE_NONE) return OPUSFE_NONE;
+            if (neq(k, key_tok(rep))) return h;
+            h = (h + 1) & S.slot_mask;
+        }
+        return OPUSFE_NONE;
+    }
+    __device__ uint32_t last_entry(NameKey k, uint32_t kind) const {
+        uint32_t s = find_slot(k);
+        if (s == OPUSFE_NONE) return OPUSFE_NONE;
+        const NameSlot sl = S.slots[s];
+        for (uint32_t j = uni(sl.count); j > 0; j--) {
+            NameEntry e = S.entries[uni(sl.offset) + j - 1];
+            if ((uni(e.kind_index) >> 30) == kind) return uni(sl.offset) + j - 1;
+        }
+        return OPUSFE_NONE;
+    }
+    uint64_t user_syms;   // bit per operator-symbol token kind that has user-defined overloads in this unit
 
     // ---- spans / errors -------------------------------------------------------------------------
     __device__ void report(uint32_t kind, uint32_t low, uint32_t high) {
@@ -92,15 +183,22 @@ struct Lowerer {
 
     // ---- variables / instructions / blocks (generate_ir.rs:118-131) -------------------------------
     __device__ uint32_t new_var(uint32_t type_id, bool is_temporary) {
+        LPROF(LP_NEWVAR);
         if (nvars >= vcap) { internal(); return 0; }
         vars[nvars] = opusfe_variable{type_id, is_temporary ? 1u : 0u};
+        if (nvars < LDS_VARS) lds->vtype[nvars] = type_id;
         return nvars++;
     }
-    __device__ __forceinline__ uint32_t vtype(uint32_t v) const { return v < nvars ? vars[v].type_id : (uint32_t)TP_Error; }
+    __device__ __forceinline__ uint32_t vtype(uint32_t v) const { return v < nvars ? uni(v < LDS_VARS ? lds->vtype[v] : vars[v].type_id) : (uint32_t)TP_Error; }
+    __device__ __forceinline__ void set_vtype(uint32_t v, uint32_t t) { if (v < nvars) { vars[v].type_id = t; if (v < LDS_VARS) lds->vtype[v] = t; } }
     __device__ uint32_t push_to(uint32_t bb, const opusfe_instr& in) {
+        LPROF(LP_PUSH);
         if (ninstrs >= icap || bb >= nbbs) { internal(); return 0; }
         uint32_t t = ninstrs++;
-        instrs[t] = in; ibb[t] = bb; irank[t] = bbcnt[bb]++; bblast[bb] = t;
+        uint32_t rank;
+        if (bb < LDS_BBS) { rank = lds->bbcnt[bb]; lds->bbcnt[bb] = rank + 1; lds->bblast[bb] = t; }
+        else { rank = bbcnt[bb]; bbcnt[bb] = rank + 1; bblast[bb] = t; }
+        instrs[t] = in; ibb[t] = bb; irank[t] = uni(rank);
         return t;
     }
     __device__ __forceinline__ uint32_t push(const opusfe_instr& in) { return push_to(bb_index, in); }
@@ -109,12 +207,14 @@ struct Lowerer {
     }
     __device__ uint32_t new_bb() {
         if (nbbs >= bcap) { internal(); return 0; }
-        bbcnt[nbbs] = 0; bblast[nbbs] = OPUSFE_NONE;
+        if (nbbs < LDS_BBS) { lds->bbcnt[nbbs] = 0; lds->bblast[nbbs] = OPUSFE_NONE; } else { bbcnt[nbbs] = 0; bblast[nbbs] = OPUSFE_NONE; }
         return nbbs++;
     }
+    __device__ __forceinline__ uint32_t bb_last(uint32_t bb) const { return uni(bb < LDS_BBS ? lds->bblast[bb] : bblast[bb]); }
     __device__ uint32_t generate_error() { uint32_t v = new_var(TP_Error, true); push(ins(I_Error, v)); return v; }
     __device__ uint32_t new_type(const TypeRec& r) {
         if (ntypes >= tcap) { internal(); return TP_Error; }
+        if (ntypes < LDS_TYPES) lds->types[ntypes] = r;
         uint32_t id = tbase + ntypes++;
         S.types[id] = r;
         return id;
@@ -147,33 +247,52 @@ struct Lowerer {
     const uint8_t* undefined_flag;
 
     // ---- scopes / locals (generate_ir.rs:176-185) -------------------------------------------------
+    __device__ __forceinline__ uint32_t l_name(uint32_t j) const { return uni(j < LDS_LOCALS ? lds->lname[j] : lname[j]); }
+    __device__ __forceinline__ uint32_t l_var(uint32_t j) const { return uni(j < LDS_LOCALS ? lds->lvar[j] : lvar[j]); }
+    __device__ __forceinline__ void l_set_var(uint32_t j, uint32_t v) { if (j < LDS_LOCALS) lds->lvar[j] = v; else lvar[j] = v; }
+    __device__ __forceinline__ uint32_t l_stack(uint32_t j) const { return uni(j < LDS_LOCALS ? lds->lstack[j] : lstack[j]); }
+    // the name hash is compared first (LDS); the bytes only on a hash match
     __device__ uint32_t local_find(NameKey k) const {
-        for (uint32_t j = nlocals; j > 0; j--) if (lvar[j - 1] != OPUSFE_NONE && name_eq(S.src, S.tok, k, key_tok(lname[j - 1]))) return j - 1;
+        LPROF(LP_LOCALFIND);
+        const uint32_t h = name_hash(S.tok, k);
+        for (uint32_t j = nlocals; j > 0; j--) {
+            const uint32_t e = j - 1;
+            if (l_var(e) == OPUSFE_NONE) continue;
+            if (e < LDS_LOCALS && uni(lds->lhash[e]) != h) continue;
+            if (neq(k, key_tok(l_name(e)))) return e;
+        }
         return OPUSFE_NONE;
     }
     __device__ void local_set(uint32_t name_tok, uint32_t v) {
         uint32_t j = local_find(key_tok(name_tok));
-        if (j != OPUSFE_NONE) { lvar[j] = v; return; }
+        if (j != OPUSFE_NONE) { l_set_var(j, v); return; }
         if (nlocals >= lcap) { internal(); return; }
-        lname[nlocals] = name_tok; lvar[nlocals] = v; nlocals++;
+        if (nlocals < LDS_LOCALS) { lds->lname[nlocals] = name_tok; lds->lvar[nlocals] = v; lds->lhash[nlocals] = name_hash(S.tok, key_tok(name_tok)); }
+        else { lname[nlocals] = name_tok; lvar[nlocals] = v; }
+        nlocals++;
     }
     __device__ bool contains_local(uint32_t name_tok) const {
-        for (uint32_t j = 0; j < nstack; j++) if (name_eq(S.src, S.tok, key_tok(name_tok), key_tok(lstack[j]))) return true;
+        for (uint32_t j = 0; j < nstack; j++) if (neq(key_tok(name_tok), key_tok(l_stack(j)))) return true;
         return false;
     }
-    __device__ void stack_push(uint32_t name_tok) { if (nstack >= lcap) { internal(); return; } lstack[nstack++] = name_tok; }
+    __device__ void stack_push(uint32_t name_tok) {
+        if (nstack >= lcap) { internal(); return; }
+        if (nstack < LDS_LOCALS) lds->lstack[nstack] = name_tok; else lstack[nstack] = name_tok;
+        nstack++;
+    }
     __device__ void end_scope(uint32_t n) {
-        while (nstack > n) { uint32_t name = lstack[--nstack]; uint32_t j = local_find(key_tok(name)); if (j != OPUSFE_NONE) lvar[j] = OPUSFE_NONE; }
+        while (nstack > n) { uint32_t name = l_stack(--nstack); uint32_t j = local_find(key_tok(name)); if (j != OPUSFE_NONE) l_set_var(j, OPUSFE_NONE); }
     }
 
     // ---- generate_ir.rs:207-231 -------------------------------------------------------------------
     __device__ uint32_t autocast(uint32_t variable, uint32_t expected, uint32_t span_node) {
+        LPROF(LP_AUTOCAST);
         uint32_t found = vtype(variable);
         if (T().types_match(found, expected)) return variable;
         int ct = T().can_autocast(found, expected);
         if (ct >= 0) {
-            uint8_t fk = S.types[found].kind;
-            if (fk == TY_GenericInteger || fk == TY_Generic) { if (variable < nvars) vars[variable].type_id = expected; return variable; }
+            uint8_t fk = trec(found).kind;
+            if (fk == TY_GenericInteger || fk == TY_Generic) { set_vtype(variable, expected); return variable; }
             uint32_t r = new_var(expected, true);
             push(ins(I_Cast, r, variable, 0, 0, 0, (uint16_t)ct));
             return r;
@@ -183,7 +302,7 @@ struct Lowerer {
     }
     // :235-242
     __device__ uint32_t get_lvalue_type(uint32_t v) {
-        const TypeRec r = S.types[vtype(v)];
+        const TypeRec r = trec(vtype(v));
         if (r.kind == TY_Pointer) return r.sub;
         if (r.kind != TY_Error) unsupported();   // reference: unreachable!()
         return TP_Error;
@@ -193,7 +312,8 @@ struct Lowerer {
 
     // :808-855; `sp_low/sp_high` is the span for errors
     __device__ uint32_t try_cast_pointer(uint32_t v, uint8_t pt, uint32_t sp_low, uint32_t sp_high) {
-        const TypeRec r = S.types[vtype(v)];
+        LPROF(LP_TRYCAST);
+        const TypeRec r = trec(vtype(v));
         if (r.kind == TY_Pointer) {
             uint8_t pt2 = r.ptr;
             if (pt2 == pt) return v;
@@ -215,7 +335,7 @@ struct Lowerer {
     // Compiler::lookup_function (compile.rs:1083-1139) over builtins followed by the user overloads in definition order
     __device__ bool name_has_functions(NameKey name, uint32_t* slot_out) const {
         uint8_t sym = name_sym(S.tok, name);
-        uint32_t s = name_find(S, name);
+        uint32_t s = find_slot(name);
         *slot_out = s;
         if (sym != T_Identifier && builtin_count(sym) > 0) return true;
         if (s == OPUSFE_NONE) return false;
@@ -241,6 +361,33 @@ struct Lowerer {
     }
     // arg types are read through `argv` (variable ids) unless `types` is given (Proc)
     __device__ uint32_t compiler_lookup_function(uint32_t sp_low, uint32_t sp_high, NameKey name, const uint32_t* argv, const uint32_t* types_in, uint32_t n) {
+        LPROF(LP_LOOKUPFN);
+        {   // builtin operator on primitive operands with no user overloads of that symbol: the general algorithm below
+            // reduces to pure arithmetic (candidates have pairwise different parameter types, so nothing is "ignorable"
+            // unless there is exactly one candidate)
+            const uint8_t sym = name_sym(S.tok, name);
+            if (sym != T_Identifier && !types_in && builtin_count(sym) > 0 && !((user_syms >> sym) & 1) && n == builtin_nargs(sym)) {
+                const uint32_t a0 = vtype(argv[0]), a1 = n > 1 ? vtype(argv[1]) : a0;
+                if (a0 < TP_COUNT && a1 < TP_COUNT && a0 != TP_Error && a1 != TP_Error) {
+                    int cnt = 0, first = -1, pick = -1;
+                    const int total = builtin_count(sym);
+                    for (int idx = 0; idx < total; idx++) {
+                        const uint32_t t = builtin_arg_type(sym, idx);
+                        const bool integral = kind_is_integral(prim_kind(t));
+                        const bool ok0 = a0 == t || (a0 == TP_GenericInteger && integral) || a0 == TP_Generic;
+                        const bool ok1 = a1 == t || (a1 == TP_GenericInteger && integral) || a1 == TP_Generic;
+                        if (!(ok0 && ok1)) continue;
+                        cnt++;
+                        if (first < 0) first = idx;
+                        const bool d0 = a0 == TP_GenericInteger ? t == TP_Integer32 : (a0 != TP_Generic && t == a0);
+                        const bool d1 = a1 == TP_GenericInteger ? t == TP_Integer32 : (a1 != TP_Generic && t == a1);
+                        if (pick < 0 && d0 && d1) pick = idx;
+                    }
+                    if (cnt == 1) return FN_BUILTIN | ((uint32_t)sym << 8) | (uint32_t)first;
+                    if (cnt > 1 && pick >= 0) return FN_BUILTIN | ((uint32_t)sym << 8) | (uint32_t)pick;
+                }
+            }
+        }
         uint32_t slot;
         if (!name_has_functions(name, &slot)) { report(SE_UndefinedFunction, sp_low, sp_high); return FN_NONE; }
         if (n > 64) { unsupported(); return FN_NONE; }
@@ -280,18 +427,19 @@ struct Lowerer {
     // `same_span`) else the i-th node of the sibling chain starting there.  Returns false when there is no callee.
     struct Callee { uint32_t fv; uint32_t out; bool builtin; };
     __device__ bool call_variables(uint32_t sp_low, uint32_t sp_high, NameKey name, uint32_t* argv, uint32_t n, uint32_t span_node, bool same_span, Callee* res) {
-        for (uint32_t i = 0; i < n; i++) if (S.types[vtype(argv[i])].kind == TY_Error) return false;
+        LPROF(LP_CALLVARS);
+        for (uint32_t i = 0; i < n; i++) if (trec(vtype(argv[i])).kind == TY_Error) return false;
         // lookup_function: a local of that name shadows the global functions
         uint32_t fv, ret; bool builtin = false;
         uint32_t arg_src = 0;        // 0: function id `fid`; 1: members of function type `ftype`
         uint32_t fid = FN_NONE; TypeRec ftype{};
         uint32_t lj = local_find(name);
         if (lj != OPUSFE_NONE) {
-            uint32_t variable = lvar[lj];
+            uint32_t variable = l_var(lj);
             uint32_t typ = get_lvalue_type(variable);
             uint32_t nv = new_var(typ, true);
             push(ins(I_Load, nv, variable));
-            ftype = S.types[typ];
+            ftype = trec(typ);
             if (ftype.kind != TY_Function) { report(SE_CallOfNonFunction, sp_low, sp_high); return false; }
             fv = nv; ret = ftype.sub; arg_src = 1;
         } else {
@@ -323,20 +471,21 @@ struct Lowerer {
 
     // get_field_type (:1090-1101) -> type id or NONE
     __device__ uint32_t get_field_type(uint32_t rec, uint32_t field_tok) {
-        const TypeRec r = S.types[get_lvalue_type(rec)];
+        const TypeRec r = trec(get_lvalue_type(rec));
         if (r.kind != TY_Record) return OPUSFE_NONE;
         uint32_t n = T().member_count(r), c = T().member_first(r);
-        for (uint32_t i = 0; i < n; i++) { if (name_eq(S.src, S.tok, key_tok(field_tok), key_tok(T().member_name(c)))) return T().member_type(c); c = T().member_next(c); }
+        for (uint32_t i = 0; i < n; i++) { if (neq(key_tok(field_tok), key_tok(T().member_name(c)))) return T().member_type(c); c = T().member_next(c); }
         return OPUSFE_NONE;
     }
     // generate_ir_for_field_access (:1103-1149)
     __device__ uint32_t field_access(uint32_t rec, uint32_t field_tok, uint8_t pt, uint32_t sp_low, uint32_t sp_high) {
+        LPROF(LP_FIELD);
         if (pt == PT_Array || pt == PT_ArrayMutable) { report(SE_ArrayPointerToNonArray, sp_low, sp_high); return generate_error(); }
-        const TypeRec r = S.types[get_lvalue_type(rec)];
+        const TypeRec r = trec(get_lvalue_type(rec));
         if (r.kind == TY_Record) {
             uint32_t n = T().member_count(r), c = T().member_first(r);
             for (uint32_t i = 0; i < n; i++) {
-                if (name_eq(S.src, S.tok, key_tok(field_tok), key_tok(T().member_name(c)))) {
+                if (neq(key_tok(field_tok), key_tok(T().member_name(c)))) {
                     uint32_t rvv = new_var(type_pointer(pt, T().member_type(c)), true);
                     push(ins(I_Field, rvv, rec, 0, field_tok));
                     return rvv;
@@ -361,11 +510,12 @@ struct Lowerer {
 
     // lookup_name (:857-893).  Returns false for "None" (the name is a constant global)
     __device__ bool lookup_name(uint32_t name_tok, uint32_t sp_low, uint32_t sp_high, uint8_t pt, uint32_t* var, bool* is_lvalue) {
+        LPROF(LP_LOOKUPNAME);
         *is_lvalue = true;
         NameKey key = key_tok(name_tok);
         uint32_t lj = local_find(key);
-        if (lj != OPUSFE_NONE) { *var = try_cast_pointer(lvar[lj], pt, sp_low, sp_high); return true; }
-        uint32_t ge = name_last(S, key, NK_GLOBAL);
+        if (lj != OPUSFE_NONE) { *var = try_cast_pointer(l_var(lj), pt, sp_low, sp_high); return true; }
+        uint32_t ge = last_entry(key, NK_GLOBAL);
         if (ge != OPUSFE_NONE) {
             uint32_t gid = S.entries[ge].kind_index & 0x3FFFFFFFu;
             if (S.globals[gid].is_const) return false;
@@ -394,15 +544,17 @@ struct Lowerer {
 
     // ---- machine ----------------------------------------------------------------------------------
     __device__ __forceinline__ bool call(uint8_t entry, uint8_t resume, uint32_t node, uint8_t aux, uint32_t a, uint32_t f = 0) {
+        LPROF(LP_FRAMES);
         cur.st = resume;
         if (sp + 1 >= fcap) { internal(); return false; }
-        frames[sp++] = cur;
+        if (sp < LDS_FRAMES) lds->frames[sp] = cur; else frames[sp] = cur;
+        sp++;
         cur.st = entry; cur.aux = aux; cur.cnt = 0; cur.node = node; cur.a = a; cur.b = cur.c = cur.d = cur.e = 0; cur.f = f;
         return true;
     }
-    __device__ __forceinline__ void retn() { if (sp == 0) { cur.st = LS_DONE; return; } cur = frames[--sp]; }
-    __device__ __forceinline__ void push_raw(const LFrame& fr) { if (sp + 1 >= fcap) { internal(); return; } frames[sp++] = fr; }
-    __device__ __forceinline__ LFrame pop_raw() { if (sp == 0) { internal(); return LFrame{}; } return frames[--sp]; }
+    __device__ __forceinline__ void retn() { LPROF(LP_FRAMES); if (sp == 0) { cur.st = LS_DONE; return; } --sp; cur = uni(sp < LDS_FRAMES ? lds->frames[sp] : frames[sp]); }
+    __device__ __forceinline__ void push_raw(const LFrame& fr) { if (sp + 1 >= fcap) { internal(); return; } if (sp < LDS_FRAMES) lds->frames[sp] = fr; else frames[sp] = fr; sp++; }
+    __device__ __forceinline__ LFrame pop_raw() { if (sp == 0) { internal(); return LFrame{}; } --sp; return uni(sp < LDS_FRAMES ? lds->frames[sp] : frames[sp]); }
 
     __device__ void p_finish(uint32_t var, bool lv) {
         if ((cur.aux & PF_MUSTLV) && !lv) { report_node(SE_InvalidLvalue, cur.f); var = generate_error(); }   // generate_pointer_from_expression :970-979
@@ -431,7 +583,7 @@ struct Lowerer {
                 a = N(a).next;
             }
         }
-        const bool returns_null = S.types[F.ret].kind == TY_Null;
+        const bool returns_null = trec(F.ret).kind == TY_Null;
         cur.st = LS_BLOCK; cur.aux = 0; cur.cnt = 0; cur.node = body; cur.a = cur.b = cur.c = cur.d = cur.e = cur.f = 0;
         sp = 0;
         for (;;) {
@@ -627,7 +779,7 @@ struct Lowerer {
                             uint32_t size = t.aux & 0xFF; bool sg = (t.aux & 0x100) != 0;
                             if (!sg) typ = size == 8 ? TP_Natural8 : size == 16 ? TP_Natural16 : size == 32 ? TP_Natural32 : size == 64 ? TP_Natural64 : TP_Size;
                             else typ = size == 8 ? TP_Integer8 : size == 16 ? TP_Integer16 : size == 32 ? TP_Integer32 : size == 64 ? TP_Integer64 : TP_Offset;
-                        } else if (cur.a != OPUSFE_NONE && (kind_is_integral(S.types[cur.a].kind) || S.types[cur.a].kind == TY_GenericInteger)) typ = cur.a;
+                        } else if (cur.a != OPUSFE_NONE && (kind_is_integral(trec(cur.a).kind) || trec(cur.a).kind == TY_GenericInteger)) typ = cur.a;
                         else typ = TP_Integer32;
                         uint64_t val = (t.flags & OPUSFE_TF_INLINE) ? (uint64_t)t.payload : S.val64[t.payload];
                         uint32_t v = new_var(typ, true);
@@ -686,7 +838,7 @@ struct Lowerer {
             case LS_OP_IS_1: cur.b = rv; CALL_E(N(nd.first_child).next, OPUSFE_NONE, LS_OP_IS_2);
             case LS_OP_IS_2: {
                 uint32_t l = cur.b, r = rv;
-                const TypeRec lt = S.types[vtype(l)], rt = S.types[vtype(r)];
+                const TypeRec lt = trec(vtype(l)), rt = trec(vtype(r));
                 if (lt.kind == TY_Pointer && rt.kind == TY_Pointer && lt.ptr == rt.ptr && T().types_match(lt.sub, rt.sub)) {
                     uint32_t v = new_var(TP_Bool, true);
                     push(ins(I_Equals, v, l, r));
@@ -756,13 +908,13 @@ struct Lowerer {
             }
             case LS_NEG_1: {   // :749-789
                 uint32_t sub = rv, st = vtype(sub);
-                uint8_t k = S.types[st].kind;
+                uint8_t k = trec(st).kind;
                 if (k == TY_Integer8 || k == TY_Integer16 || k == TY_Integer32 || k == TY_Integer64 || k == TY_Offset) {
                     uint32_t out = new_var(st, true);
                     push(ins(I_Negate, out, sub));
                     rv = out;
                 } else if (k == TY_GenericInteger) {
-                    uint32_t t = bb_index < nbbs ? bblast[bb_index] : OPUSFE_NONE;
+                    uint32_t t = bb_index < nbbs ? bb_last(bb_index) : OPUSFE_NONE;
                     if (t != OPUSFE_NONE && instrs[t].opcode == I_Integer) {
                         uint64_t val = (uint64_t)instrs[t].c | ((uint64_t)instrs[t].extra << 32);
                         val = 0 - val;
@@ -782,7 +934,7 @@ struct Lowerer {
                         uint32_t var; bool lv;
                         if (lookup_name(nd.payload, nd.low, nd.high, pt, &var, &lv)) { p_finish(var, lv); goto next; }
                         // constant global (:993-998)
-                        uint32_t ge = name_last(S, key_tok(nd.payload), NK_GLOBAL);
+                        uint32_t ge = last_entry(key_tok(nd.payload), NK_GLOBAL);
                         uint32_t gid = S.entries[ge].kind_index & 0x3FFFFFFFu;
                         uint32_t v = new_var(S.globals[gid].type_id, true);
                         push(ins(I_GlobalConstant, v, 0, 0, gid));
@@ -860,8 +1012,8 @@ struct Lowerer {
                 bool il = cur.b & 1;
                 uint32_t it = vtype(cur.a);
                 uint32_t indexee_type = it;
-                if (il) { const TypeRec r = S.types[it]; if (r.kind == TY_Pointer) indexee_type = r.sub; else { if (r.kind != TY_Error) unsupported(); indexee_type = TP_Error; } }
-                const TypeRec r = S.types[indexee_type];
+                if (il) { const TypeRec r = trec(it); if (r.kind == TY_Pointer) indexee_type = r.sub; else { if (r.kind != TY_Error) unsupported(); indexee_type = TP_Error; } }
+                const TypeRec r = trec(indexee_type);
                 uint32_t isl, ish;
                 if (nd.kind == E_NamedCall) { isl = S.tok[nd.payload].low; ish = isl + S.tok[nd.payload].len; } else { isl = N(nd.first_child).low; ish = N(nd.first_child).high; }
                 if (r.kind == TY_Pointer) { if (il) cur.a = dereference_pointer(cur.a); cur.b = (IDX_PTR << 1); }
@@ -885,7 +1037,7 @@ struct Lowerer {
                 uint32_t isl, ish;
                 if (nd.kind == E_NamedCall) { isl = S.tok[nd.payload].low; ish = isl + S.tok[nd.payload].len; } else { isl = N(nd.first_child).low; ish = N(nd.first_child).high; }
                 if (mode == IDX_FN) {
-                    const TypeRec r = S.types[vtype(cur.a)];
+                    const TypeRec r = trec(vtype(cur.a));
                     uint32_t out = new_var(r.sub, true);
                     push(ins(I_Call, out, cur.a, 0, cur.d, 0, (uint16_t)cur.e));
                     if (cur.e > 0xFFFF) unsupported();
@@ -893,7 +1045,7 @@ struct Lowerer {
                 }
                 if (cur.e != 1) report_node(SE_InvalidNumberOfArgs, cur.node);
                 if (cur.e == 0) { unsupported(); p_finish(generate_error(), true); goto next; }   // reference: pop().unwrap() panics
-                const TypeRec r = S.types[vtype(cur.a)];
+                const TypeRec r = trec(vtype(cur.a));
                 if (mode == IDX_PTR) {
                     uint32_t result_type;
                     if (r.ptr == PT_Array) result_type = type_pointer(PT_Array, r.sub);
@@ -905,7 +1057,7 @@ struct Lowerer {
                 }
                 // array: the indexee is an lvalue pointer to the array
                 if (r.kind != TY_Pointer) { unsupported(); p_finish(generate_error(), true); goto next; }
-                uint32_t result_type = type_pointer(r.ptr, S.types[r.sub].sub);
+                uint32_t result_type = type_pointer(r.ptr, trec(r.sub).sub);
                 uint32_t v = new_var(result_type, true);
                 push(ins(I_IndexArray, v, cur.a, cur.d));
                 p_finish(try_cast_pointer(v, pt, isl, ish), true); goto next;
@@ -932,7 +1084,7 @@ struct Lowerer {
     finished:
         // epilogue (:151-171)
         if (rdiv || returns_null) {
-            uint32_t t = bblast[bb_index];
+            uint32_t t = bb_last(bb_index);
             bool term = false;
             if (t != OPUSFE_NONE) { uint16_t op = instrs[t].opcode; term = op == I_Return || op == I_Jump || op == I_Branch || op == I_Unreachable; }
             if (!term) {
@@ -947,11 +1099,27 @@ struct Lowerer {
     }
 };
 
+// which operator symbols have user-defined overloads (one lane per symbol)
+__global__ void k_sem_user_syms(SemView S, uint64_t* __restrict__ out) {
+    const uint8_t SYMS[11] = {T_Plus, T_Minus, T_Asterisk, T_Slash, T_Percent, T_EqualsEquals, T_LessThan, T_GreaterThan, T_LessThanEquals, T_GreaterThanEquals, T_Not};
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        uint64_t m = 0;
+        for (int i = 0; i < 11; i++) {
+            uint32_t s = name_find(S, key_sym(SYMS[i]));
+            if (s == OPUSFE_NONE) continue;
+            const NameSlot sl = S.slots[s];
+            for (uint32_t j = 0; j < sl.count; j++) if ((S.entries[sl.offset + j].kind_index >> 30) == NK_FUNCTION) { m |= 1ull << SYMS[i]; break; }
+        }
+        *out = m;
+    }
+}
+
 // one lane per function definition
 __global__ __launch_bounds__(64) void k_lower_functions(SemView S, LowerBuffers B, const uint8_t* __restrict__ undefined_flag, const uint32_t* __restrict__ def_nodes,
                                                          uint32_t n_defs, uint32_t n_nodes, const DefCnt* __restrict__ def_excl, FuncIr* __restrict__ out,
-                                                         uint32_t* __restrict__ status) {
-    uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+                                                         uint32_t* __restrict__ status, uint64_t* __restrict__ prof_out, const uint64_t* __restrict__ user_syms) {
+    const uint32_t d = blockIdx.x * (blockDim.x / UNIT_LANES) + threadIdx.x / UNIT_LANES;
+    const uint32_t lane = threadIdx.x % UNIT_LANES;
     if (d >= n_defs) return;
     const uint32_t dn = def_nodes[d];
     if (S.nodes[dn].kind != D_Function) return;
@@ -960,7 +1128,11 @@ __global__ __launch_bounds__(64) void k_lower_functions(SemView S, LowerBuffers 
     // externs simply leave their slot empty (n_instrs == 0, func == NONE)
     const uint32_t dn_end = d + 1 < n_defs ? def_nodes[d + 1] : n_nodes;
     const uint32_t nn = dn_end - dn;
+    __shared__ LowerLds lds_block[64 / UNIT_LANES];
     Lowerer L;
+    L.lds = &lds_block[threadIdx.x / UNIT_LANES];
+    L.lane = lane;
+    L.user_syms = *user_syms;
     L.S = S; L.fidx = fidx; L.F = S.funcs[fidx]; L.undefined_flag = undefined_flag;
     L.vars = B.vars + lower_base(CAP_VARS, dn, fidx); L.nvars = 0; L.vcap = (uint32_t)lower_cap(CAP_VARS, nn);
     uint64_t ib = lower_base(CAP_INSTRS, dn, fidx);
@@ -979,7 +1151,16 @@ __global__ __launch_bounds__(64) void k_lower_functions(SemView S, LowerBuffers 
     // body = last child of the definition
     uint32_t c = S.nodes[dn].first_child;
     while (S.nodes[c].next != OPUSFE_NONE) c = S.nodes[c].next;
+#ifdef OPUSFE_LOWER_PROF
+    for (int i = 0; i < LP_COUNT; i++) L.prof[i] = 0;
+    { uint64_t t0 = __builtin_readcyclecounter(); L.run(c); L.prof[LP_TOTAL] = __builtin_readcyclecounter() - t0; }
+    if (lane == 0) for (int i = 0; i < LP_COUNT; i++) atomicAdd((unsigned long long*)prof_out + i, (unsigned long long)L.prof[i]);
+#else
     L.run(c);
+#endif
+    // block sizes of the LDS-resident blocks go to the global table read by k_ir_bb_offsets
+    for (uint32_t b = lane; b < L.nbbs && b < LDS_BBS; b += UNIT_LANES) L.bbcnt[b] = L.lds->bbcnt[b];
+    if (lane != 0) return;
     FuncIr r{};
     r.def_node = dn; r.func = fidx; r.n_vars = L.nvars; r.n_instrs = L.ninstrs; r.n_bbs = L.nbbs; r.n_types = L.ntypes; r.n_cargs = L.ncargs;
     r.n_errs = L.nerrs < L.ecap ? L.nerrs : L.ecap; r.status = L.dev_status;
@@ -1162,8 +1343,23 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
         return;
     }
     if (n_funcs == 0) { u->status = OPUSFE_OK; R->have_host = true; return; }
-    LAUNCH(ctx, "lower_functions", k_lower_functions, grid_for(n_defs, 64), 64, S, B, undefined_flag, u->d_def_nodes, n_defs, n_nodes, def_excl, R->d_funcs,
-           ctx->d_status + WL_STATUS);
+    uint64_t* user_syms = tmp.get<uint64_t>(1);
+    LAUNCH(ctx, "sem_user_syms", k_sem_user_syms, 1, 64, S, user_syms);
+    uint64_t* prof_buf = tmp.get<uint64_t>(LP_COUNT);
+    HIP_TRY(hipMemsetAsync(prof_buf, 0, LP_COUNT * 8, st));
+    LAUNCH(ctx, "lower_functions", k_lower_functions, grid_for((uint64_t)n_defs * UNIT_LANES, 64), 64, S, B, undefined_flag, u->d_def_nodes, n_defs, n_nodes, def_excl, R->d_funcs,
+           ctx->d_status + WL_STATUS, prof_buf, user_syms);
+#ifdef OPUSFE_LOWER_PROF
+    {
+        uint64_t h[LP_COUNT];
+        HIP_TRY(hipMemcpyAsync(h, prof_buf, sizeof h, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        static const char* const NAMES[LP_COUNT] = {"total", "node loads", "local_find", "call_variables", "autocast", "try_cast_pointer", "lookup_name", "field_access",
+                                                    "push", "new_var", "frames", "compiler_lookup_function"};
+        fprintf(stderr, "lowering cycle accounting (inclusive, summed over functions):\n");
+        for (int i = 0; i < LP_COUNT; i++) fprintf(stderr, "  %-26s %14llu  %5.1f%%\n", NAMES[i], (unsigned long long)h[i], 100.0 * h[i] / (double)h[0]);
+    }
+#endif
     IrCnt* cnt = tmp.get<IrCnt>(n_funcs);
     LAUNCH(ctx, "ir_counts", k_ir_counts, grid_for(n_funcs, 256), 256, R->d_funcs, n_funcs, cnt);
     prof_begin(ctx, "ir_scan");

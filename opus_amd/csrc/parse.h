@@ -615,7 +615,8 @@ struct SegParser {
 __global__ __launch_bounds__(64) void k_parse_segments(const opusfe_token* __restrict__ tok, uint32_t n_tokens, const uint32_t* __restrict__ seg_start,
                                                         uint32_t n_segs, opusfe_node* __restrict__ nodes, PFrame* __restrict__ frames,
                                                         uint32_t* __restrict__ seg_info, uint32_t* __restrict__ status, uint32_t* __restrict__ first_err_seg) {
-    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t s = blockIdx.x * (blockDim.x / UNIT_LANES) + threadIdx.x / UNIT_LANES;
+    const uint32_t lane = threadIdx.x % UNIT_LANES;
     if (s >= n_segs) return;
     uint32_t tb = seg_start[s], te = (s + 1 < n_segs) ? seg_start[s + 1] : n_tokens;
     SegParser P;
@@ -631,6 +632,7 @@ __global__ __launch_bounds__(64) void k_parse_segments(const opusfe_token* __res
     if (ok && P.i != te) {   // a definition straddled a segment boundary: the segmentation rule did not hold
         ok = false; P.err_kind = 0x200u | DS_INTERNAL_SEGMENT; P.err_tok = P.tk(P.i);
     }
+    if (lane != 0) return;
     uint32_t* si = seg_info + (uint64_t)s * SI_WORDS;
     si[SI_NODE_BASE] = 0; si[SI_NODE_COUNT] = P.nn; si[SI_DEF_COUNT] = def_count; si[SI_FIRST_DEF] = first_def;
     si[SI_ERR_KIND] = ok ? OPUSFE_NONE : P.err_kind; si[SI_ERR_TOK] = P.err_tok; si[SI_ERR_LOW] = P.err_low; si[SI_ERR_LEN] = P.err_len;
@@ -709,7 +711,7 @@ inline void run_parser(opusfe_ctx* ctx, opusfe_unit* u) {
     Cnt2* scan_tmp = tmp.get<Cnt2>((n_segs + SCAN_TILE - 1) / SCAN_TILE + 1);
     uint32_t init[4] = {0xFFFFFFFFu, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(ctx->d_status + WP_FIRST_ERR, init, sizeof init, hipMemcpyHostToDevice, st));
-    LAUNCH(ctx, "parse_segments", k_parse_segments, grid_for(n_segs, 64), 64, u->d_tokens, n_tok, u->d_seg_start, n_segs, sparse, frames,
+    LAUNCH(ctx, "parse_segments", k_parse_segments, grid_for((uint64_t)n_segs * UNIT_LANES, 64), 64, u->d_tokens, n_tok, u->d_seg_start, n_segs, sparse, frames,
            u->d_seg_info, ctx->d_status, ctx->d_status + WP_FIRST_ERR);
     LAUNCH(ctx, "ast_counts", k_ast_counts, grid_for(n_segs, 256), 256, u->d_seg_info, n_segs, cnt);
     prof_begin(ctx, "ast_scan");

@@ -164,8 +164,16 @@ __host__ __device__ __forceinline__ bool kind_is_integral(uint8_t k) {   // comp
 struct TypeOps {
     const SemView& S;
     uint32_t* dev_status;   // lane-local status word (DS_UNSUPPORTED_SEMANTIC when the reference would overflow its stack)
-    __device__ __forceinline__ TypeRec rec(uint32_t t) const { return S.types[t]; }
-    __device__ __forceinline__ uint8_t kind(uint32_t t) const { return S.types[t].kind; }
+    // records of the types the running function created itself, kept in LDS by the lowering kernel (else null)
+    const TypeRec* local_cache; uint32_t local_base, local_cached;
+    // primitives need no memory access; the function's own types come from LDS; everything else from the table
+    __device__ __forceinline__ TypeRec rec(uint32_t t) const {
+        if (t < TP_COUNT) { TypeRec r{}; r.kind = prim_kind(t); r.alias = OPUSFE_NONE; return r; }
+        uint32_t k = t - local_base;
+        if (t >= local_base && k < local_cached) return local_cache[k];
+        return S.types[t];
+    }
+    __device__ __forceinline__ uint8_t kind(uint32_t t) const { return t < TP_COUNT ? prim_kind(t) : rec(t).kind; }
     __device__ __forceinline__ bool is_integral(uint32_t t) const { return kind_is_integral(kind(t)); }
 
     // member lists of Record / Function types
@@ -193,6 +201,7 @@ struct TypeOps {
     // compile.rs:698-751, recursion replaced by a bounded work list (the reference recurses without a
     // cycle check: on a self-referential record it overflows its stack; we report UNSUPPORTED instead)
     __device__ bool types_match(uint32_t a0, uint32_t b0) const {
+        if (a0 < TP_COUNT && b0 < TP_COUNT) return a0 == b0;    // primitives: one id per kind
         uint32_t stack_a[48], stack_b[48];
         int sp = 0;
         uint32_t a = a0, b = b0;
@@ -201,7 +210,7 @@ struct TypeOps {
             if (--budget == 0) { *dev_status = DS_UNSUPPORTED_SEMANTIC; return false; }
             bool descend = false;
             {
-                const TypeRec ra = S.types[a], rb = S.types[b];
+                const TypeRec ra = rec(a), rb = rec(b);
                 if (ra.kind != rb.kind) return false;
                 switch (ra.kind) {
                     case TY_Pointer: if (ra.ptr != rb.ptr) return false; a = ra.sub; b = rb.sub; descend = true; break;
@@ -259,8 +268,15 @@ struct TypeOps {
     }
     // compile.rs:624-670; returns CastKind or -1
     __device__ int can_autocast(uint32_t from, uint32_t to) const {
+        if (from < TP_COUNT && to < TP_COUNT) {   // both primitive: no table access
+            if (from == to) return CT_None;
+            if (from == TP_Error || to == TP_Error) return CT_Error;
+            if (from == TP_GenericInteger && kind_is_integral(prim_kind(to))) return CT_Error;
+            if (from == TP_Generic) return CT_Error;
+            return -1;
+        }
         if (types_match(from, to)) return CT_None;
-        const TypeRec t1 = S.types[from], t2 = S.types[to];
+        const TypeRec t1 = rec(from), t2 = rec(to);
         if (t1.kind == TY_Error || t2.kind == TY_Error) return CT_Error;
         if (t1.kind == TY_GenericInteger && kind_is_integral(t2.kind)) return CT_Error;
         if (t1.kind == TY_Generic) return CT_Error;
@@ -271,7 +287,7 @@ struct TypeOps {
                 && types_match(t2.sub, TP_Natural8)) return CT_PointerType;
             if (((p1 == PT_ArrayMutable && p2 == PT_Mutable) || (p1 == PT_ArrayMutable && p2 == PT_Reference) || (p1 == PT_Array && p2 == PT_Reference))
                 && types_match(t1.sub, TP_Natural8)) return CT_PointerType;
-            const TypeRec s1 = S.types[t1.sub];
+            const TypeRec s1 = rec(t1.sub);
             if (s1.kind == TY_Array && types_match(s1.sub, t2.sub)) {
                 if ((p1 == PT_Reference && p2 == PT_Array) || (p1 == PT_Mutable && p2 == PT_ArrayMutable) || (p1 == PT_Mutable && p2 == PT_Array)) return CT_PointerToArray;
                 return -1;
@@ -284,7 +300,7 @@ struct TypeOps {
     __device__ int can_cast(uint32_t from, uint32_t to) const {
         int c = can_autocast(from, to);
         if (c >= 0) return c;
-        const TypeRec t1 = S.types[from], t2 = S.types[to];
+        const TypeRec t1 = rec(from), t2 = rec(to);
         if (kind_is_integral(t1.kind) && kind_is_integral(t2.kind)) return CT_Integer;
         if (t1.kind == TY_Pointer && t2.kind == TY_Pointer && t1.ptr == t2.ptr) return CT_Pointer;
         if ((t1.kind == TY_Pointer || t1.kind == TY_Function) && kind_is_integral(t2.kind)) return CT_PointerToInteger;

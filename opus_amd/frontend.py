@@ -36,6 +36,8 @@ class Counts(C.Structure):
 
 
 def library_path():
+    if os.environ.get("OPUSFE_LIB"):          # e.g. the -DOPUSFE_LOWER_PROF build used by tools/ for cycle accounting
+        return os.environ["OPUSFE_LIB"]
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "libopusfe.so")
 
 

@@ -216,8 +216,10 @@ void emu_lower(EmuUnit& E) {
     SemView S{E.src.data(), tok, u.h_val64.data(), nodes, R->tid_of_node.data(), types, slots, n_slots - 1, entries, R->funcrecs.data(), R->globals.data(), n_gtypes};
     R->funcs.assign(n_funcs, FuncIr{});
     uint32_t lstatus[2] = {0, 0};
+    uint64_t user_syms = 0;
+    emu_launch(k_sem_user_syms, 1, 1, S, &user_syms);
     emu_launch(k_lower_functions, grid_for(n_defs, 64), 64, S, B, (const uint8_t*)undefined_flag.data(), def_nodes, n_defs, n_nodes, (const DefCnt*)def_excl.data(),
-               R->funcs.data(), lstatus);
+               R->funcs.data(), lstatus, (uint64_t*)nullptr, (const uint64_t*)&user_syms);
     std::vector<IrCnt> cnt(n_funcs);
     emu_launch(k_ir_counts, grid_for(n_funcs, 256), 256, (const FuncIr*)R->funcs.data(), n_funcs, cnt.data());
     IrCnt tot{0, 0, 0, 0, 0, 0};
