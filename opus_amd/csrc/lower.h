@@ -1129,7 +1129,10 @@ __global__ __launch_bounds__(64) void k_lower_functions(SemView S, LowerBuffers 
     const uint32_t dn_end = d + 1 < n_defs ? def_nodes[d + 1] : n_nodes;
     const uint32_t nn = dn_end - dn;
     __shared__ LowerLds lds_block[64 / UNIT_LANES];
-    Lowerer L;
+    // the machine's registers live in LDS too: helper functions the compiler keeps out of line receive `this`, and an
+    // object in scratch (private memory) would turn every field access into a global-memory round trip
+    __shared__ Lowerer machine_block[64 / UNIT_LANES];
+    Lowerer& L = machine_block[threadIdx.x / UNIT_LANES];
     L.lds = &lds_block[threadIdx.x / UNIT_LANES];
     L.lane = lane;
     L.user_syms = *user_syms;

@@ -619,7 +619,8 @@ __global__ __launch_bounds__(64) void k_parse_segments(const opusfe_token* __res
     const uint32_t lane = threadIdx.x % UNIT_LANES;
     if (s >= n_segs) return;
     uint32_t tb = seg_start[s], te = (s + 1 < n_segs) ? seg_start[s + 1] : n_tokens;
-    SegParser P;
+    __shared__ SegParser machine_block[64 / UNIT_LANES];   // see lower.h: keeps the machine state out of scratch memory
+    SegParser& P = machine_block[threadIdx.x / UNIT_LANES];
     P.tok = tok; P.nodes = nodes; P.n_tokens = n_tokens;
     P.nbase = seg_node_base(tb, s); P.ncap = seg_node_cap(tb, te);
     P.stack = frames + seg_frame_base(tb, s); P.fcap = seg_frame_cap(tb, te);

@@ -14,6 +14,7 @@
 #define __global__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __shared__ static
+#define __noinline__
 #define __launch_bounds__(...)
 
 struct uint4 { unsigned x, y, z, w; };
