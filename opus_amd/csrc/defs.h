@@ -8,6 +8,22 @@
 // Lanes that work on one unit (segment / function) in the sequential-machine kernels.  On the GPU a whole wave runs
 // ONE unit with wave-uniform control flow: no divergence, and every memory instruction touches one cache line
 // instead of 64.  The host emulation (tests/emu) runs one lane per unit.
+// occupancy hint of the two sequential-machine kernels (waves per SIMD the register allocator must leave room for)
+#ifndef OPUSFE_PARSE_WAVES
+#define OPUSFE_PARSE_WAVES 6
+#endif
+#ifndef OPUSFE_LOWER_WAVES
+#define OPUSFE_LOWER_WAVES 4
+#endif
+#ifdef OPUSFE_EMU
+#define MACHINE_ATTR(w)
+#else
+#ifdef OPUSFE_FLATTEN
+#define MACHINE_ATTR(w) __attribute__((flatten, amdgpu_waves_per_eu(w, w)))
+#else
+#define MACHINE_ATTR(w) __attribute__((amdgpu_waves_per_eu(w, w)))
+#endif
+#endif
 #ifdef OPUSFE_EMU
 #define UNIT_LANES 1u
 #else

@@ -49,13 +49,23 @@ struct LowerBuffers {
 // Per-unit working set kept in LDS (one wave == one function): the first entries of every table live here and only
 // larger functions spill to the sparse global regions.  All lanes execute the same instruction stream on the same
 // addresses, so an LDS read is a broadcast and a global access touches one cache line.
-enum { LDS_FRAMES = 32, LDS_VARS = 1024, LDS_BBS = 256, LDS_LOCALS = 64, LDS_TYPES = 192 };
+#ifndef OPUSFE_LDS_VARS
+#define OPUSFE_LDS_VARS 512
+#endif
+#ifndef OPUSFE_LDS_BBS
+#define OPUSFE_LDS_BBS 256
+#endif
+#ifndef OPUSFE_LDS_TYPES
+#define OPUSFE_LDS_TYPES 192
+#endif
+enum { LDS_FRAMES = 32, LDS_VARS = OPUSFE_LDS_VARS, LDS_BBS = OPUSFE_LDS_BBS, LDS_LOCALS = 64, LDS_TYPES = OPUSFE_LDS_TYPES };
 struct LowerLds {
     LFrame frames[LDS_FRAMES];
     uint32_t vtype[LDS_VARS];
     uint32_t bbcnt[LDS_BBS], bblast[LDS_BBS];
     uint32_t lname[LDS_LOCALS], lvar[LDS_LOCALS], lhash[LDS_LOCALS], lstack[LDS_LOCALS];
     TypeRec types[LDS_TYPES];
+    uint32_t match_stack[96];   // work list of TypeOps::types_match
 };
 
 #ifdef OPUSFE_EMU
@@ -126,7 +136,7 @@ struct Lowerer {
     __device__ __forceinline__ void internal() { if (dev_status < DS_INTERNAL_CAPACITY) dev_status = DS_INTERNAL_CAPACITY; }
     __device__ __forceinline__ void unsupported() { if (dev_status < DS_UNSUPPORTED_SEMANTIC) dev_status = DS_UNSUPPORTED_SEMANTIC; }
     __device__ __forceinline__ opusfe_node N(uint32_t i) const { LPROF(LP_NODE); return uni(S.nodes[i]); }
-    __device__ __forceinline__ TypeOps T() { return TypeOps{S, &dev_status, lds->types, tbase, ntypes < LDS_TYPES ? ntypes : (uint32_t)LDS_TYPES}; }
+    __device__ __forceinline__ TypeOps T() { return TypeOps{S, &dev_status, lds->types, tbase, ntypes < LDS_TYPES ? ntypes : (uint32_t)LDS_TYPES, lds->match_stack}; }
     __device__ __forceinline__ TypeRec trec(uint32_t t) { return T().rec(t); }
 
     // ---- names (wave-cooperative byte compare: one memory round trip instead of one per character) ----
@@ -353,10 +363,10 @@ struct Lowerer {
         if ((e.kind_index >> 30) != NK_FUNCTION) return FN_NONE;
         return e.kind_index & 0x3FFFFFFFu;
     }
-    __device__ bool candidate_ok(uint32_t f, const uint32_t* arg_types, uint32_t n) {
+    __device__ bool candidate_ok(uint32_t f, const uint32_t* argv, const uint32_t* types_in, uint32_t n) {
         if (fn_nargs(f) != n) return false;
         uint32_t cur = fn_arg_cursor(f);
-        for (uint32_t i = 0; i < n; i++) if (T().can_autocast(arg_types[i], fn_arg_type(f, cur)) < 0) return false;
+        for (uint32_t i = 0; i < n; i++) if (T().can_autocast(types_in ? types_in[i] : vtype(argv[i]), fn_arg_type(f, cur)) < 0) return false;
         return true;
     }
     // arg types are read through `argv` (variable ids) unless `types` is given (Proc)
@@ -391,13 +401,12 @@ struct Lowerer {
         uint32_t slot;
         if (!name_has_functions(name, &slot)) { report(SE_UndefinedFunction, sp_low, sp_high); return FN_NONE; }
         if (n > 64) { unsupported(); return FN_NONE; }
-        uint32_t at[64];
-        for (uint32_t i = 0; i < n; i++) at[i] = types_in ? types_in[i] : vtype(argv[i]);
+#define ARG_T(i) (types_in ? types_in[i] : vtype(argv[i]))
         uint32_t total = 0; candidate(name, slot, 0, &total);
         uint32_t first = FN_NONE; uint64_t ignorable = ~0ull;
         for (uint32_t c = 0; c < total; c++) {
             uint32_t f = candidate(name, slot, c, &total);
-            if (f == FN_NONE || !candidate_ok(f, at, n)) continue;
+            if (f == FN_NONE || !candidate_ok(f, argv, types_in, n)) continue;
             if (first == FN_NONE) first = f;
             uint32_t c1 = fn_arg_cursor(first), c2 = fn_arg_cursor(f);
             for (uint32_t i = 0; i < n; i++) {
@@ -408,18 +417,19 @@ struct Lowerer {
         if (first == FN_NONE) { report(SE_NoOverloadForFunction, sp_low, sp_high); return FN_NONE; }
         for (uint32_t c = 0; c < total; c++) {
             uint32_t f = candidate(name, slot, c, &total);
-            if (f == FN_NONE || !candidate_ok(f, at, n)) continue;
+            if (f == FN_NONE || !candidate_ok(f, argv, types_in, n)) continue;
             bool all = true;
             uint32_t cf = fn_arg_cursor(f);
             for (uint32_t i = 0; i < n; i++) {
                 uint32_t ft = fn_arg_type(f, cf);
                 if ((ignorable >> i) & 1) continue;
-                if (!T().types_match_default_generic(ft, at[i])) { all = false; break; }
+                if (!T().types_match_default_generic(ft, ARG_T(i))) { all = false; break; }
             }
             if (all) return f;
         }
         report(SE_AmbiguousOverload, sp_low, sp_high);
         return FN_NONE;
+#undef ARG_T
     }
 
     // IrGenerator::lookup_function + get_function_call_variables (generate_ir.rs:1151-1198).
@@ -799,11 +809,13 @@ struct Lowerer {
                     case E_Variable: case E_Dereference: case E_VariableDefinition: case E_Field: case E_NamedCall: case E_CallOrIndex: case E_Record:
                         cur.st = LS_P; cur.aux = PT_Reference | PF_DEREF; cur.f = cur.node; goto next;
                     case E_Proc: {   // :586-602
-                        uint32_t types[64];
                         if (nd.nchild > 64) { unsupported(); rv = generate_error(); retn(); goto next; }
+                        const uint32_t saved_cargs = ncargs;
+                        uint32_t* types = cargs + reserve_cargs(nd.nchild);    // scratch use of the pool, released below
                         uint32_t c = nd.first_child;
                         for (uint32_t i = 0; i < nd.nchild; i++) { types[i] = resolve_type(c, undefined_flag); c = N(c).next; }
                         uint32_t f = compiler_lookup_function(nd.low, nd.high, key_tok(nd.payload), nullptr, types, nd.nchild);
+                        ncargs = saved_cargs;
                         if (f == FN_NONE) { rv = generate_error(); retn(); goto next; }
                         if (fn_is_builtin(f)) { report_node(SE_ReferenceToBuiltinFunction, cur.node); rv = generate_error(); retn(); goto next; }
                         uint32_t v = new_var(type_function(f), true);
@@ -1115,7 +1127,7 @@ __global__ void k_sem_user_syms(SemView S, uint64_t* __restrict__ out) {
 }
 
 // one lane per function definition
-__global__ __launch_bounds__(64) void k_lower_functions(SemView S, LowerBuffers B, const uint8_t* __restrict__ undefined_flag, const uint32_t* __restrict__ def_nodes,
+__global__ MACHINE_ATTR(OPUSFE_LOWER_WAVES) __launch_bounds__(64) void k_lower_functions(SemView S, LowerBuffers B, const uint8_t* __restrict__ undefined_flag, const uint32_t* __restrict__ def_nodes,
                                                          uint32_t n_defs, uint32_t n_nodes, const DefCnt* __restrict__ def_excl, FuncIr* __restrict__ out,
                                                          uint32_t* __restrict__ status, uint64_t* __restrict__ prof_out, const uint64_t* __restrict__ user_syms) {
     const uint32_t d = blockIdx.x * (blockDim.x / UNIT_LANES) + threadIdx.x / UNIT_LANES;
@@ -1131,8 +1143,12 @@ __global__ __launch_bounds__(64) void k_lower_functions(SemView S, LowerBuffers 
     __shared__ LowerLds lds_block[64 / UNIT_LANES];
     // the machine's registers live in LDS too: helper functions the compiler keeps out of line receive `this`, and an
     // object in scratch (private memory) would turn every field access into a global-memory round trip
+#ifdef OPUSFE_FLATTEN
+    Lowerer L;
+#else
     __shared__ Lowerer machine_block[64 / UNIT_LANES];
     Lowerer& L = machine_block[threadIdx.x / UNIT_LANES];
+#endif
     L.lds = &lds_block[threadIdx.x / UNIT_LANES];
     L.lane = lane;
     L.user_syms = *user_syms;

@@ -612,15 +612,19 @@ struct SegParser {
     }
 };
 
-__global__ __launch_bounds__(64) void k_parse_segments(const opusfe_token* __restrict__ tok, uint32_t n_tokens, const uint32_t* __restrict__ seg_start,
+__global__ MACHINE_ATTR(OPUSFE_PARSE_WAVES) __launch_bounds__(64) void k_parse_segments(const opusfe_token* __restrict__ tok, uint32_t n_tokens, const uint32_t* __restrict__ seg_start,
                                                         uint32_t n_segs, opusfe_node* __restrict__ nodes, PFrame* __restrict__ frames,
                                                         uint32_t* __restrict__ seg_info, uint32_t* __restrict__ status, uint32_t* __restrict__ first_err_seg) {
     const uint32_t s = blockIdx.x * (blockDim.x / UNIT_LANES) + threadIdx.x / UNIT_LANES;
     const uint32_t lane = threadIdx.x % UNIT_LANES;
     if (s >= n_segs) return;
     uint32_t tb = seg_start[s], te = (s + 1 < n_segs) ? seg_start[s + 1] : n_tokens;
+#ifdef OPUSFE_FLATTEN
+    SegParser P;
+#else
     __shared__ SegParser machine_block[64 / UNIT_LANES];   // see lower.h: keeps the machine state out of scratch memory
     SegParser& P = machine_block[threadIdx.x / UNIT_LANES];
+#endif
     P.tok = tok; P.nodes = nodes; P.n_tokens = n_tokens;
     P.nbase = seg_node_base(tb, s); P.ncap = seg_node_cap(tb, te);
     P.stack = frames + seg_frame_base(tb, s); P.fcap = seg_frame_cap(tb, te);

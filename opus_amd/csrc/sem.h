@@ -166,6 +166,7 @@ struct TypeOps {
     uint32_t* dev_status;   // lane-local status word (DS_UNSUPPORTED_SEMANTIC when the reference would overflow its stack)
     // records of the types the running function created itself, kept in LDS by the lowering kernel (else null)
     const TypeRec* local_cache; uint32_t local_base, local_cached;
+    uint32_t* match_stack;   // 2 x 48 words of work list for types_match
     // primitives need no memory access; the function's own types come from LDS; everything else from the table
     __device__ __forceinline__ TypeRec rec(uint32_t t) const {
         if (t < TP_COUNT) { TypeRec r{}; r.kind = prim_kind(t); r.alias = OPUSFE_NONE; return r; }
@@ -202,7 +203,7 @@ struct TypeOps {
     // cycle check: on a self-referential record it overflows its stack; we report UNSUPPORTED instead)
     __device__ bool types_match(uint32_t a0, uint32_t b0) const {
         if (a0 < TP_COUNT && b0 < TP_COUNT) return a0 == b0;    // primitives: one id per kind
-        uint32_t stack_a[48], stack_b[48];
+        uint32_t* stack_a = match_stack; uint32_t* stack_b = match_stack + 48;
         int sp = 0;
         uint32_t a = a0, b = b0;
         uint32_t budget = 1u << 20;
