@@ -109,6 +109,12 @@ int opusfe_parse_device(opusfe_ctx* ctx, const uint8_t* d_src, uint64_t len, opu
 int opusfe_lex_device(opusfe_ctx* ctx, const uint8_t* d_src, uint64_t len, int force_dents, opusfe_unit** out);
 int opusfe_lex(opusfe_ctx* ctx, const uint8_t* src, uint64_t len, int force_dents, opusfe_unit** out);
 
+/* corpus of independent files (one reference run per file, frontend.rs:23-118 without imports): parses (and lowers when
+   `lower` != 0) every file; units[i] / statuses[i] receive the unit and its return code; the call itself only fails on
+   device / argument errors.  Each unit is released with opusfe_free_unit. */
+int opusfe_parse_batch(opusfe_ctx* ctx, uint32_t n, const uint8_t* const* srcs, const uint64_t* lens, int lower,
+                       opusfe_unit** units, int* statuses);
+
 /* ---- seam B: AST -> IR (frontend.rs:140 compile_source, IR part) ---- */
 int opusfe_lower(opusfe_ctx* ctx, opusfe_unit* unit);
 

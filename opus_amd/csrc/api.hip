@@ -262,6 +262,22 @@ int opusfe_lower(opusfe_ctx* ctx, opusfe_unit* unit) {
     return guarded(ctx, [&] { run_lower(ctx, unit); return unit->status; });
 }
 
+// Corpus of independent files (BASELINE config 5): every file is its own compilation universe like one run of the
+// reference (frontend.rs:52-55).  Round-1 implementation: the files go through the single-source pipeline one after
+// the other on ctx's stream (launch-bound for small files; a segmented multi-file pipeline is DESIGN.md §8 work).
+int opusfe_parse_batch(opusfe_ctx* ctx, uint32_t n, const uint8_t* const* srcs, const uint64_t* lens, int lower, opusfe_unit** units, int* statuses) {
+    if (!ctx || (n && (!srcs || !lens || !units || !statuses))) return OPUSFE_ERR_ARG;
+    int worst = OPUSFE_OK;
+    for (uint32_t i = 0; i < n; i++) {
+        units[i] = nullptr;
+        int rc = opusfe_parse(ctx, srcs[i], lens[i], &units[i]);
+        if (rc == OPUSFE_OK && lower) rc = opusfe_lower(ctx, units[i]);
+        statuses[i] = rc;
+        if (rc >= OPUSFE_ERR_HIP && rc != OPUSFE_SEMANTIC) worst = rc;
+    }
+    return worst;
+}
+
 int opusfe_semantic_error_count(const opusfe_unit* u, uint64_t* n) {
     if (!u || !n) return OPUSFE_ERR_ARG;
     *n = u->ir ? ((const IrResult*)u->ir)->n_sem_errors : 0;

@@ -60,6 +60,8 @@ def lib():
             getattr(L, name).argtypes = [vp, vp, u64, C.POINTER(vp)]
         for name in ("opusfe_lex", "opusfe_lex_device"):
             getattr(L, name).argtypes = [vp, vp, u64, i, C.POINTER(vp)]
+        L.opusfe_parse_batch.argtypes = [vp, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(u64), i, C.POINTER(vp), C.POINTER(i)]
+        L.opusfe_semantic_error_count.argtypes = [vp, C.POINTER(u64)]
         L.opusfe_lower.argtypes = [vp, vp]
         L.opusfe_unit_status.argtypes = [vp]
         L.opusfe_get_counts.argtypes = [vp, C.POINTER(Counts)]
@@ -179,6 +181,19 @@ class Context:
     def get_definitions_device(self, d_ptr: int, length: int):
         out = C.c_void_p()
         return self._finish(lib().opusfe_parse_device(self.handle, C.c_void_p(d_ptr), length, C.byref(out)), out)
+
+    def compile_corpus(self, sources, lower=True):
+        """Corpus of independent files (one reference run per file): list of Units, each with its own status."""
+        n = len(sources)
+        srcs = (C.c_char_p * n)(*sources)
+        lens = (C.c_uint64 * n)(*[len(s) for s in sources])
+        units = (C.c_void_p * n)()
+        statuses = (C.c_int * n)()
+        rc = lib().opusfe_parse_batch(self.handle, n, srcs, lens, int(lower), units, statuses)
+        out = [Unit(self, C.c_void_p(units[k]), statuses[k]) for k in range(n)]
+        if rc != OK:
+            raise OpusfeError(rc, self.message())
+        return out
 
     def lex(self, source: bytes, force_dents=False):
         out = C.c_void_p()

@@ -1,0 +1,39 @@
+"""Host-side multi-GPU logic (one process per GPU, torch.distributed; backend "nccl" is RCCL on ROCm, "gloo" in the CPU tests).
+
+Independent files and segment-aligned shards need NO data-path collective: ranks only agree on who owns
+what (a pure function of the sizes) and reduce their timings / counters at the end.
+"""
+import torch
+
+
+def shard_by_bytes(sizes, rank, world):
+    """Indices of the files rank `rank` owns: contiguous split by cumulative byte balance (deterministic on every rank)."""
+    total = sum(sizes)
+    lo, hi = total * rank / world, total * (rank + 1) / world
+    out, acc = [], 0
+    for i, s in enumerate(sizes):
+        mid = acc + s / 2.0
+        if lo <= mid < hi or (rank == world - 1 and mid >= hi):
+            out.append(i)
+        acc += s
+    return out
+
+
+def _device(dist):
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
+def all_reduce_max(value, dist):
+    if dist is None:
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=_device(dist))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def all_reduce_sum(value, dist):
+    if dist is None:
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=_device(dist))
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())

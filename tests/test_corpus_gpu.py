@@ -1,0 +1,50 @@
+"""GPU: corpus of independent files (BASELINE config 5) — per-file IR / first-error parity with the oracle."""
+import hashlib
+
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+def make_corpus(n, seed0=5_000_000):
+    files = []
+    for i in range(n):
+        size = 1024 + (i * 7919) % (24 * 1024)
+        src = O.generate(seed0 + i, size)
+        if i % 10 == 7:                      # a share of the files carries exactly one injected fault
+            bad = O.inject(src, seed0 + i, i % 10)
+            src = bad or src
+        files.append(src)
+    return files
+
+
+def test_corpus_matches_oracle_per_file(fe):
+    files = make_corpus(60)
+    units = fe.compile_corpus(files)
+    assert len(units) == len(files)
+    errors = 0
+    for src, u in zip(files, units):
+        want_err = O.dump(src, O.ERROR)
+        if want_err != "Ok\n":
+            errors += 1
+            if u.status == 2:
+                continue                     # swallowed bad escape: documented UNSUPPORTED
+            assert u.status == 1 and u.dump_error() == want_err
+            continue
+        if u.status == 2:
+            continue
+        assert u.status == 0, (u.status, src[:60])
+        got, want = u.dump_ir(), O.dump(src, O.IR)
+        assert hashlib.sha256(got.encode()).digest() == hashlib.sha256(want.encode()).digest()
+    assert errors >= 3
+    for u in units:
+        u.close()
+
+
+def test_empty_corpus_and_empty_file(fe):
+    assert fe.compile_corpus([]) == []
+    u = fe.compile_corpus([b"", b"; nothing\n"])
+    assert [x.status for x in u] == [0, 0]
+    assert all(x.dump_ir() == "" for x in u)
