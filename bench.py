@@ -52,6 +52,10 @@ def main():
     ap.add_argument("--bytes", type=float, default=1e9, help="source bytes per GPU")
     ap.add_argument("--seed", type=int, default=3)
     ap.add_argument("--stage", default="ir", choices=["lex", "parse", "ir"], help="deepest stage to run (default: whole path)")
+    ap.add_argument("--workload", default=None, choices=["c3", "c4"],
+                    help="c3: one source per GPU (default at N=1; at N>1 independent shards, no collective); "
+                         "c4: ONE logical source of N x bytes cut at arbitrary byte positions, carries exchanged by all-gather (default at N>1)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo lets several ranks share one GPU (rehearsal only)")
     ap.add_argument("--cpu-sample-bytes", type=float, default=48e6)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -67,27 +71,64 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     dist = None
+    local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
+    workload = args.workload or ("c3" if world == 1 else "c4")
 
     nbytes = int(args.bytes)
     threads = min(16, os.cpu_count() or 8)
     t0 = time.time()
-    src = O.generate(args.seed + 1000 * rank, nbytes, flags=1, threads=max(1, threads // max(1, min(world, 8))) if world > 1 else threads)
+    gen_threads = max(1, threads // max(1, min(world, 8))) if world > 1 else threads
+    if workload == "c3":
+        src = O.generate(args.seed + 1000 * rank, nbytes, flags=1, threads=gen_threads)
+    else:
+        # rank r holds bytes [r*B + shift, (r+1)*B + shift) of ONE generated source of world*B bytes (rank 0 from byte 0):
+        # the cuts fall in the middle of lines, strings and blocks on purpose
+        nblk = 16
+        blk = nbytes // nblk
+        nbytes = blk * nblk
+        shift = 12345 if world > 1 else 0
+        mine = O.generate_range(args.seed, rank * nblk, nblk, blk, flags=1, threads=gen_threads)
+        nxt = O.generate_range(args.seed, (rank + 1) * nblk, 1, blk, flags=1, threads=1)[:shift] if rank + 1 < world else b""
+        src = (mine if rank == 0 else mine[shift:]) + nxt
     gen_s = time.time() - t0
-    d_src = torch.empty(nbytes + 64, dtype=torch.uint8, device="cuda")
-    d_src[:nbytes].copy_(torch.frombuffer(bytearray(src), dtype=torch.uint8))
+    n_local = len(src)
+    d_src = torch.empty(n_local + 64, dtype=torch.uint8, device="cuda")
+    d_src[:n_local].copy_(torch.frombuffer(bytearray(src), dtype=torch.uint8))
     torch.cuda.synchronize()
 
     ctx = opus_amd.Context(local_rank)
+    gather = None
+    if workload == "c4" and world > 1:
+        from opus_amd import shard, sharding
+        gather = sharding.make_gather(dist, torch.device("cuda", local_rank))
+
+    def step_c4():
+        st = shard.RankState(ctx, d_src[:n_local], rank, world)
+        shard.plan([st], gather)
+        res = shard.compile_sharded([st], gather, lower=(args.stage == "ir"))[0]
+        if res["status"] != opus_amd.OK:
+            raise SystemExit(f"rank {rank}: sharded hot path failed: status {res['status']} (first bad rank {res['first_bad_rank']}): {ctx.message()}")
+        c = res["unit"].counts()
+        own = res["own_counts"]
+        for k in ("source_bytes", "tokens", "nodes"):
+            c[k] = own[k]                  # tokens / nodes of the bytes this rank owns (the unit also holds the other ranks' headers)
+        res["unit"].close()
+        return c
 
     def step():
+        if gather is not None:
+            return step_c4()
         if args.stage == "lex":
-            u = ctx.lex_device(d_src.data_ptr(), nbytes)
+            u = ctx.lex_device(d_src.data_ptr(), n_local)
         else:
-            u = ctx.get_definitions_device(d_src.data_ptr(), nbytes)
+            u = ctx.get_definitions_device(d_src.data_ptr(), n_local)
         if u.status != opus_amd.OK:
             raise SystemExit(f"rank {rank}: hot path failed: status {u.status}: {ctx.message()} {u.dump_error() if u.status == 1 else ''}")
         if args.stage == "ir":
@@ -116,9 +157,8 @@ def main():
     kstats = ctx.kernel_stats()
     ctx.set_profiling(False)
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        from opus_amd import sharding as _sh
+        dt = _sh.all_reduce_max(dt, dist)
 
     S, T, N = counts["source_bytes"], counts["tokens"], counts["nodes"]
     I, V = counts["instrs"], counts["vars"]
@@ -154,9 +194,11 @@ def main():
         out = {"metric": f"source MB/s {stage_name} (whole node)", "value": round(value, 2), "unit": "MB/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-               "config": {"workload": f"C3: one synthetic source of {nbytes} B per GPU, generator G(seed={args.seed}), depth-1000 regions, {world} GPU(s)",
+               "config": {"workload": (f"C3: one synthetic source of {nbytes} B per GPU, generator G(seed={args.seed}), depth-1000 regions, {world} GPU(s)" if workload == "c3" else
+                                       f"C4: ONE synthetic source of {world * nbytes} B cut at arbitrary bytes over {world} GPUs ({nbytes} B each), carries by all-gather, generator G(seed={args.seed})"),
                           "source_bytes_per_gpu": nbytes, "tokens": T, "nodes": N, "instrs": I, "vars": V,
-                          "functions": counts["functions"], "algorithmic_bytes": total_alg, "sharding": "none" if world == 1 else "independent shards, no collective"},
+                          "functions": counts["functions"], "algorithmic_bytes": total_alg, "sharding": "none" if world == 1 else ("independent shards, no collective" if workload == "c3" else
+                                       "byte-range shards; all-gather of ctx/tail/depth/cut carries, prefix halo, definition headers")},
                "hbm_gbs_whole_path": round(world * total_alg / (dt / args.steps) / 1e9, 2),
                "hbm_frac_whole_path": round(total_alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 5),
                "roofline": roofline, "cpu_baseline": cpu,

@@ -115,6 +115,21 @@ int opusfe_lex(opusfe_ctx* ctx, const uint8_t* src, uint64_t len, int force_dent
 int opusfe_parse_batch(opusfe_ctx* ctx, uint32_t n, const uint8_t* const* srcs, const uint64_t* lens, int lower,
                        opusfe_unit** units, int* statuses);
 
+/* ---- one huge source sharded over several GPUs (no reference counterpart: the reference is single-threaded; this is the
+   byte-range analogue of its sequential lexer state, parse.rs:364-391, carried across shards) ----
+   A shard starts right after a '\n'.  The host chains three tiny exchanges (all_gather over RCCL): context function ->
+   start state, token-kind tails -> bracket depth, then picks as its cut the first top-level segment start. */
+typedef struct opusfe_shard opusfe_shard;
+int opusfe_shard_ctx(opusfe_ctx* ctx, const uint8_t* d_src, uint64_t len, uint32_t* fn);
+int opusfe_shard_lex(opusfe_ctx* ctx, const uint8_t* d_src, uint64_t len, uint32_t start_state, opusfe_shard** out,
+                     uint64_t* n_tokens, uint64_t* tail_kinds);
+int opusfe_shard_net_depth(opusfe_shard* shard, uint64_t prev_kinds, int64_t* net);
+int opusfe_shard_boundary(opusfe_shard* shard, int64_t depth_in, uint64_t* pos);
+void opusfe_shard_free(opusfe_shard* shard);
+/* device text (owned by the unit) that other shards prepend / append to see this unit's definitions: functions as
+   `extern <signature>`, externs / types / globals verbatim, one per line, in file order */
+int opusfe_unit_headers(opusfe_unit* unit, const uint8_t** d_out, uint64_t* len);
+
 /* ---- seam B: AST -> IR (frontend.rs:140 compile_source, IR part) ---- */
 int opusfe_lower(opusfe_ctx* ctx, opusfe_unit* unit);
 

@@ -69,7 +69,7 @@ void run_lexer(opusfe_ctx* ctx, opusfe_unit* u, int force_dents) {
         Cnt3* tile_cnt = tmp.get<Cnt3>(ntiles);
         Cnt3* scan_tmp = tmp.get<Cnt3>((ntiles + SCAN_TILE - 1) / SCAN_TILE + 1);
         LAUNCH(ctx, "lex_ctx_chunk", k_ctx_chunk, ntiles, LEX_THREADS, src, n, chunk_fn, tile_fn);
-        LAUNCH(ctx, "lex_ctx_tiles", k_ctx_tiles, 1, SCAN_THREADS, tile_fn, tile_state, (uint32_t)ntiles);
+        LAUNCH(ctx, "lex_ctx_tiles", k_ctx_tiles, 1, SCAN_THREADS, tile_fn, tile_state, (uint32_t)ntiles, (uint32_t)CS_N, (uint32_t*)nullptr);
         LAUNCH(ctx, "lex_count", k_lex_count, ntiles, LEX_THREADS, src, n, chunk_fn, tile_state, chunk_state, chunk_cnt, chunk_str, tile_cnt, status);
         prof_begin(ctx, "scan_cnt3");
         device_scan<true>(tile_cnt, tile_cnt, ntiles, OpAddCnt3(), Cnt3{0, 0, 0, 0}, scan_tmp, (Cnt3*)(ctx->d_status + W_LEXTOT), st);
@@ -93,12 +93,12 @@ void run_lexer(opusfe_ctx* ctx, opusfe_unit* u, int force_dents) {
     uint32_t* seg_excl = tmp.get<uint32_t>(G);
     uint32_t* scan_tmp32 = tmp.get<uint32_t>((G + SCAN_TILE - 1) / SCAN_TILE + 1);
     if (T > 0) {
-        LAUNCH(ctx, "tok_delta", k_tok_delta, grid_for(T, 256), 256, raw, T, depth, force_dents);
+        LAUNCH(ctx, "tok_delta", k_tok_delta, grid_for(T, 256), 256, raw, T, depth, force_dents, (uint64_t)TK_NO_PREV);
         prof_begin(ctx, "scan_depth");
         device_scan<false>(depth, depth, T, OpAddI32(), (int32_t)0, (int32_t*)scan_tmp32, (int32_t*)nullptr, st);
         prof_end(ctx);
     }
-    LAUNCH(ctx, "tok_gap", k_gap, grid_for(G, 256), 256, src, n, raw, T, depth, gapval);
+    LAUNCH(ctx, "tok_gap", k_gap, grid_for(G, 256), 256, src, n, raw, T, depth, gapval, (int32_t)0);
     prof_begin(ctx, "scan_indent");
     device_scan<true>(gapval, prev, G, OpLast(), (uint32_t)0, scan_tmp32, (uint32_t*)nullptr, st);
     prof_end(ctx);
@@ -165,6 +165,155 @@ int guarded(opusfe_ctx* ctx, F&& f) {
 constexpr uint64_t MAX_LEN = 0xFFFF0000ull;   // positions are u32 per unit (SURVEY §7 hard part 6: larger inputs are sharded)
 
 }  // namespace
+
+
+// ---- multi-GPU shard carries ---------------------------------------------------------
+// A shard is a byte range of one huge source that starts right after a '\n'.  The carries form a chain:
+//   context-DFA function of the bytes  ->  start state  ->  raw tokens  ->  kinds of the last tokens  ->  bracket depth
+// Each link is a few bytes per rank exchanged with all_gather by the host (opus_amd/shard.py); these entry points
+// compute the rank-local part on the GPU.
+struct opusfe_shard {
+    opusfe_ctx* ctx; const uint8_t* d_src; uint32_t len;
+    opusfe_token* raw; uint32_t T;
+    int32_t* depth; uint32_t* gapval; uint32_t* prev; uint32_t* scan_tmp;
+    uint64_t* val64; uint8_t* strpool;
+};
+
+namespace {
+void shard_release(opusfe_shard* s) {
+    opusfe_ctx* ctx = s->ctx;
+    dev_free(ctx, s->raw); dev_free(ctx, s->depth); dev_free(ctx, s->gapval); dev_free(ctx, s->prev); dev_free(ctx, s->scan_tmp);
+    dev_free(ctx, s->val64); dev_free(ctx, s->strpool);
+    delete s;
+}
+}  // namespace
+
+extern "C" {
+
+// composed context-automaton transition function (18 bits, lex.h CTXFN) of d_src[0, len)
+int opusfe_shard_ctx(opusfe_ctx* ctx, const uint8_t* d_src, uint64_t len, uint32_t* fn) {
+    if (!fn || (len && !d_src) || len > MAX_LEN) return OPUSFE_ERR_ARG;
+    return guarded(ctx, [&] {
+        *fn = CTX_IDENTITY;
+        if (len == 0) return (int)OPUSFE_OK;
+        TempList tmp(ctx);
+        const uint32_t n = (uint32_t)len;
+        const uint64_t nchunks = ((uint64_t)n + LEX_CHUNK - 1) / LEX_CHUNK, ntiles = (nchunks + LEX_THREADS - 1) / LEX_THREADS;
+        uint32_t* chunk_fn = tmp.get<uint32_t>(nchunks);
+        uint32_t* tile_fn = tmp.get<uint32_t>(ntiles);
+        uint8_t* tile_state = tmp.get<uint8_t>(ntiles);
+        LAUNCH(ctx, "lex_ctx_chunk", k_ctx_chunk, ntiles, LEX_THREADS, d_src, n, chunk_fn, tile_fn);
+        LAUNCH(ctx, "lex_ctx_tiles", k_ctx_tiles, 1, SCAN_THREADS, tile_fn, tile_state, (uint32_t)ntiles, (uint32_t)CS_N, ctx->d_status + 60);
+        HIP_TRY(hipMemcpyAsync(ctx->h_status + 60, ctx->d_status + 60, 4, hipMemcpyDeviceToHost, ctx->stream));
+        sync_stream(ctx);
+        *fn = ctx->h_status[60];
+        return (int)OPUSFE_OK;
+    });
+}
+
+// raw (dent-free) tokens of a shard whose first byte is in context `start_state`; *n_tokens and the kinds of its last
+// (up to 8) tokens, most recent in the low byte, T_EndOfFile where there is none
+int opusfe_shard_lex(opusfe_ctx* ctx, const uint8_t* d_src, uint64_t len, uint32_t start_state, opusfe_shard** out, uint64_t* n_tokens, uint64_t* tail_kinds) {
+    if (!out || !n_tokens || !tail_kinds || (len && !d_src) || len > MAX_LEN || start_state > CS_C) return OPUSFE_ERR_ARG;
+    *out = nullptr;
+    return guarded(ctx, [&] {
+        opusfe_shard* s = new opusfe_shard();
+        s->ctx = ctx; s->d_src = d_src; s->len = (uint32_t)len; s->raw = nullptr; s->T = 0;
+        s->depth = nullptr; s->gapval = nullptr; s->prev = nullptr; s->scan_tmp = nullptr; s->val64 = nullptr; s->strpool = nullptr;
+        *out = s;
+        *n_tokens = 0; *tail_kinds = TK_NO_PREV;
+        const uint32_t n = (uint32_t)len;
+        hipStream_t st = ctx->stream;
+        HIP_TRY(hipMemsetAsync(ctx->d_status, 0, 64 * sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(ctx->d_status + W_UNSUP_POS, 0xFF, sizeof(uint32_t), st));
+        if (n == 0) return (int)OPUSFE_OK;
+        TempList tmp(ctx);
+        const uint64_t nchunks = ((uint64_t)n + LEX_CHUNK - 1) / LEX_CHUNK, ntiles = (nchunks + LEX_THREADS - 1) / LEX_THREADS;
+        uint32_t* chunk_fn = tmp.get<uint32_t>(nchunks);
+        uint32_t* tile_fn = tmp.get<uint32_t>(ntiles);
+        uint8_t* tile_state = tmp.get<uint8_t>(ntiles);
+        uint8_t* chunk_state = tmp.get<uint8_t>(nchunks);
+        uint32_t* chunk_cnt = tmp.get<uint32_t>(nchunks);
+        uint32_t* chunk_str = tmp.get<uint32_t>(nchunks);
+        Cnt3* tile_cnt = tmp.get<Cnt3>(ntiles);
+        Cnt3* scan_tmp = tmp.get<Cnt3>((ntiles + SCAN_TILE - 1) / SCAN_TILE + 1);
+        uint32_t* status = ctx->d_status + W_STATUS;
+        LAUNCH(ctx, "lex_ctx_chunk", k_ctx_chunk, ntiles, LEX_THREADS, d_src, n, chunk_fn, tile_fn);
+        LAUNCH(ctx, "lex_ctx_tiles", k_ctx_tiles, 1, SCAN_THREADS, tile_fn, tile_state, (uint32_t)ntiles, start_state, (uint32_t*)nullptr);
+        LAUNCH(ctx, "lex_count", k_lex_count, ntiles, LEX_THREADS, d_src, n, chunk_fn, tile_state, chunk_state, chunk_cnt, chunk_str, tile_cnt, status);
+        device_scan<true>(tile_cnt, tile_cnt, ntiles, OpAddCnt3(), Cnt3{0, 0, 0, 0}, scan_tmp, (Cnt3*)(ctx->d_status + W_LEXTOT), st);
+        fetch_status(ctx);
+        const uint32_t T = ctx->h_status[W_LEXTOT], nval = ctx->h_status[W_LEXTOT + 1], nstr = ctx->h_status[W_LEXTOT + 2];
+        s->T = T;
+        s->raw = dev_alloc_t<opusfe_token>(ctx, T);
+        s->val64 = dev_alloc_t<uint64_t>(ctx, nval);
+        s->strpool = dev_alloc_t<uint8_t>(ctx, nstr);
+        LAUNCH(ctx, "lex_emit", k_lex_emit, ntiles, LEX_THREADS, d_src, n, chunk_state, chunk_cnt, chunk_str, tile_cnt, s->raw, s->val64, s->strpool, status);
+        const uint64_t G = (uint64_t)T + 1;
+        s->depth = dev_alloc_t<int32_t>(ctx, G); s->gapval = dev_alloc_t<uint32_t>(ctx, G); s->prev = dev_alloc_t<uint32_t>(ctx, G);
+        s->scan_tmp = dev_alloc_t<uint32_t>(ctx, (G + SCAN_TILE - 1) / SCAN_TILE + 2);
+        // kinds of the last tokens
+        opusfe_token tail[8];
+        const uint32_t nt = T < 8 ? T : 8;
+        if (nt) HIP_TRY(hipMemcpyAsync(tail, s->raw + (T - nt), nt * sizeof(opusfe_token), hipMemcpyDeviceToHost, st));
+        sync_stream(ctx);
+        uint64_t kinds = TK_NO_PREV;
+        for (uint32_t j = 0; j < nt; j++) {
+            uint8_t k = tail[nt - 1 - j].kind;
+            if (k == T_Error) k = T_String;   // an "unterminated" string at the end of a shard continues in the next one
+            kinds = (kinds & ~(0xFFull << (8 * j))) | ((uint64_t)k << (8 * j));
+        }
+        *n_tokens = T; *tail_kinds = kinds;
+        return (int)OPUSFE_OK;
+    });
+}
+
+// net change of the bracket counter (`ignore_dents`) over the shard, given the kinds of the tokens before it
+int opusfe_shard_net_depth(opusfe_shard* s, uint64_t prev_kinds, int64_t* net) {
+    if (!s || !net) return OPUSFE_ERR_ARG;
+    opusfe_ctx* ctx = s->ctx;
+    return guarded(ctx, [&] {
+        *net = 0;
+        if (s->T == 0) return (int)OPUSFE_OK;
+        hipStream_t st = ctx->stream;
+        LAUNCH(ctx, "tok_delta", k_tok_delta, grid_for(s->T, 256), 256, s->raw, s->T, s->depth, 0, prev_kinds);
+        device_scan<false>(s->depth, s->depth, s->T, OpAddI32(), (int32_t)0, (int32_t*)s->scan_tmp, (int32_t*)(ctx->d_status + 61), st);
+        HIP_TRY(hipMemcpyAsync(ctx->h_status + 61, ctx->d_status + 61, 4, hipMemcpyDeviceToHost, st));
+        sync_stream(ctx);
+        *net = (int32_t)ctx->h_status[61];
+        return (int)OPUSFE_OK;
+    });
+}
+
+// byte position of the first top-level segment start that is provable inside the shard (after opusfe_shard_net_depth
+// with the same prev_kinds), or UINT64_MAX when there is none
+int opusfe_shard_boundary(opusfe_shard* s, int64_t depth_in, uint64_t* pos) {
+    if (!s || !pos) return OPUSFE_ERR_ARG;
+    opusfe_ctx* ctx = s->ctx;
+    return guarded(ctx, [&] {
+        *pos = ~0ull;
+        if (s->T == 0) return (int)OPUSFE_OK;
+        hipStream_t st = ctx->stream;
+        const uint64_t G = (uint64_t)s->T + 1;
+        LAUNCH(ctx, "tok_gap", k_gap, grid_for(G, 256), 256, s->d_src, s->len, s->raw, s->T, s->depth, s->gapval, (int32_t)depth_in);
+        device_scan<true>(s->gapval, s->prev, G, OpLast(), (uint32_t)0, s->scan_tmp, (uint32_t*)nullptr, st);
+        HIP_TRY(hipMemsetAsync(ctx->d_status + 62, 0xFF, 4, st));
+        LAUNCH(ctx, "shard_first_segment", k_shard_first_segment, grid_for(s->T, 256), 256, s->raw, s->T, s->gapval, s->prev, ctx->d_status + 62);
+        HIP_TRY(hipMemcpyAsync(ctx->h_status + 62, ctx->d_status + 62, 4, hipMemcpyDeviceToHost, st));
+        sync_stream(ctx);
+        if (ctx->h_status[62] != 0xFFFFFFFFu) *pos = ctx->h_status[62];
+        return (int)OPUSFE_OK;
+    });
+}
+
+void opusfe_shard_free(opusfe_shard* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->ctx->device);
+    (void)hipStreamSynchronize(s->ctx->stream);
+    shard_release(s);
+}
+
+}  // extern "C"
 
 extern "C" {
 
@@ -278,6 +427,36 @@ int opusfe_parse_batch(opusfe_ctx* ctx, uint32_t n, const uint8_t* const* srcs, 
     return worst;
 }
 
+// Text another shard needs to know about this unit's definitions (multi-GPU IR generation): device buffer owned by
+// the unit.  Functions appear as `extern <signature>`, everything else verbatim, one definition per line, file order.
+int opusfe_unit_headers(opusfe_unit* u, const uint8_t** d_out, uint64_t* len) {
+    if (!u || !d_out || !len) return OPUSFE_ERR_ARG;
+    if (!u->parsed || u->status != OPUSFE_OK) return OPUSFE_ERR_ARG;
+    opusfe_ctx* ctx = u->ctx;
+    return guarded(ctx, [&] {
+        if (!u->d_headers) {
+            const uint32_t n_defs = (uint32_t)u->n_defs;
+            u->n_headers = 0;
+            if (n_defs) {
+                TempList tmp(ctx);
+                uint32_t* off = tmp.get<uint32_t>(n_defs);
+                uint32_t* scan_tmp = tmp.get<uint32_t>((n_defs + SCAN_TILE - 1) / SCAN_TILE + 2);
+                LAUNCH(ctx, "hdr_len", k_hdr_len, grid_for(n_defs, 256), 256, u->d_nodes, u->d_def_nodes, n_defs, off);
+                device_scan<true>(off, off, n_defs, OpAddU32(), (uint32_t)0, scan_tmp, ctx->d_status + 63, ctx->stream);
+                HIP_TRY(hipMemcpyAsync(ctx->h_status + 63, ctx->d_status + 63, 4, hipMemcpyDeviceToHost, ctx->stream));
+                sync_stream(ctx);
+                u->n_headers = ctx->h_status[63];
+                u->d_headers = dev_alloc_t<uint8_t>(ctx, u->n_headers + 16);
+                unsigned grid = (unsigned)((n_defs + 3) / 4); if (grid > 4096) grid = 4096;
+                LAUNCH(ctx, "hdr_copy", k_hdr_copy, grid, 256, u->d_src, u->d_nodes, u->d_def_nodes, n_defs, off, u->d_headers);
+                sync_stream(ctx);
+            } else u->d_headers = dev_alloc_t<uint8_t>(ctx, 16);
+        }
+        *d_out = u->d_headers; *len = u->n_headers;
+        return (int)OPUSFE_OK;
+    });
+}
+
 int opusfe_semantic_error_count(const opusfe_unit* u, uint64_t* n) {
     if (!u || !n) return OPUSFE_ERR_ARG;
     *n = u->ir ? ((const IrResult*)u->ir)->n_sem_errors : 0;
@@ -348,7 +527,7 @@ void opusfe_free_unit(opusfe_unit* u) {
     (void)hipStreamSynchronize(ctx->stream);
     if (u->own_src) dev_free(ctx, (void*)u->d_src);
     dev_free(ctx, u->d_tokens); dev_free(ctx, u->d_val64); dev_free(ctx, u->d_strpool); dev_free(ctx, u->d_seg_start);
-    dev_free(ctx, u->d_nodes); dev_free(ctx, u->d_seg_info); dev_free(ctx, u->d_def_nodes);
+    dev_free(ctx, u->d_nodes); dev_free(ctx, u->d_seg_info); dev_free(ctx, u->d_def_nodes); dev_free(ctx, u->d_headers);
     free_ir(ctx, u);
     delete u;
 }

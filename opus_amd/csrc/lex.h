@@ -88,7 +88,8 @@ __global__ __launch_bounds__(LEX_THREADS) void k_ctx_chunk(const uint8_t* __rest
 }
 
 // tile_fn[i] (composed function of tile i)  ->  tile_state[i] = context state at the start of tile i
-__global__ __launch_bounds__(SCAN_THREADS) void k_ctx_tiles(const uint32_t* __restrict__ tile_fn, uint8_t* __restrict__ tile_state, uint32_t ntiles) {
+__global__ __launch_bounds__(SCAN_THREADS) void k_ctx_tiles(const uint32_t* __restrict__ tile_fn, uint8_t* __restrict__ tile_state, uint32_t ntiles,
+                                                            uint32_t start_state, uint32_t* __restrict__ total_fn) {
     __shared__ uint32_t lds[4];
     __shared__ uint32_t wave_last[4];
     __shared__ uint32_t carry_s;
@@ -111,11 +112,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_ctx_tiles(const uint32_t* __re
         else excl = ctx_compose(carry_s, prev);
         uint32_t run = excl;
 #pragma unroll
-        for (int i = 0; i < SCAN_ITEMS; i++) { if (b + i < ntiles) tile_state[b + i] = (uint8_t)ctx_apply(run, CS_N); run = ctx_compose(run, v[i]); }
+        for (int i = 0; i < SCAN_ITEMS; i++) { if (b + i < ntiles) tile_state[b + i] = (uint8_t)ctx_apply(run, start_state); run = ctx_compose(run, v[i]); }
         __syncthreads();
         if (threadIdx.x == 0) carry_s = ctx_compose(carry_s, total);
         __syncthreads();
     }
+    if (threadIdx.x == 0 && total_fn) *total_fn = carry_s;   // composed function of the whole byte range (the shard carry)
 }
 
 // ---- one token ----------------------------------------------------------------------------------
@@ -457,16 +459,25 @@ __global__ __launch_bounds__(LEX_THREADS) void k_lex_emit(const uint8_t* __restr
 }
 
 // ---- token-level passes ----------------------------------------------------------------------
-__device__ __forceinline__ bool tk_record_open(const opusfe_token* __restrict__ raw, uint32_t k) {
+// kind of the token `back` places before raw token k; tokens before raw[0] come from the shard carry `prev_kinds`
+// (byte j = kind of the (j+1)-th token before the shard, T_EndOfFile = none; 0xFF..FF for a whole source)
+#define TK_NO_PREV 0x3B3B3B3B3B3B3B3Bull   /* T_EndOfFile in every byte */
+__device__ __forceinline__ uint8_t tk_kind_back(const opusfe_token* __restrict__ raw, int64_t k, int back, uint64_t prev_kinds) {
+    int64_t i = k - back;
+    if (i >= 0) return raw[i].kind;
+    int64_t j = -i - 1;
+    return j < 8 ? (uint8_t)(prev_kinds >> (8 * j)) : (uint8_t)T_EndOfFile;
+}
+__device__ __forceinline__ bool tk_record_open(const opusfe_token* __restrict__ raw, int64_t k, uint64_t prev_kinds) {
     // `{` that raises ignore_dents: `record {` (parse.rs:925-928) or `record <name> {` (parse.rs:1047-1054),
     // where <name> may be the two-token form `operator X` (parse.rs:776).
-    if (k >= 1 && raw[k - 1].kind == T_Record) return true;
-    if (k >= 2 && raw[k - 1].kind == T_Identifier && raw[k - 2].kind == T_Record) return true;
-    if (k >= 3 && raw[k - 2].kind == T_Operator && raw[k - 3].kind == T_Record) return true;
+    if (tk_kind_back(raw, k, 1, prev_kinds) == T_Record) return true;
+    if (tk_kind_back(raw, k, 1, prev_kinds) == T_Identifier && tk_kind_back(raw, k, 2, prev_kinds) == T_Record) return true;
+    if (tk_kind_back(raw, k, 2, prev_kinds) == T_Operator && tk_kind_back(raw, k, 3, prev_kinds) == T_Record) return true;
     return false;
 }
 
-__global__ void k_tok_delta(const opusfe_token* __restrict__ raw, uint32_t T, int32_t* __restrict__ delta, int force_dents) {
+__global__ void k_tok_delta(const opusfe_token* __restrict__ raw, uint32_t T, int32_t* __restrict__ delta, int force_dents, uint64_t prev_kinds) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= T) return;
     int32_t d = 0;
@@ -474,11 +485,12 @@ __global__ void k_tok_delta(const opusfe_token* __restrict__ raw, uint32_t T, in
         uint8_t kd = raw[k].kind;
         if (kd == T_LeftParenthesis) d = 1;
         else if (kd == T_RightParenthesis) d = -1;
-        else if (kd == T_LeftBrace) d = tk_record_open(raw, k) ? 1 : 0;
+        else if (kd == T_LeftBrace) d = tk_record_open(raw, k, prev_kinds) ? 1 : 0;
         else if (kd == T_RightBrace) {
             // `{}` / `{N}` array forms never touch ignore_dents (parse.rs:943-958)
-            bool array_close = (k >= 1 && raw[k - 1].kind == T_LeftBrace && !tk_record_open(raw, k - 1))
-                            || (k >= 2 && raw[k - 1].kind == T_Integer && raw[k - 2].kind == T_LeftBrace && !tk_record_open(raw, k - 2));
+            bool array_close = (tk_kind_back(raw, k, 1, prev_kinds) == T_LeftBrace && !tk_record_open(raw, (int64_t)k - 1, prev_kinds))
+                            || (tk_kind_back(raw, k, 1, prev_kinds) == T_Integer && tk_kind_back(raw, k, 2, prev_kinds) == T_LeftBrace
+                                && !tk_record_open(raw, (int64_t)k - 2, prev_kinds));
             d = array_close ? 0 : -1;
         }
     }
@@ -488,10 +500,10 @@ __global__ void k_tok_delta(const opusfe_token* __restrict__ raw, uint32_t T, in
 // For gap k (before raw token k; k == T is the gap before end of file): value | 1<<31 when the gap
 // is dent-sensitive and crosses a line (or is the very first gap / the EOF gap).
 __global__ void k_gap(const uint8_t* __restrict__ src, uint32_t n, const opusfe_token* __restrict__ raw, uint32_t T,
-                      const int32_t* __restrict__ depth_incl, uint32_t* __restrict__ gapval) {
+                      const int32_t* __restrict__ depth_incl, uint32_t* __restrict__ gapval, int32_t depth_in) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k > T) return;
-    bool sens = (k == 0) || depth_incl[k - 1] == 0;
+    bool sens = (k == 0 ? depth_in : depth_incl[k - 1] + depth_in) == 0;
     uint32_t out = 0;
     if (sens) {
         if (k == T) out = 0x80000000u;                       // EOF: -(indent) (parse.rs:461-464)
@@ -546,8 +558,27 @@ __global__ void k_final(const opusfe_token* __restrict__ raw, uint32_t T, uint32
         uint8_t kd = raw[k].kind;
         if (k == 0) flag = 1;
         else if (d < 0 && (g & 0x7FFFFFFFu) == 0 && kd != T_Else && kd != T_Error) flag = 1;
+        // `extern`, `type`, `const`, `import`, `library` occur nowhere in the grammar except as the first token of a
+        // definition (parse.rs:1262-1322): wherever one stands, a parser that is not between definitions fails ON it, so it
+        // may always open a segment (splits long runs of unindented declarations, e.g. the header blocks of shard.py)
+        else if (kd == T_Extern || kd == T_Type || kd == T_Const || kd == T_Import || kd == T_Library) flag = 1;
     }
     seg_flag[k] = flag;
+}
+
+// Shard cut search (multi-GPU): byte position of the first raw token that starts a top-level segment by
+// evidence found INSIDE the shard — its gap crosses a line in dent-sensitive mode with no leading TAB, and the previous
+// dent-sensitive line crossing of this shard had some (the dedent to column 0 that closes every open block).
+__global__ void k_shard_first_segment(const opusfe_token* __restrict__ raw, uint32_t T, const uint32_t* __restrict__ gapval,
+                                      const uint32_t* __restrict__ prev_excl, uint32_t* __restrict__ out_pos) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= T) return;
+    uint32_t g = gapval[k], p = prev_excl[k];
+    if (!(g >> 31) || (g & 0x7FFFFFFFu) != 0) return;
+    if (!(p >> 31) || (p & 0x7FFFFFFFu) == 0) return;
+    uint8_t kd = raw[k].kind;
+    if (kd == T_Else || kd == T_Error) return;
+    atomicMin(out_pos, raw[k].low);
 }
 
 // seg_start[id] = index in the final token stream where segment id starts

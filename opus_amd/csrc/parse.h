@@ -695,6 +695,33 @@ __global__ void k_count_newlines(const uint8_t* __restrict__ src, uint32_t n, ui
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
 }
 
+// ---- definition headers (multi-GPU IR generation: what another rank must know about this shard's definitions) ----
+// Function -> "extern " + signature text; Extern / Type / Variable / Constant -> their own text; each followed by '\n'.
+__device__ __forceinline__ uint32_t hdr_len(const opusfe_node& d) {
+    if (d.kind == D_Import || d.kind == D_Library) return 0;
+    return (d.high - d.low) + 1u + (d.kind == D_Function ? 7u : 0u);
+}
+__global__ void k_hdr_len(const opusfe_node* __restrict__ nodes, const uint32_t* __restrict__ def_nodes, uint32_t n_defs, uint32_t* __restrict__ len) {
+    uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d < n_defs) len[d] = hdr_len(nodes[def_nodes[d]]);
+}
+__global__ __launch_bounds__(256) void k_hdr_copy(const uint8_t* __restrict__ src, const opusfe_node* __restrict__ nodes, const uint32_t* __restrict__ def_nodes,
+                                                   uint32_t n_defs, const uint32_t* __restrict__ off, uint8_t* __restrict__ out) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t d = wave; d < n_defs; d += nwaves) {
+        const opusfe_node n = nodes[def_nodes[d]];
+        const uint32_t total = hdr_len(n);
+        if (total == 0) continue;
+        uint8_t* o = out + off[d];
+        uint32_t pre = 0;
+        if (n.kind == D_Function) { const char E[8] = "extern "; if (lane < 7) o[lane] = (uint8_t)E[lane]; pre = 7; }
+        const uint32_t body = n.high - n.low;
+        for (uint32_t j = lane; j < body; j += 64) o[pre + j] = src[n.low + j];
+        if (lane == 0) o[pre + body] = '\n';
+    }
+}
+
 #ifndef OPUSFE_EMU
 // ---- host driver ------------------------------------------------------------------------------
 enum { WP_FIRST_ERR = 16, WP_LINES = 17, WP_TOTALS = 18 /* Cnt2 */ };

@@ -19,6 +19,7 @@ struct opusfe_unit {
     uint32_t* d_seg_info = nullptr;                            // per segment: node_base, node_count, first_def, def_count, err..., 8 words
     uint64_t n_nodes = 0, n_defs = 0, n_funcs = 0;
     uint32_t* d_def_nodes = nullptr;                           // definition index -> root node
+    uint8_t* d_headers = nullptr; uint64_t n_headers = 0;      // definition headers (opusfe_unit_headers)
     bool parsed = false;
     bool has_error = false; opusfe_error error{}; uint32_t err_seg = 0;
     uint32_t unsup_pos = 0xFFFFFFFFu;                          // first byte the reference cannot be followed on (lexer)

@@ -62,6 +62,13 @@ def lib():
             getattr(L, name).argtypes = [vp, vp, u64, i, C.POINTER(vp)]
         L.opusfe_parse_batch.argtypes = [vp, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(u64), i, C.POINTER(vp), C.POINTER(i)]
         L.opusfe_semantic_error_count.argtypes = [vp, C.POINTER(u64)]
+        u32 = C.c_uint32
+        L.opusfe_shard_ctx.argtypes = [vp, vp, u64, C.POINTER(u32)]
+        L.opusfe_shard_lex.argtypes = [vp, vp, u64, u32, C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]
+        L.opusfe_shard_net_depth.argtypes = [vp, u64, C.POINTER(C.c_int64)]
+        L.opusfe_shard_boundary.argtypes = [vp, C.c_int64, C.POINTER(u64)]
+        L.opusfe_shard_free.argtypes = [vp]
+        L.opusfe_unit_headers.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
         L.opusfe_lower.argtypes = [vp, vp]
         L.opusfe_unit_status.argtypes = [vp]
         L.opusfe_get_counts.argtypes = [vp, C.POINTER(Counts)]
@@ -136,6 +143,14 @@ class Unit:
         self.status = rc
         return rc
 
+    def headers_device(self):
+        """(device pointer, length) of the definition-header text other shards need (opusfe_unit_headers)."""
+        p, n = C.c_void_p(), C.c_uint64()
+        rc = lib().opusfe_unit_headers(self.handle, C.byref(p), C.byref(n))
+        if rc != OK:
+            raise OpusfeError(rc, self.ctx.message())
+        return p.value or 0, n.value
+
     def tokens(self):
         n = C.c_uint64()
         lib().opusfe_copy_tokens(self.handle, None, 0, C.byref(n))
@@ -203,6 +218,38 @@ class Context:
     def lex_device(self, d_ptr: int, length: int, force_dents=False):
         out = C.c_void_p()
         return self._finish(lib().opusfe_lex_device(self.handle, C.c_void_p(d_ptr), length, int(force_dents), C.byref(out)), out)
+
+    # ---- shard carries (one huge source over several GPUs) ----
+    def shard_ctx(self, d_ptr, length):
+        fn = C.c_uint32()
+        rc = lib().opusfe_shard_ctx(self.handle, C.c_void_p(d_ptr), length, C.byref(fn))
+        if rc != OK:
+            raise OpusfeError(rc, self.message())
+        return fn.value
+
+    def shard_lex(self, d_ptr, length, start_state):
+        h, n, tail = C.c_void_p(), C.c_uint64(), C.c_uint64()
+        rc = lib().opusfe_shard_lex(self.handle, C.c_void_p(d_ptr), length, start_state, C.byref(h), C.byref(n), C.byref(tail))
+        if rc != OK:
+            raise OpusfeError(rc, self.message())
+        return h, n.value, tail.value
+
+    def shard_net_depth(self, shard, prev_kinds):
+        net = C.c_int64()
+        rc = lib().opusfe_shard_net_depth(shard, prev_kinds, C.byref(net))
+        if rc != OK:
+            raise OpusfeError(rc, self.message())
+        return net.value
+
+    def shard_boundary(self, shard, depth_in):
+        pos = C.c_uint64()
+        rc = lib().opusfe_shard_boundary(shard, depth_in, C.byref(pos))
+        if rc != OK:
+            raise OpusfeError(rc, self.message())
+        return None if pos.value == 0xFFFFFFFFFFFFFFFF else pos.value
+
+    def shard_free(self, shard):
+        lib().opusfe_shard_free(shard)
 
     def set_profiling(self, on=True):
         lib().opusfe_set_profiling(self.handle, int(on))

@@ -37,3 +37,27 @@ def all_reduce_sum(value, dist):
     t = torch.tensor([value], dtype=torch.float64, device=_device(dist))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+def make_gather(dist, device):
+    """gather(name, [local_value]) -> list over all ranks, for python objects (all_gather_object) and 1-D uint8 tensors
+    of different lengths (sizes first, then one padded all_gather).  Works with backend "nccl" (RCCL) and "gloo"."""
+    world = dist.get_world_size()
+    on_cpu = dist.get_backend() != "nccl"
+
+    def gather(name, values):
+        v = values[0]
+        if not torch.is_tensor(v):
+            out = [None] * world
+            dist.all_gather_object(out, v)
+            return out
+        sizes = [None] * world
+        dist.all_gather_object(sizes, int(v.numel()))
+        cap = max(max(sizes), 1)
+        pad = torch.zeros(cap, dtype=torch.uint8, device="cpu" if on_cpu else device)
+        pad[:v.numel()] = v.cpu() if on_cpu else v
+        bufs = [torch.empty(cap, dtype=torch.uint8, device=pad.device) for _ in range(world)]
+        dist.all_gather(bufs, pad)
+        return [bufs[q][:sizes[q]].to(device) for q in range(world)]
+
+    return gather

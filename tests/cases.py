@@ -38,6 +38,8 @@ PARSE_CASES = [
     "f() null\n\tfor in x\n\t\ty\n", "f() null\n\tfor i x\n\t\ty\n", "f() null\n\tx = a.1\n", "f() null\n\tx = a:5\n",
     "f() null\n\tx = proc 5()\n", "f() null\n\tx = proc f[int32]\n", "f() null\n\tx = (a\n\t\t+ b)\n\ty = z\n",
     "f() null\n\tx = g(\na,\nb)\n\ty = 1\n", "var x @ @mut @ {} {} mut {3} (int32) null\n",
+    "f() null\n\tx = 1\n\textern g() null\n", "var a int32 extern g() null\ntype T = int32 const c int32 = 1\n", "f() null x\nextern g() null\n",
+    "f() null\n\tx = (1 +\nextern g() null\n", "f() null\n\tif a\n\t\tb\n\ttype T = int32\n", "var a int32 =\ntype T = int32\n", "import \"a\" library \"b\" extern f() null\n",
     "f() null\n\tx = 1 +\n", "f() null\n\tx = 1 + )\n", "f() null\n\tx = \"bad \\q esc\"\n", "f() null\n\tif a\n\t\tb\n\t\"bad \\q esc\" c\n\td\n",
 ]
 

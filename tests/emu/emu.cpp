@@ -91,10 +91,10 @@ void emu_lex(EmuUnit& E, int force_dents) {
     std::vector<int32_t> depth(G);
     std::vector<uint32_t> gapval(G), prev(G), cnt(G), out_off(G), seg_flag(G), seg_excl(G);
     if (T) {
-        emu_launch(k_tok_delta, grid_for(T, 256), 256, raw.data(), T, depth.data(), force_dents);
+        emu_launch(k_tok_delta, grid_for(T, 256), 256, raw.data(), T, depth.data(), force_dents, (uint64_t)TK_NO_PREV);
         for (uint32_t k = 1; k < T; k++) depth[k] += depth[k - 1];
     }
-    emu_launch(k_gap, grid_for(G, 256), 256, src, n, raw.data(), T, depth.data(), gapval.data());
+    emu_launch(k_gap, grid_for(G, 256), 256, src, n, raw.data(), T, depth.data(), gapval.data(), (int32_t)0);
     { uint32_t run = 0; for (uint64_t k = 0; k < G; k++) { prev[k] = run; run = OpLast()(run, gapval[k]); } }
     emu_launch(k_dent_count, grid_for(G, 256), 256, gapval.data(), prev.data(), T, cnt.data());
     uint32_t total = 0;

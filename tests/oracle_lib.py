@@ -41,6 +41,8 @@ def gen():
         _g = _ensure(GEN_SO, os.path.join(ROOT, "tools"))
         _g.opusgen_generate.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int]
         _g.opusgen_generate.restype = C.c_uint64
+        _g.opusgen_generate_range.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, C.c_int]
+        _g.opusgen_generate_range.restype = C.c_uint64
         _g.opusgen_generate_lines.argtypes = [C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64]
         _g.opusgen_generate_lines.restype = C.c_uint64
         _g.opusgen_inject.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64]
@@ -67,6 +69,15 @@ def generate(seed: int, nbytes: int, flags=0, block_bytes=0, threads=8) -> bytes
     buf = C.create_string_buffer(nbytes)
     n = gen().opusgen_generate(seed, nbytes, flags, block_bytes, buf, nbytes, threads)
     assert n == nbytes, "generator failed"
+    return buf.raw[:n]
+
+
+def generate_range(seed: int, first_block: int, n_blocks: int, block_bytes: int, flags=0, threads=8) -> bytes:
+    """blocks [first_block, first_block + n_blocks) of generate(seed, ..., block_bytes=block_bytes)"""
+    cap = n_blocks * block_bytes
+    buf = C.create_string_buffer(cap)
+    n = gen().opusgen_generate_range(seed, first_block, n_blocks, block_bytes, flags, buf, cap, threads)
+    assert n == cap, "generator failed"
     return buf.raw[:n]
 
 

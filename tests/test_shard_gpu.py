@@ -1,0 +1,79 @@
+"""GPU: one source sharded at ARBITRARY byte positions over W simulated ranks (the carry chain of opus_amd/shard.py run in
+one process on one GPU).  The concatenated per-rank IR must equal the oracle's IR of the whole source, and every rank's cut
+must be a real top-level segment start."""
+import pytest
+import torch
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+def run_sharded(fe, src: bytes, world: int, cuts=None):
+    from opus_amd import shard
+    n = len(src)
+    if cuts is None:
+        cuts = [n * r // world for r in range(world)] + [n]
+    whole = torch.frombuffer(bytearray(src), dtype=torch.uint8).cuda()
+    states = [shard.RankState(fe, whole[cuts[r]:cuts[r + 1]].clone(), r, world) for r in range(world)]
+
+    def gather(name, values):
+        return values            # all ranks live in this process
+
+    shard.plan(states, gather)
+    owned = b"".join(bytes(s.own.cpu().numpy()) for s in states)
+    assert owned == src, "the owned ranges must tile the source"
+    res = shard.compile_sharded(states, gather)
+    return states, res
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("seed,size", [(3, 600_000), (12, 250_000)])
+def test_sharded_ir_equals_whole_file_ir(fe, seed, size, world):
+    src = O.generate(seed, size)
+    states, res = run_sharded(fe, src, world)
+    assert all(r["status"] == 0 for r in res), [r["status"] for r in res]
+    got = "".join(r["unit"].dump_ir() for r in res)
+    want = O.dump(src, O.IR)
+    assert got == want
+    # every cut is a line start at column 0 that opens a definition
+    pos = 0
+    for s in states:
+        if s.own.numel() and pos > 0:
+            assert src[pos - 1:pos] == b"\n" and src[pos:pos + 1] not in (b"\t", b" ", b"\n", b";")
+        pos += s.own.numel()
+
+
+def test_cuts_inside_strings_comments_and_parentheses(fe):
+    body = ("f(a int32) int32\n\tvar s = \"line one\nfake() null\n\tnot code\n\"\n\tvar t = g(\na,\nb)\n\t; comment with \" quote\n"
+            "\treturn a\ng(a int32, b int32) int32\n\treturn a + b\n")
+    src = (body.replace("f(", "f0(") + "".join(body.replace("f(", f"f{i}(").replace("g(a int32, b", f"g{i}(a int32, b").replace("g(\n", f"g{i}(\n")
+                                               for i in range(1, 40))).encode()
+    src = ("g(a int32, b int32) int32\n\treturn a\n").encode() + b"".join(
+        (f"f{i}(a int32) int32\n\tvar s = \"line one\nfake() null\n\tnot code\n\"\n\tvar t = g(\na,\nb)\n\t; comment with \" quote\n\treturn a\n").encode()
+        for i in range(60))
+    assert O.dump(src, O.ERROR) == "Ok\n"
+    want = O.dump(src, O.IR)
+    for world in (2, 5):
+        for shift in (0, 7, 23, 41):
+            n = len(src)
+            cuts = [0] + [min(n, n * r // world + shift) for r in range(1, world)] + [n]
+            states, res = run_sharded(fe, src, world, cuts)
+            assert all(r["status"] == 0 for r in res)
+            assert "".join(r["unit"].dump_ir() for r in res) == want
+
+
+def test_syntax_error_is_reported_by_the_owning_rank(fe):
+    src = O.generate(5, 200_000)
+    bad = O.inject(src, 77, 0)
+    want = O.dump(bad, O.ERROR)
+    assert want != "Ok\n"
+    states, res = run_sharded(fe, bad, 4)
+    first = res[0]["first_bad_rank"]
+    assert first is not None
+    u = res[first]["unit"]
+    e = u.error()
+    offset = sum(s.own.numel() for s in states[:first])
+    kind, low = want.split()[0], int(want.split()[1])
+    assert u.dump_error().split()[0] == kind
+    assert e.low + offset == low

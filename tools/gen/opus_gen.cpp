@@ -543,6 +543,28 @@ uint64_t opusgen_generate(uint64_t seed, uint64_t target, uint32_t flags, uint64
     return target;
 }
 
+// Blocks [first_block, first_block + n_blocks) of the source opusgen_generate(seed, ...) would produce with the same
+// block size: lets every rank of a multi-GPU run materialise only ITS part of one huge logical source.
+uint64_t opusgen_generate_range(uint64_t seed, uint64_t first_block, uint64_t n_blocks, uint64_t block_bytes, uint32_t flags, char* out, uint64_t cap, int threads) {
+    if (block_bytes == 0) block_bytes = 64ull << 20;
+    if (cap < n_blocks * block_bytes) return 0;
+    if (threads < 1) threads = 1;
+    std::vector<std::thread> pool;
+    std::vector<int> ok(n_blocks, 1);
+    auto work = [&](int tid) {
+        for (uint64_t i = (uint64_t)tid; i < n_blocks; i += (uint64_t)threads) {
+            uint64_t b = first_block + i;
+            std::string s = generate_block(seed, (uint32_t)b, (size_t)block_bytes, b == 0, b == 0 && (flags & 1), 1000);
+            if (s.size() != block_bytes) { ok[i] = 0; continue; }
+            memcpy(out + i * block_bytes, s.data(), s.size());
+        }
+    };
+    if (threads == 1) work(0);
+    else { for (int t = 0; t < threads; t++) pool.emplace_back(work, t); for (auto& t : pool) t.join(); }
+    for (auto v : ok) if (!v) return 0;
+    return n_blocks * block_bytes;
+}
+
 // Generates at least `min_lines` lines cut at a definition boundary (C1).  Returns the length.
 uint64_t opusgen_generate_lines(uint64_t seed, uint64_t min_lines, char* out, uint64_t cap) {
     Gen g(seed * 0x9E3779B97F4A7C15ull + 0x1234567ull, "", true);
