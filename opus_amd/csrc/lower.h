@@ -63,7 +63,7 @@ struct LowerLds {
     LFrame frames[LDS_FRAMES];
     uint32_t vtype[LDS_VARS];
     uint32_t bbcnt[LDS_BBS], bblast[LDS_BBS];
-    uint32_t lname[LDS_LOCALS], lvar[LDS_LOCALS], lhash[LDS_LOCALS], lstack[LDS_LOCALS];
+    uint32_t lname[LDS_LOCALS], lvar[LDS_LOCALS], lhash[LDS_LOCALS], lstack[LDS_LOCALS], lshash[LDS_LOCALS];
     TypeRec types[LDS_TYPES];
     uint32_t match_stack[96];   // work list of TypeOps::types_match
 };
@@ -140,7 +140,8 @@ struct Lowerer {
     __device__ __forceinline__ TypeRec trec(uint32_t t) { return T().rec(t); }
 
     // ---- names (wave-cooperative byte compare: one memory round trip instead of one per character) ----
-    uint32_t lane;
+    // (the machine object is shared by the wave, so the lane id cannot be one of its fields)
+    __device__ __forceinline__ static uint32_t lane_of() { return threadIdx.x % UNIT_LANES; }
     __device__ bool neq(NameKey a, NameKey b) const {
         uint8_t sa = name_sym(S.tok, a), sb = name_sym(S.tok, b);
         if (sa != sb) return false;
@@ -154,7 +155,7 @@ struct Lowerer {
 #else
         const uint32_t len = uni(x.len), xl = uni(x.low), yl = uni(y.low);
         for (uint32_t base = 0; base < len; base += 64) {
-            uint32_t i = base + lane;
+            uint32_t i = base + lane_of();
             bool ne = i < len && S.src[xl + i] != S.src[yl + i];
             if (__ballot(ne)) return false;
         }
@@ -261,17 +262,37 @@ struct Lowerer {
     __device__ __forceinline__ uint32_t l_var(uint32_t j) const { return uni(j < LDS_LOCALS ? lds->lvar[j] : lvar[j]); }
     __device__ __forceinline__ void l_set_var(uint32_t j, uint32_t v) { if (j < LDS_LOCALS) lds->lvar[j] = v; else lvar[j] = v; }
     __device__ __forceinline__ uint32_t l_stack(uint32_t j) const { return uni(j < LDS_LOCALS ? lds->lstack[j] : lstack[j]); }
-    // the name hash is compared first (LDS); the bytes only on a hash match
+    // The LDS-resident part of the table is searched by all lanes at once (lane j looks at entry base + j; the newest
+    // match wins); a hash match is confirmed on the bytes.  Entries beyond LDS_LOCALS live in global memory.
     __device__ uint32_t local_find(NameKey k) const {
         LPROF(LP_LOCALFIND);
         const uint32_t h = name_hash(S.tok, k);
-        for (uint32_t j = nlocals; j > 0; j--) {
+        for (uint32_t j = nlocals; j > LDS_LOCALS; j--) {          // spilled entries (rare), newest first
             const uint32_t e = j - 1;
-            if (l_var(e) == OPUSFE_NONE) continue;
-            if (e < LDS_LOCALS && uni(lds->lhash[e]) != h) continue;
-            if (neq(k, key_tok(l_name(e)))) return e;
+            if (l_var(e) != OPUSFE_NONE && neq(k, key_tok(l_name(e)))) return e;
+        }
+        const uint32_t n = nlocals < LDS_LOCALS ? nlocals : (uint32_t)LDS_LOCALS;
+#ifdef OPUSFE_EMU
+        for (uint32_t j = n; j > 0; j--) {
+            const uint32_t e = j - 1;
+            if (lds->lvar[e] != OPUSFE_NONE && lds->lhash[e] == h && neq(k, key_tok(lds->lname[e]))) return e;
         }
         return OPUSFE_NONE;
+#else
+        for (uint32_t top = n; top > 0;) {
+            const uint32_t base = top > 64 ? top - 64 : 0;
+            const uint32_t e = base + lane_of();
+            const bool m = e < top && lds->lvar[e] != OPUSFE_NONE && lds->lhash[e] == h;
+            uint64_t mask = __ballot(m);
+            while (mask) {
+                const uint32_t hit = base + 63u - (uint32_t)__builtin_clzll(mask);
+                if (neq(k, key_tok(uni(lds->lname[hit])))) return hit;
+                mask &= ~(1ull << (hit - base));
+            }
+            top = base;
+        }
+        return OPUSFE_NONE;
+#endif
     }
     __device__ void local_set(uint32_t name_tok, uint32_t v) {
         uint32_t j = local_find(key_tok(name_tok));
@@ -282,12 +303,29 @@ struct Lowerer {
         nlocals++;
     }
     __device__ bool contains_local(uint32_t name_tok) const {
-        for (uint32_t j = 0; j < nstack; j++) if (neq(key_tok(name_tok), key_tok(l_stack(j)))) return true;
+        const NameKey k = key_tok(name_tok);
+        const uint32_t h = name_hash(S.tok, k);
+        for (uint32_t j = LDS_LOCALS; j < nstack; j++) if (neq(k, key_tok(l_stack(j)))) return true;
+        const uint32_t n = nstack < LDS_LOCALS ? nstack : (uint32_t)LDS_LOCALS;
+#ifdef OPUSFE_EMU
+        for (uint32_t j = 0; j < n; j++) if (lds->lshash[j] == h && neq(k, key_tok(lds->lstack[j]))) return true;
         return false;
+#else
+        for (uint32_t base = 0; base < n; base += 64) {
+            const uint32_t e = base + lane_of();
+            uint64_t mask = __ballot(e < n && lds->lshash[e] == h);
+            while (mask) {
+                const uint32_t hit = base + (uint32_t)__builtin_ctzll(mask);
+                if (neq(k, key_tok(uni(lds->lstack[hit])))) return true;
+                mask &= mask - 1;
+            }
+        }
+        return false;
+#endif
     }
     __device__ void stack_push(uint32_t name_tok) {
         if (nstack >= lcap) { internal(); return; }
-        if (nstack < LDS_LOCALS) lds->lstack[nstack] = name_tok; else lstack[nstack] = name_tok;
+        if (nstack < LDS_LOCALS) { lds->lstack[nstack] = name_tok; lds->lshash[nstack] = name_hash(S.tok, key_tok(name_tok)); } else lstack[nstack] = name_tok;
         nstack++;
     }
     __device__ void end_scope(uint32_t n) {
@@ -1150,7 +1188,6 @@ __global__ MACHINE_ATTR(OPUSFE_LOWER_WAVES) __launch_bounds__(64) void k_lower_f
     Lowerer& L = machine_block[threadIdx.x / UNIT_LANES];
 #endif
     L.lds = &lds_block[threadIdx.x / UNIT_LANES];
-    L.lane = lane;
     L.user_syms = *user_syms;
     L.S = S; L.fidx = fidx; L.F = S.funcs[fidx]; L.undefined_flag = undefined_flag;
     L.vars = B.vars + lower_base(CAP_VARS, dn, fidx); L.nvars = 0; L.vcap = (uint32_t)lower_cap(CAP_VARS, nn);

@@ -84,8 +84,13 @@ __host__ __device__ __forceinline__ uint8_t name_sym(const opusfe_token* tok, Na
 __host__ __device__ __forceinline__ uint32_t name_hash(const opusfe_token* tok, NameKey k) {
     uint8_t s = name_sym(tok, k);
     if (s == T_Identifier) return tok[k.tok].payload;
-    int n; const char* t = sym_text(s, &n);
-    return fnv1a(t, n);
+    switch (s) {   // FNV-1a of the symbol text, folded at compile time
+        case T_Plus: return fnv1a("+", 1); case T_Minus: return fnv1a("-", 1); case T_Asterisk: return fnv1a("*", 1); case T_Slash: return fnv1a("/", 1);
+        case T_Percent: return fnv1a("%", 1); case T_EqualsEquals: return fnv1a("=", 1); case T_LessThan: return fnv1a("<", 1);
+        case T_GreaterThan: return fnv1a(">", 1); case T_LessThanEquals: return fnv1a("<=", 2); case T_GreaterThanEquals: return fnv1a(">=", 2);
+        case T_Is: return fnv1a("is", 2); case T_Not: return fnv1a("not", 3); case T_For: return fnv1a("for", 3); case T_Continue: return fnv1a("continue", 8);
+        default: return fnv1a("", 0);
+    }
 }
 __host__ __device__ __forceinline__ bool name_eq(const uint8_t* src, const opusfe_token* tok, NameKey a, NameKey b) {
     uint8_t sa = name_sym(tok, a), sb = name_sym(tok, b);
