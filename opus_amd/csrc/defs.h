@@ -24,10 +24,14 @@
 #define MACHINE_ATTR(w) __attribute__((amdgpu_waves_per_eu(w, w)))
 #endif
 #endif
+// MACHINE_STATE: a register of a per-workgroup machine (parser, lowering): a static LDS variable on the GPU (one wave
+// per workgroup runs one machine); the host emulation runs the lanes one after the other, so a plain static does there.
 #ifdef OPUSFE_EMU
 #define UNIT_LANES 1u
+#define MACHINE_STATE inline static
 #else
 #define UNIT_LANES 64u
+#define MACHINE_STATE inline static __shared__
 #endif
 
 // parse.rs:5-67, same order as the reference's enum Token.

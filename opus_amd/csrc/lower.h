@@ -110,33 +110,36 @@ enum LState : uint8_t {
 enum { PF_DEREF = 4, PF_MUSTLV = 8 };                 // flags in LFrame.aux of a P frame (low 2 bits: PtrKind)
 enum { IDX_PTR = 0, IDX_ARR = 1, IDX_FN = 2 };
 
+// The machine's registers are static LDS variables (one machine per workgroup == one wave): every helper reaches
+// them with ds_read/ds_write at constant addresses.  As fields of an object they were reached through a generic
+// `this` pointer (flat loads, or scratch when the object was private) in every helper the compiler keeps out of line.
 struct Lowerer {
-    SemView S;
-    LowerLds* lds;
-    uint32_t fidx; FuncRec F;
+    MACHINE_STATE SemView S;
+    MACHINE_STATE LowerLds lds;
+    MACHINE_STATE uint32_t fidx; MACHINE_STATE FuncRec F;
     // sparse regions of this function
-    opusfe_variable* vars; uint32_t nvars, vcap;
-    opusfe_instr* instrs; uint32_t* ibb; uint32_t* irank; uint32_t ninstrs, icap;
-    uint32_t* bbcnt; uint32_t* bblast; uint32_t nbbs, bcap;
-    uint32_t tbase, ntypes, tcap;
-    uint32_t* cargs; uint32_t ncargs, ccap;
-    uint32_t* lname; uint32_t* lvar; uint32_t nlocals, lcap;
-    uint32_t* lstack; uint32_t nstack;
-    LFrame* frames; uint32_t sp, fcap;
-    SemErr* errs; uint32_t nerrs, ecap;
+    MACHINE_STATE opusfe_variable* vars; MACHINE_STATE uint32_t nvars, vcap;
+    MACHINE_STATE opusfe_instr* instrs; MACHINE_STATE uint32_t* ibb; MACHINE_STATE uint32_t* irank; MACHINE_STATE uint32_t ninstrs, icap;
+    MACHINE_STATE uint32_t* bbcnt; MACHINE_STATE uint32_t* bblast; MACHINE_STATE uint32_t nbbs, bcap;
+    MACHINE_STATE uint32_t tbase, ntypes, tcap;
+    MACHINE_STATE uint32_t* cargs; MACHINE_STATE uint32_t ncargs, ccap;
+    MACHINE_STATE uint32_t* lname; MACHINE_STATE uint32_t* lvar; MACHINE_STATE uint32_t nlocals, lcap;
+    MACHINE_STATE uint32_t* lstack; MACHINE_STATE uint32_t nstack;
+    MACHINE_STATE LFrame* frames; MACHINE_STATE uint32_t sp, fcap;
+    MACHINE_STATE SemErr* errs; MACHINE_STATE uint32_t nerrs, ecap;
     // generate_ir.rs:75-97 state
-    uint32_t bb_index, break_head, loop_begin;
-    uint32_t dev_status;
-    LFrame cur;
-    uint32_t rv; bool rl; bool rdiv;
+    MACHINE_STATE uint32_t bb_index, break_head, loop_begin;
+    MACHINE_STATE uint32_t dev_status;
+    MACHINE_STATE LFrame cur;
+    MACHINE_STATE uint32_t rv; MACHINE_STATE bool rl; MACHINE_STATE bool rdiv;
 #ifdef OPUSFE_LOWER_PROF
-    mutable uint64_t prof[LP_COUNT];
+    MACHINE_STATE uint64_t prof[LP_COUNT];
 #endif
 
     __device__ __forceinline__ void internal() { if (dev_status < DS_INTERNAL_CAPACITY) dev_status = DS_INTERNAL_CAPACITY; }
     __device__ __forceinline__ void unsupported() { if (dev_status < DS_UNSUPPORTED_SEMANTIC) dev_status = DS_UNSUPPORTED_SEMANTIC; }
     __device__ __forceinline__ opusfe_node N(uint32_t i) const { LPROF(LP_NODE); return uni(S.nodes[i]); }
-    __device__ __forceinline__ TypeOps T() { return TypeOps{S, &dev_status, lds->types, tbase, ntypes < LDS_TYPES ? ntypes : (uint32_t)LDS_TYPES, lds->match_stack}; }
+    __device__ __forceinline__ TypeOps T() { return TypeOps{S, &dev_status, lds.types, tbase, ntypes < LDS_TYPES ? ntypes : (uint32_t)LDS_TYPES, lds.match_stack}; }
     __device__ __forceinline__ TypeRec trec(uint32_t t) { return T().rec(t); }
 
     // ---- names (wave-cooperative byte compare: one memory round trip instead of one per character) ----
@@ -182,7 +185,7 @@ struct Lowerer {
         }
         return OPUSFE_NONE;
     }
-    uint64_t user_syms;   // bit per operator-symbol token kind that has user-defined overloads in this unit
+    MACHINE_STATE uint64_t user_syms;   // bit per operator-symbol token kind that has user-defined overloads in this unit
 
     // ---- spans / errors -------------------------------------------------------------------------
     __device__ void report(uint32_t kind, uint32_t low, uint32_t high) {
@@ -197,17 +200,17 @@ struct Lowerer {
         LPROF(LP_NEWVAR);
         if (nvars >= vcap) { internal(); return 0; }
         vars[nvars] = opusfe_variable{type_id, is_temporary ? 1u : 0u};
-        if (nvars < LDS_VARS) lds->vtype[nvars] = type_id;
+        if (nvars < LDS_VARS) lds.vtype[nvars] = type_id;
         return nvars++;
     }
-    __device__ __forceinline__ uint32_t vtype(uint32_t v) const { return v < nvars ? uni(v < LDS_VARS ? lds->vtype[v] : vars[v].type_id) : (uint32_t)TP_Error; }
-    __device__ __forceinline__ void set_vtype(uint32_t v, uint32_t t) { if (v < nvars) { vars[v].type_id = t; if (v < LDS_VARS) lds->vtype[v] = t; } }
+    __device__ __forceinline__ uint32_t vtype(uint32_t v) const { return v < nvars ? uni(v < LDS_VARS ? lds.vtype[v] : vars[v].type_id) : (uint32_t)TP_Error; }
+    __device__ __forceinline__ void set_vtype(uint32_t v, uint32_t t) { if (v < nvars) { vars[v].type_id = t; if (v < LDS_VARS) lds.vtype[v] = t; } }
     __device__ uint32_t push_to(uint32_t bb, const opusfe_instr& in) {
         LPROF(LP_PUSH);
         if (ninstrs >= icap || bb >= nbbs) { internal(); return 0; }
         uint32_t t = ninstrs++;
         uint32_t rank;
-        if (bb < LDS_BBS) { rank = lds->bbcnt[bb]; lds->bbcnt[bb] = rank + 1; lds->bblast[bb] = t; }
+        if (bb < LDS_BBS) { rank = lds.bbcnt[bb]; lds.bbcnt[bb] = rank + 1; lds.bblast[bb] = t; }
         else { rank = bbcnt[bb]; bbcnt[bb] = rank + 1; bblast[bb] = t; }
         instrs[t] = in; ibb[t] = bb; irank[t] = uni(rank);
         return t;
@@ -218,14 +221,14 @@ struct Lowerer {
     }
     __device__ uint32_t new_bb() {
         if (nbbs >= bcap) { internal(); return 0; }
-        if (nbbs < LDS_BBS) { lds->bbcnt[nbbs] = 0; lds->bblast[nbbs] = OPUSFE_NONE; } else { bbcnt[nbbs] = 0; bblast[nbbs] = OPUSFE_NONE; }
+        if (nbbs < LDS_BBS) { lds.bbcnt[nbbs] = 0; lds.bblast[nbbs] = OPUSFE_NONE; } else { bbcnt[nbbs] = 0; bblast[nbbs] = OPUSFE_NONE; }
         return nbbs++;
     }
-    __device__ __forceinline__ uint32_t bb_last(uint32_t bb) const { return uni(bb < LDS_BBS ? lds->bblast[bb] : bblast[bb]); }
+    __device__ __forceinline__ uint32_t bb_last(uint32_t bb) const { return uni(bb < LDS_BBS ? lds.bblast[bb] : bblast[bb]); }
     __device__ uint32_t generate_error() { uint32_t v = new_var(TP_Error, true); push(ins(I_Error, v)); return v; }
     __device__ uint32_t new_type(const TypeRec& r) {
         if (ntypes >= tcap) { internal(); return TP_Error; }
-        if (ntypes < LDS_TYPES) lds->types[ntypes] = r;
+        if (ntypes < LDS_TYPES) lds.types[ntypes] = r;
         uint32_t id = tbase + ntypes++;
         S.types[id] = r;
         return id;
@@ -255,13 +258,13 @@ struct Lowerer {
         for (uint32_t k = y; k <= last; k++) if (undefined_flag[k]) report_node(SE_UndefinedType, k);
         return S.tid_of_node[y];
     }
-    const uint8_t* undefined_flag;
+    MACHINE_STATE const uint8_t* undefined_flag;
 
     // ---- scopes / locals (generate_ir.rs:176-185) -------------------------------------------------
-    __device__ __forceinline__ uint32_t l_name(uint32_t j) const { return uni(j < LDS_LOCALS ? lds->lname[j] : lname[j]); }
-    __device__ __forceinline__ uint32_t l_var(uint32_t j) const { return uni(j < LDS_LOCALS ? lds->lvar[j] : lvar[j]); }
-    __device__ __forceinline__ void l_set_var(uint32_t j, uint32_t v) { if (j < LDS_LOCALS) lds->lvar[j] = v; else lvar[j] = v; }
-    __device__ __forceinline__ uint32_t l_stack(uint32_t j) const { return uni(j < LDS_LOCALS ? lds->lstack[j] : lstack[j]); }
+    __device__ __forceinline__ uint32_t l_name(uint32_t j) const { return uni(j < LDS_LOCALS ? lds.lname[j] : lname[j]); }
+    __device__ __forceinline__ uint32_t l_var(uint32_t j) const { return uni(j < LDS_LOCALS ? lds.lvar[j] : lvar[j]); }
+    __device__ __forceinline__ void l_set_var(uint32_t j, uint32_t v) { if (j < LDS_LOCALS) lds.lvar[j] = v; else lvar[j] = v; }
+    __device__ __forceinline__ uint32_t l_stack(uint32_t j) const { return uni(j < LDS_LOCALS ? lds.lstack[j] : lstack[j]); }
     // The LDS-resident part of the table is searched by all lanes at once (lane j looks at entry base + j; the newest
     // match wins); a hash match is confirmed on the bytes.  Entries beyond LDS_LOCALS live in global memory.
     __device__ uint32_t local_find(NameKey k) const {
@@ -275,18 +278,18 @@ struct Lowerer {
 #ifdef OPUSFE_EMU
         for (uint32_t j = n; j > 0; j--) {
             const uint32_t e = j - 1;
-            if (lds->lvar[e] != OPUSFE_NONE && lds->lhash[e] == h && neq(k, key_tok(lds->lname[e]))) return e;
+            if (lds.lvar[e] != OPUSFE_NONE && lds.lhash[e] == h && neq(k, key_tok(lds.lname[e]))) return e;
         }
         return OPUSFE_NONE;
 #else
         for (uint32_t top = n; top > 0;) {
             const uint32_t base = top > 64 ? top - 64 : 0;
             const uint32_t e = base + lane_of();
-            const bool m = e < top && lds->lvar[e] != OPUSFE_NONE && lds->lhash[e] == h;
+            const bool m = e < top && lds.lvar[e] != OPUSFE_NONE && lds.lhash[e] == h;
             uint64_t mask = __ballot(m);
             while (mask) {
                 const uint32_t hit = base + 63u - (uint32_t)__builtin_clzll(mask);
-                if (neq(k, key_tok(uni(lds->lname[hit])))) return hit;
+                if (neq(k, key_tok(uni(lds.lname[hit])))) return hit;
                 mask &= ~(1ull << (hit - base));
             }
             top = base;
@@ -298,7 +301,7 @@ struct Lowerer {
         uint32_t j = local_find(key_tok(name_tok));
         if (j != OPUSFE_NONE) { l_set_var(j, v); return; }
         if (nlocals >= lcap) { internal(); return; }
-        if (nlocals < LDS_LOCALS) { lds->lname[nlocals] = name_tok; lds->lvar[nlocals] = v; lds->lhash[nlocals] = name_hash(S.tok, key_tok(name_tok)); }
+        if (nlocals < LDS_LOCALS) { lds.lname[nlocals] = name_tok; lds.lvar[nlocals] = v; lds.lhash[nlocals] = name_hash(S.tok, key_tok(name_tok)); }
         else { lname[nlocals] = name_tok; lvar[nlocals] = v; }
         nlocals++;
     }
@@ -308,15 +311,15 @@ struct Lowerer {
         for (uint32_t j = LDS_LOCALS; j < nstack; j++) if (neq(k, key_tok(l_stack(j)))) return true;
         const uint32_t n = nstack < LDS_LOCALS ? nstack : (uint32_t)LDS_LOCALS;
 #ifdef OPUSFE_EMU
-        for (uint32_t j = 0; j < n; j++) if (lds->lshash[j] == h && neq(k, key_tok(lds->lstack[j]))) return true;
+        for (uint32_t j = 0; j < n; j++) if (lds.lshash[j] == h && neq(k, key_tok(lds.lstack[j]))) return true;
         return false;
 #else
         for (uint32_t base = 0; base < n; base += 64) {
             const uint32_t e = base + lane_of();
-            uint64_t mask = __ballot(e < n && lds->lshash[e] == h);
+            uint64_t mask = __ballot(e < n && lds.lshash[e] == h);
             while (mask) {
                 const uint32_t hit = base + (uint32_t)__builtin_ctzll(mask);
-                if (neq(k, key_tok(uni(lds->lstack[hit])))) return true;
+                if (neq(k, key_tok(uni(lds.lstack[hit])))) return true;
                 mask &= mask - 1;
             }
         }
@@ -325,7 +328,7 @@ struct Lowerer {
     }
     __device__ void stack_push(uint32_t name_tok) {
         if (nstack >= lcap) { internal(); return; }
-        if (nstack < LDS_LOCALS) { lds->lstack[nstack] = name_tok; lds->lshash[nstack] = name_hash(S.tok, key_tok(name_tok)); } else lstack[nstack] = name_tok;
+        if (nstack < LDS_LOCALS) { lds.lstack[nstack] = name_tok; lds.lshash[nstack] = name_hash(S.tok, key_tok(name_tok)); } else lstack[nstack] = name_tok;
         nstack++;
     }
     __device__ void end_scope(uint32_t n) {
@@ -595,14 +598,14 @@ struct Lowerer {
         LPROF(LP_FRAMES);
         cur.st = resume;
         if (sp + 1 >= fcap) { internal(); return false; }
-        if (sp < LDS_FRAMES) lds->frames[sp] = cur; else frames[sp] = cur;
+        if (sp < LDS_FRAMES) lds.frames[sp] = cur; else frames[sp] = cur;
         sp++;
         cur.st = entry; cur.aux = aux; cur.cnt = 0; cur.node = node; cur.a = a; cur.b = cur.c = cur.d = cur.e = 0; cur.f = f;
         return true;
     }
-    __device__ __forceinline__ void retn() { LPROF(LP_FRAMES); if (sp == 0) { cur.st = LS_DONE; return; } --sp; cur = uni(sp < LDS_FRAMES ? lds->frames[sp] : frames[sp]); }
-    __device__ __forceinline__ void push_raw(const LFrame& fr) { if (sp + 1 >= fcap) { internal(); return; } if (sp < LDS_FRAMES) lds->frames[sp] = fr; else frames[sp] = fr; sp++; }
-    __device__ __forceinline__ LFrame pop_raw() { if (sp == 0) { internal(); return LFrame{}; } --sp; return uni(sp < LDS_FRAMES ? lds->frames[sp] : frames[sp]); }
+    __device__ __forceinline__ void retn() { LPROF(LP_FRAMES); if (sp == 0) { cur.st = LS_DONE; return; } --sp; cur = uni(sp < LDS_FRAMES ? lds.frames[sp] : frames[sp]); }
+    __device__ __forceinline__ void push_raw(const LFrame& fr) { if (sp + 1 >= fcap) { internal(); return; } if (sp < LDS_FRAMES) lds.frames[sp] = fr; else frames[sp] = fr; sp++; }
+    __device__ __forceinline__ LFrame pop_raw() { if (sp == 0) { internal(); return LFrame{}; } --sp; return uni(sp < LDS_FRAMES ? lds.frames[sp] : frames[sp]); }
 
     __device__ void p_finish(uint32_t var, bool lv) {
         if ((cur.aux & PF_MUSTLV) && !lv) { report_node(SE_InvalidLvalue, cur.f); var = generate_error(); }   // generate_pointer_from_expression :970-979
@@ -1178,16 +1181,7 @@ __global__ MACHINE_ATTR(OPUSFE_LOWER_WAVES) __launch_bounds__(64) void k_lower_f
     // externs simply leave their slot empty (n_instrs == 0, func == NONE)
     const uint32_t dn_end = d + 1 < n_defs ? def_nodes[d + 1] : n_nodes;
     const uint32_t nn = dn_end - dn;
-    __shared__ LowerLds lds_block[64 / UNIT_LANES];
-    // the machine's registers live in LDS too: helper functions the compiler keeps out of line receive `this`, and an
-    // object in scratch (private memory) would turn every field access into a global-memory round trip
-#ifdef OPUSFE_FLATTEN
-    Lowerer L;
-#else
-    __shared__ Lowerer machine_block[64 / UNIT_LANES];
-    Lowerer& L = machine_block[threadIdx.x / UNIT_LANES];
-#endif
-    L.lds = &lds_block[threadIdx.x / UNIT_LANES];
+    Lowerer L;      // no fields of its own: the state is the static LDS block above
     L.user_syms = *user_syms;
     L.S = S; L.fidx = fidx; L.F = S.funcs[fidx]; L.undefined_flag = undefined_flag;
     L.vars = B.vars + lower_base(CAP_VARS, dn, fidx); L.nvars = 0; L.vcap = (uint32_t)lower_cap(CAP_VARS, nn);
@@ -1215,7 +1209,7 @@ __global__ MACHINE_ATTR(OPUSFE_LOWER_WAVES) __launch_bounds__(64) void k_lower_f
     L.run(c);
 #endif
     // block sizes of the LDS-resident blocks go to the global table read by k_ir_bb_offsets
-    for (uint32_t b = lane; b < L.nbbs && b < LDS_BBS; b += UNIT_LANES) L.bbcnt[b] = L.lds->bbcnt[b];
+    for (uint32_t b = lane; b < L.nbbs && b < LDS_BBS; b += UNIT_LANES) L.bbcnt[b] = L.lds.bbcnt[b];
     if (lane != 0) return;
     FuncIr r{};
     r.def_node = dn; r.func = fidx; r.n_vars = L.nvars; r.n_instrs = L.ninstrs; r.n_bbs = L.nbbs; r.n_types = L.ntypes; r.n_cargs = L.ncargs;
