@@ -63,23 +63,24 @@ enum PState : uint8_t {
 };
 
 struct SegParser {
-    const opusfe_token* __restrict__ tok;
-    opusfe_node* __restrict__ nodes;     // sparse array
-    PFrame* __restrict__ stack;
-    uint64_t nbase, ncap, fcap;
-    uint32_t i;          // next token to consume
-    bool peeked;         // token i has been lexed by the reference at this point (peek_token)
-    uint32_t position;   // parse.rs `position`: end of the last consumed token
-    uint32_t nn;         // nodes created
-    uint32_t sp, max_sp;
-    PFrame cur;
-    uint32_t ret;
+    // registers of the machine: static LDS variables, one machine per workgroup (defs.h MACHINE_STATE)
+    MACHINE_STATE const opusfe_token* tok;
+    MACHINE_STATE opusfe_node* nodes;     // sparse array
+    MACHINE_STATE PFrame* stack;
+    MACHINE_STATE uint64_t nbase, ncap, fcap;
+    MACHINE_STATE uint32_t i;          // next token to consume
+    MACHINE_STATE bool peeked;         // token i has been lexed by the reference at this point (peek_token)
+    MACHINE_STATE uint32_t position;   // parse.rs `position`: end of the last consumed token
+    MACHINE_STATE uint32_t nn;         // nodes created
+    MACHINE_STATE uint32_t sp, max_sp;
+    MACHINE_STATE PFrame cur;
+    MACHINE_STATE uint32_t ret;
     // error
-    uint32_t err_kind, err_tok, err_low, err_len, err_expected;
-    uint32_t dev_status;
-    uint32_t unsup_pos;   // where the reference could no longer be followed (swallowed RESYNC error), else NONE
+    MACHINE_STATE uint32_t err_kind, err_tok, err_low, err_len, err_expected;
+    MACHINE_STATE uint32_t dev_status;
+    MACHINE_STATE uint32_t unsup_pos;   // where the reference could no longer be followed (swallowed RESYNC error), else NONE
 
-    uint32_t n_tokens;
+    MACHINE_STATE uint32_t n_tokens;
 
     // Every access is range checked: on malformed input (the part of a file after its first syntax error is
     // still parsed by other lanes) a wrong index becomes an internal-error status, never a GPU memory fault.
@@ -619,12 +620,7 @@ __global__ MACHINE_ATTR(OPUSFE_PARSE_WAVES) __launch_bounds__(64) void k_parse_s
     const uint32_t lane = threadIdx.x % UNIT_LANES;
     if (s >= n_segs) return;
     uint32_t tb = seg_start[s], te = (s + 1 < n_segs) ? seg_start[s + 1] : n_tokens;
-#ifdef OPUSFE_FLATTEN
-    SegParser P;
-#else
-    __shared__ SegParser machine_block[64 / UNIT_LANES];   // see lower.h: keeps the machine state out of scratch memory
-    SegParser& P = machine_block[threadIdx.x / UNIT_LANES];
-#endif
+    SegParser P;    // no fields of its own: the state is static LDS (see lower.h)
     P.tok = tok; P.nodes = nodes; P.n_tokens = n_tokens;
     P.nbase = seg_node_base(tb, s); P.ncap = seg_node_cap(tb, te);
     P.stack = frames + seg_frame_base(tb, s); P.fcap = seg_frame_cap(tb, te);
