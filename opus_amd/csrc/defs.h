@@ -34,6 +34,59 @@
 #define MACHINE_STATE inline static __shared__
 #endif
 
+// ---- explicit global-memory accesses ------------------------------------------------------------
+// A pointer that device code reads back from LDS (machine state) or from a by-value struct is a generic pointer, and
+// the compiler then emits FLAT instructions for it (they tie up the LDS counter as well as the memory counter).  These
+// helpers state that the pointee is in global memory: global_load / global_store, vectorised by the backend.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(OPUSFE_EMU)
+#define OPUSFE_GLOBAL __attribute__((address_space(1)))
+template <class T> __device__ __forceinline__ T gld(const T* p) {
+    if constexpr (sizeof(T) % 4 == 0 && sizeof(T) > 8) {
+        union U { T v; uint32_t w[sizeof(T) / 4]; __device__ U() {} } u;
+        const OPUSFE_GLOBAL uint32_t* g = (const OPUSFE_GLOBAL uint32_t*)p;
+#pragma unroll
+        for (unsigned i = 0; i < sizeof(T) / 4; i++) u.w[i] = g[i];
+        return u.v;
+    } else if constexpr (sizeof(T) == 8) {
+        union U { T v; uint64_t w; __device__ U() {} } u; u.w = *(const OPUSFE_GLOBAL uint64_t*)p; return u.v;
+    } else if constexpr (sizeof(T) == 4) {
+        union U { T v; uint32_t w; __device__ U() {} } u; u.w = *(const OPUSFE_GLOBAL uint32_t*)p; return u.v;
+    } else if constexpr (sizeof(T) == 2) {
+        union U { T v; uint16_t w; __device__ U() {} } u; u.w = *(const OPUSFE_GLOBAL uint16_t*)p; return u.v;
+    } else {
+        static_assert(sizeof(T) == 1, "gld: unsupported size");
+        union U { T v; uint8_t w; __device__ U() {} } u; u.w = *(const OPUSFE_GLOBAL uint8_t*)p; return u.v;
+    }
+}
+template <class T> __device__ __forceinline__ void gst(T* p, const T& v) {
+    if constexpr (sizeof(T) % 4 == 0 && sizeof(T) > 8) {
+        union U { T v; uint32_t w[sizeof(T) / 4]; __device__ U() {} } u; u.v = v;
+        OPUSFE_GLOBAL uint32_t* g = (OPUSFE_GLOBAL uint32_t*)p;
+#pragma unroll
+        for (unsigned i = 0; i < sizeof(T) / 4; i++) g[i] = u.w[i];
+    } else if constexpr (sizeof(T) == 8) {
+        union U { T v; uint64_t w; __device__ U() {} } u; u.v = v; *(OPUSFE_GLOBAL uint64_t*)p = u.w;
+    } else if constexpr (sizeof(T) == 4) {
+        union U { T v; uint32_t w; __device__ U() {} } u; u.v = v; *(OPUSFE_GLOBAL uint32_t*)p = u.w;
+    } else if constexpr (sizeof(T) == 2) {
+        union U { T v; uint16_t w; __device__ U() {} } u; u.v = v; *(OPUSFE_GLOBAL uint16_t*)p = u.w;
+    } else {
+        static_assert(sizeof(T) == 1, "gst: unsupported size");
+        union U { T v; uint8_t w; __device__ U() {} } u; u.v = v; *(OPUSFE_GLOBAL uint8_t*)p = u.w;
+    }
+}
+#else
+template <class T> __host__ __device__ __forceinline__ T gld(const T* p) { return *p; }
+template <class T> __host__ __device__ __forceinline__ void gst(T* p, const T& v) { *p = v; }
+#endif
+// read-only table in global memory: t[i] is a global load that returns the record by value
+template <class T> struct GTable {
+    const T* p;
+    GTable() = default;
+    __host__ __device__ GTable(const T* q) : p(q) {}
+    __host__ __device__ __forceinline__ T operator[](uint64_t i) const { return gld(p + i); }
+};
+
 // parse.rs:5-67, same order as the reference's enum Token.
 enum TokKind : uint8_t {
     T_LeftParenthesis, T_RightParenthesis, T_LeftSquareBracket, T_RightSquareBracket, T_LeftBrace, T_RightBrace,

@@ -139,7 +139,7 @@ struct Lowerer {
     __device__ __forceinline__ void internal() { if (dev_status < DS_INTERNAL_CAPACITY) dev_status = DS_INTERNAL_CAPACITY; }
     __device__ __forceinline__ void unsupported() { if (dev_status < DS_UNSUPPORTED_SEMANTIC) dev_status = DS_UNSUPPORTED_SEMANTIC; }
     __device__ __forceinline__ opusfe_node N(uint32_t i) const { LPROF(LP_NODE); return uni(S.nodes[i]); }
-    __device__ __forceinline__ TypeOps T() { return TypeOps{S, &dev_status, lds.types, tbase, ntypes < LDS_TYPES ? ntypes : (uint32_t)LDS_TYPES, lds.match_stack}; }
+    __device__ __forceinline__ static TypeOps<Lowerer> T() { return TypeOps<Lowerer>{}; }
     __device__ __forceinline__ TypeRec trec(uint32_t t) { return T().rec(t); }
 
     // ---- names (wave-cooperative byte compare: one memory round trip instead of one per character) ----
@@ -189,30 +189,30 @@ struct Lowerer {
 
     // ---- spans / errors -------------------------------------------------------------------------
     __device__ void report(uint32_t kind, uint32_t low, uint32_t high) {
-        if (nerrs < ecap) errs[nerrs] = SemErr{kind, low, high - low};
+        if (nerrs < ecap) gst(errs + nerrs, SemErr{kind, low, high - low});
         nerrs++;   // counting past the capacity is fine: has_errors is what matters, the list is clipped
     }
     __device__ void report_node(uint32_t kind, uint32_t node) { report(kind, N(node).low, N(node).high); }
-    __device__ void report_tok(uint32_t kind, uint32_t t) { report(kind, S.tok[t].low, S.tok[t].low + S.tok[t].len); }
+    __device__ void report_tok(uint32_t kind, uint32_t t) { const opusfe_token x = S.tok[t]; report(kind, x.low, x.low + x.len); }
 
     // ---- variables / instructions / blocks (generate_ir.rs:118-131) -------------------------------
     __device__ uint32_t new_var(uint32_t type_id, bool is_temporary) {
         LPROF(LP_NEWVAR);
         if (nvars >= vcap) { internal(); return 0; }
-        vars[nvars] = opusfe_variable{type_id, is_temporary ? 1u : 0u};
+        gst(vars + nvars, opusfe_variable{type_id, is_temporary ? 1u : 0u});
         if (nvars < LDS_VARS) lds.vtype[nvars] = type_id;
         return nvars++;
     }
-    __device__ __forceinline__ uint32_t vtype(uint32_t v) const { return v < nvars ? uni(v < LDS_VARS ? lds.vtype[v] : vars[v].type_id) : (uint32_t)TP_Error; }
-    __device__ __forceinline__ void set_vtype(uint32_t v, uint32_t t) { if (v < nvars) { vars[v].type_id = t; if (v < LDS_VARS) lds.vtype[v] = t; } }
+    __device__ __forceinline__ uint32_t vtype(uint32_t v) const { return v < nvars ? uni(v < LDS_VARS ? lds.vtype[v] : gld(&vars[v].type_id)) : (uint32_t)TP_Error; }
+    __device__ __forceinline__ void set_vtype(uint32_t v, uint32_t t) { if (v < nvars) { gst(&vars[v].type_id, t); if (v < LDS_VARS) lds.vtype[v] = t; } }
     __device__ uint32_t push_to(uint32_t bb, const opusfe_instr& in) {
         LPROF(LP_PUSH);
         if (ninstrs >= icap || bb >= nbbs) { internal(); return 0; }
         uint32_t t = ninstrs++;
         uint32_t rank;
         if (bb < LDS_BBS) { rank = lds.bbcnt[bb]; lds.bbcnt[bb] = rank + 1; lds.bblast[bb] = t; }
-        else { rank = bbcnt[bb]; bbcnt[bb] = rank + 1; bblast[bb] = t; }
-        instrs[t] = in; ibb[t] = bb; irank[t] = uni(rank);
+        else { rank = gld(bbcnt + bb); gst(bbcnt + bb, rank + 1); gst(bblast + bb, t); }
+        gst(instrs + t, in); gst(ibb + t, bb); gst(irank + t, uni(rank));
         return t;
     }
     __device__ __forceinline__ uint32_t push(const opusfe_instr& in) { return push_to(bb_index, in); }
@@ -224,13 +224,13 @@ struct Lowerer {
         if (nbbs < LDS_BBS) { lds.bbcnt[nbbs] = 0; lds.bblast[nbbs] = OPUSFE_NONE; } else { bbcnt[nbbs] = 0; bblast[nbbs] = OPUSFE_NONE; }
         return nbbs++;
     }
-    __device__ __forceinline__ uint32_t bb_last(uint32_t bb) const { return uni(bb < LDS_BBS ? lds.bblast[bb] : bblast[bb]); }
+    __device__ __forceinline__ uint32_t bb_last(uint32_t bb) const { return uni(bb < LDS_BBS ? lds.bblast[bb] : gld(bblast + bb)); }
     __device__ uint32_t generate_error() { uint32_t v = new_var(TP_Error, true); push(ins(I_Error, v)); return v; }
     __device__ uint32_t new_type(const TypeRec& r) {
         if (ntypes >= tcap) { internal(); return TP_Error; }
         if (ntypes < LDS_TYPES) lds.types[ntypes] = r;
         uint32_t id = tbase + ntypes++;
-        S.types[id] = r;
+        gst(S.types + id, r);
         return id;
     }
     __device__ uint32_t type_pointer(uint8_t pt, uint32_t sub) { TypeRec r{}; r.kind = TY_Pointer; r.ptr = pt; r.sub = sub; r.alias = OPUSFE_NONE; return new_type(r); }
@@ -255,16 +255,16 @@ struct Lowerer {
     __device__ uint32_t resolve_type(uint32_t y, const uint8_t* undefined_flag) {
         uint32_t last = y;
         while (N(last).nchild > 0) { uint32_t c = N(last).first_child; while (N(c).next != OPUSFE_NONE) c = N(c).next; last = c; }
-        for (uint32_t k = y; k <= last; k++) if (undefined_flag[k]) report_node(SE_UndefinedType, k);
+        for (uint32_t k = y; k <= last; k++) if (gld(undefined_flag + k)) report_node(SE_UndefinedType, k);
         return S.tid_of_node[y];
     }
     MACHINE_STATE const uint8_t* undefined_flag;
 
     // ---- scopes / locals (generate_ir.rs:176-185) -------------------------------------------------
-    __device__ __forceinline__ uint32_t l_name(uint32_t j) const { return uni(j < LDS_LOCALS ? lds.lname[j] : lname[j]); }
-    __device__ __forceinline__ uint32_t l_var(uint32_t j) const { return uni(j < LDS_LOCALS ? lds.lvar[j] : lvar[j]); }
-    __device__ __forceinline__ void l_set_var(uint32_t j, uint32_t v) { if (j < LDS_LOCALS) lds.lvar[j] = v; else lvar[j] = v; }
-    __device__ __forceinline__ uint32_t l_stack(uint32_t j) const { return uni(j < LDS_LOCALS ? lds.lstack[j] : lstack[j]); }
+    __device__ __forceinline__ uint32_t l_name(uint32_t j) const { return uni(j < LDS_LOCALS ? lds.lname[j] : gld(lname + j)); }
+    __device__ __forceinline__ uint32_t l_var(uint32_t j) const { return uni(j < LDS_LOCALS ? lds.lvar[j] : gld(lvar + j)); }
+    __device__ __forceinline__ void l_set_var(uint32_t j, uint32_t v) { if (j < LDS_LOCALS) lds.lvar[j] = v; else gst(lvar + j, v); }
+    __device__ __forceinline__ uint32_t l_stack(uint32_t j) const { return uni(j < LDS_LOCALS ? lds.lstack[j] : gld(lstack + j)); }
     // The LDS-resident part of the table is searched by all lanes at once (lane j looks at entry base + j; the newest
     // match wins); a hash match is confirmed on the bytes.  Entries beyond LDS_LOCALS live in global memory.
     __device__ uint32_t local_find(NameKey k) const {
@@ -302,7 +302,7 @@ struct Lowerer {
         if (j != OPUSFE_NONE) { l_set_var(j, v); return; }
         if (nlocals >= lcap) { internal(); return; }
         if (nlocals < LDS_LOCALS) { lds.lname[nlocals] = name_tok; lds.lvar[nlocals] = v; lds.lhash[nlocals] = name_hash(S.tok, key_tok(name_tok)); }
-        else { lname[nlocals] = name_tok; lvar[nlocals] = v; }
+        else { gst(lname + nlocals, name_tok); gst(lvar + nlocals, v); }
         nlocals++;
     }
     __device__ bool contains_local(uint32_t name_tok) const {
@@ -328,7 +328,7 @@ struct Lowerer {
     }
     __device__ void stack_push(uint32_t name_tok) {
         if (nstack >= lcap) { internal(); return; }
-        if (nstack < LDS_LOCALS) { lds.lstack[nstack] = name_tok; lds.lshash[nstack] = name_hash(S.tok, key_tok(name_tok)); } else lstack[nstack] = name_tok;
+        if (nstack < LDS_LOCALS) { lds.lstack[nstack] = name_tok; lds.lshash[nstack] = name_hash(S.tok, key_tok(name_tok)); } else gst(lstack + nstack, name_tok);
         nstack++;
     }
     __device__ void end_scope(uint32_t n) {
@@ -603,9 +603,9 @@ struct Lowerer {
         cur.st = entry; cur.aux = aux; cur.cnt = 0; cur.node = node; cur.a = a; cur.b = cur.c = cur.d = cur.e = 0; cur.f = f;
         return true;
     }
-    __device__ __forceinline__ void retn() { LPROF(LP_FRAMES); if (sp == 0) { cur.st = LS_DONE; return; } --sp; cur = uni(sp < LDS_FRAMES ? lds.frames[sp] : frames[sp]); }
-    __device__ __forceinline__ void push_raw(const LFrame& fr) { if (sp + 1 >= fcap) { internal(); return; } if (sp < LDS_FRAMES) lds.frames[sp] = fr; else frames[sp] = fr; sp++; }
-    __device__ __forceinline__ LFrame pop_raw() { if (sp == 0) { internal(); return LFrame{}; } --sp; return uni(sp < LDS_FRAMES ? lds.frames[sp] : frames[sp]); }
+    __device__ __forceinline__ void retn() { LPROF(LP_FRAMES); if (sp == 0) { cur.st = LS_DONE; return; } --sp; cur = uni(sp < LDS_FRAMES ? lds.frames[sp] : gld(frames + sp)); }
+    __device__ __forceinline__ void push_raw(const LFrame& fr) { if (sp + 1 >= fcap) { internal(); return; } if (sp < LDS_FRAMES) lds.frames[sp] = fr; else gst(frames + sp, fr); sp++; }
+    __device__ __forceinline__ LFrame pop_raw() { if (sp == 0) { internal(); return LFrame{}; } --sp; return uni(sp < LDS_FRAMES ? lds.frames[sp] : gld(frames + sp)); }
 
     __device__ void p_finish(uint32_t var, bool lv) {
         if ((cur.aux & PF_MUSTLV) && !lv) { report_node(SE_InvalidLvalue, cur.f); var = generate_error(); }   // generate_pointer_from_expression :970-979
@@ -745,7 +745,7 @@ struct Lowerer {
                 uint32_t inode = nd.sub ? N(nd.first_child).next : nd.first_child;
                 const uint32_t elow = N(inode).low, ehigh = N(inode).high;
                 uint32_t off = reserve_cargs(1);
-                cargs[off] = rv;
+                gst(cargs + off, rv);
                 Callee cl; uint32_t for_fn, ret_var;
                 if (call_variables(elow, ehigh, key_sym(T_For), cargs + off, 1, inode, true, &cl)) { for_fn = cl.fv; ret_var = cl.out; }
                 else { for_fn = generate_error(); ret_var = generate_error(); }
@@ -767,7 +767,7 @@ struct Lowerer {
                     local_set(nd.payload, iteration_variable);
                 }
                 uint32_t off2 = reserve_cargs(2);
-                cargs[off2] = iterator_variable; cargs[off2 + 1] = iteration_variable;
+                gst(cargs + off2, iterator_variable); gst(cargs + off2 + 1, iteration_variable);
                 uint32_t cont_fn, cond;
                 if (call_variables(elow, ehigh, key_sym(T_Continue), cargs + off2, 2, inode, true, &cl)) { cont_fn = cl.fv; cond = cl.out; }
                 else { cont_fn = generate_error(); cond = generate_error(); }
@@ -813,8 +813,8 @@ struct Lowerer {
                 push_to(else_end, ins(I_Jump, 0, 0, 0, merge));
                 for (uint32_t t = keep.b; t != OPUSFE_NONE;) {        // patch this loop's break placeholders (:357-359)
                     if (t >= ninstrs) { internal(); break; }
-                    uint32_t nx = instrs[t].a;
-                    instrs[t] = ins(I_Jump, 0, 0, 0, merge);
+                    uint32_t nx = gld(&instrs[t].a);
+                    gst(instrs + t, ins(I_Jump, 0, 0, 0, merge));
                     t = nx;
                 }
                 rdiv = div; retn(); goto next;
@@ -927,7 +927,7 @@ struct Lowerer {
                 Callee cl;
                 if (call_variables(nd.low, nd.high, key_sym(T_Not), argv, 1, right, true, &cl)) {
                     if (cl.builtin) push(ins(I_Not, cl.out, argv[0]));
-                    else { uint32_t off = reserve_cargs(1); cargs[off] = argv[0]; push(ins(I_Call, cl.out, cl.fv, 0, off, 0, 1)); }
+                    else { uint32_t off = reserve_cargs(1); gst(cargs + off, argv[0]); push(ins(I_Call, cl.out, cl.fv, 0, off, 0, 1)); }
                     rv = cl.out;
                 } else rv = generate_error();
                 retn(); goto next;
@@ -946,7 +946,7 @@ struct Lowerer {
                             case OP_LessThanEquals: op = I_LessThanEquals; break; default: op = I_GreaterThanEquals; break;
                         }
                         push(ins(op, cl.out, argv[0], argv[1]));
-                    } else { uint32_t off = reserve_cargs(2); cargs[off] = argv[0]; cargs[off + 1] = argv[1]; push(ins(I_Call, cl.out, cl.fv, 0, off, 0, 2)); }
+                    } else { uint32_t off = reserve_cargs(2); gst(cargs + off, argv[0]); gst(cargs + off + 1, argv[1]); push(ins(I_Call, cl.out, cl.fv, 0, off, 0, 2)); }
                     rv = cl.out;
                 } else rv = generate_error();
                 retn(); goto next;
@@ -968,11 +968,14 @@ struct Lowerer {
                     rv = out;
                 } else if (k == TY_GenericInteger) {
                     uint32_t t = bb_index < nbbs ? bb_last(bb_index) : OPUSFE_NONE;
-                    if (t != OPUSFE_NONE && instrs[t].opcode == I_Integer) {
-                        uint64_t val = (uint64_t)instrs[t].c | ((uint64_t)instrs[t].extra << 32);
+                    opusfe_instr li{};
+                    if (t != OPUSFE_NONE) li = gld(instrs + t);
+                    if (t != OPUSFE_NONE && li.opcode == I_Integer) {
+                        uint64_t val = (uint64_t)li.c | ((uint64_t)li.extra << 32);
                         val = 0 - val;
-                        instrs[t].c = (uint32_t)val; instrs[t].extra = (uint32_t)(val >> 32);
-                        rv = instrs[t].dst;
+                        li.c = (uint32_t)val; li.extra = (uint32_t)(val >> 32);
+                        gst(instrs + t, li);
+                        rv = li.dst;
                     } else { unsupported(); rv = generate_error(); }   // reference: unreachable!()
                 } else if (k == TY_Error) rv = generate_error();
                 else { report_node(SE_InvalidOperandType, cur.node); rv = generate_error(); }
@@ -1058,7 +1061,7 @@ struct Lowerer {
                     } else var = generate_error();
                     p_finish(var, false); goto next;
                 }
-            case LS_P_NC_ITEM: cargs[cur.a + cur.c] = rv; cur.c++; cur.b = N(cur.b).next; cur.st = LS_P_NC_LOOP; goto next;
+            case LS_P_NC_ITEM: gst(cargs + cur.a + cur.c, rv); cur.c++; cur.b = N(cur.b).next; cur.st = LS_P_NC_LOOP; goto next;
             case LS_P_COI_1: cur.a = rv; cur.b = rl ? 1 : 0; cur.c = N(nd.first_child).next; cur.st = LS_P_IDX_0; goto next;
             // ---- generate_ir_for_index (:895-967): a indexee, b is_lvalue | mode << 1, c argument cursor, d last value / pool offset, e count ----
             case LS_P_IDX_0: {
@@ -1116,7 +1119,7 @@ struct Lowerer {
                 p_finish(try_cast_pointer(v, pt, isl, ish), true); goto next;
             }
             case LS_P_IDX_ITEM:
-                if ((cur.b >> 1) == IDX_FN) cargs[cur.d + cur.e] = rv; else cur.d = rv;
+                if ((cur.b >> 1) == IDX_FN) gst(cargs + cur.d + cur.e, rv); else cur.d = rv;
                 cur.e++; cur.c = N(cur.c).next; cur.st = LS_P_IDX_LOOP; goto next;
             // ---- record literal (:1064-1078): a out, b field-init cursor, c value ----
             case LS_P_REC_LOOP: {
@@ -1139,7 +1142,7 @@ struct Lowerer {
         if (rdiv || returns_null) {
             uint32_t t = bb_last(bb_index);
             bool term = false;
-            if (t != OPUSFE_NONE) { uint16_t op = instrs[t].opcode; term = op == I_Return || op == I_Jump || op == I_Branch || op == I_Unreachable; }
+            if (t != OPUSFE_NONE) { uint16_t op = gld(instrs + t).opcode; term = op == I_Return || op == I_Jump || op == I_Branch || op == I_Unreachable; }
             if (!term) {
                 if (returns_null) { uint32_t v = new_var(TP_Null, true); push(ins(I_Null, v)); push(ins(I_Return, 0, v)); }
                 else push(ins(I_Unreachable));

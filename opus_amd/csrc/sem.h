@@ -44,16 +44,16 @@ enum { NK_FUNCTION = 0u, NK_GLOBAL = 1u, NK_TYPE = 2u };
 
 // Everything device code needs to look things up; passed by value to kernels.
 struct SemView {
-    const uint8_t* src;
-    const opusfe_token* tok;
-    const uint64_t* val64;
-    const opusfe_node* nodes;
-    const uint32_t* tid_of_node;     // Y_* nodes: resolved type id; D_Type: placeholder id
-    TypeRec* types;                  // global records [0, n_gtypes), then per-function local regions
-    const NameSlot* slots; uint32_t slot_mask;
-    const NameEntry* entries;
-    const FuncRec* funcs;
-    const GlobalRec* globals;
+    GTable<uint8_t> src;
+    GTable<opusfe_token> tok;
+    GTable<uint64_t> val64;
+    GTable<opusfe_node> nodes;
+    GTable<uint32_t> tid_of_node;    // Y_* nodes: resolved type id; D_Type: placeholder id
+    TypeRec* types;                  // global records [0, n_gtypes), then per-function local regions (gld / gst)
+    GTable<NameSlot> slots; uint32_t slot_mask;
+    GTable<NameEntry> entries;
+    GTable<FuncRec> funcs;
+    GTable<GlobalRec> globals;
     uint32_t n_gtypes;
 };
 
@@ -80,8 +80,9 @@ __host__ __device__ __forceinline__ uint8_t sym_of_op(uint8_t op) {
 }
 // A name is either an identifier token or the symbol of an operator-ish token kind.
 struct NameKey { uint32_t tok; uint8_t sym; };   // tok != NONE: identifier/operator token in the source; else symbol kind
-__host__ __device__ __forceinline__ uint8_t name_sym(const opusfe_token* tok, NameKey k) { return k.tok != OPUSFE_NONE ? (tok[k.tok].kind == T_Identifier ? (uint8_t)T_Identifier : tok[k.tok].kind) : k.sym; }
-__host__ __device__ __forceinline__ uint32_t name_hash(const opusfe_token* tok, NameKey k) {
+// (TokP / SrcP: a raw pointer or a GTable)
+template <class TokP> __host__ __device__ __forceinline__ uint8_t name_sym(TokP tok, NameKey k) { return k.tok != OPUSFE_NONE ? (uint8_t)tok[k.tok].kind : k.sym; }
+template <class TokP> __host__ __device__ __forceinline__ uint32_t name_hash(TokP tok, NameKey k) {
     uint8_t s = name_sym(tok, k);
     if (s == T_Identifier) return tok[k.tok].payload;
     switch (s) {   // FNV-1a of the symbol text, folded at compile time
@@ -92,18 +93,18 @@ __host__ __device__ __forceinline__ uint32_t name_hash(const opusfe_token* tok, 
         default: return fnv1a("", 0);
     }
 }
-__host__ __device__ __forceinline__ bool name_eq(const uint8_t* src, const opusfe_token* tok, NameKey a, NameKey b) {
+template <class SrcP, class TokP> __host__ __device__ __forceinline__ bool name_eq(SrcP src, TokP tok, NameKey a, NameKey b) {
     uint8_t sa = name_sym(tok, a), sb = name_sym(tok, b);
     if (sa != sb) return false;
     if (sa != T_Identifier) return true;
-    const opusfe_token& x = tok[a.tok]; const opusfe_token& y = tok[b.tok];
+    const opusfe_token x = tok[a.tok], y = tok[b.tok];
     if (x.len != y.len || x.payload != y.payload) return false;
     if (x.low == y.low) return true;
     for (uint32_t i = 0; i < x.len; i++) if (src[x.low + i] != src[y.low + i]) return false;
     return true;
 }
-__host__ __device__ __forceinline__ bool name_is(const uint8_t* src, const opusfe_token* tok, uint32_t t, const char* lit, uint32_t n) {
-    const opusfe_token& x = tok[t];
+template <class SrcP, class TokP> __host__ __device__ __forceinline__ bool name_is(SrcP src, TokP tok, uint32_t t, const char* lit, uint32_t n) {
+    const opusfe_token x = tok[t];
     if (x.kind != T_Identifier || x.len != n) return false;
     for (uint32_t i = 0; i < n; i++) if (src[x.low + i] != (uint8_t)lit[i]) return false;
     return true;
@@ -166,54 +167,53 @@ __host__ __device__ __forceinline__ bool kind_is_integral(uint8_t k) {   // comp
     return k <= TY_Natural64 || k == TY_Size || k == TY_Offset;
 }
 
-struct TypeOps {
-    const SemView& S;
-    uint32_t* dev_status;   // lane-local status word (DS_UNSUPPORTED_SEMANTIC when the reference would overflow its stack)
-    // records of the types the running function created itself, kept in LDS by the lowering kernel (else null)
-    const TypeRec* local_cache; uint32_t local_base, local_cached;
-    uint32_t* match_stack;   // 2 x 48 words of work list for types_match
+// M: the machine whose static LDS state the operations work on (lower.h Lowerer): M::S (tables), M::dev_status
+// (DS_UNSUPPORTED_SEMANTIC when the reference would overflow its stack), M::tbase / M::ntypes / M::lds.types (records
+// of the types the running function created itself, kept in LDS), M::lds.match_stack (2 x 48 words of work list).
+template <class M> struct TypeOps {
     // primitives need no memory access; the function's own types come from LDS; everything else from the table
-    __device__ __forceinline__ TypeRec rec(uint32_t t) const {
+    __device__ __forceinline__ static TypeRec rec(uint32_t t) {
         if (t < TP_COUNT) { TypeRec r{}; r.kind = prim_kind(t); r.alias = OPUSFE_NONE; return r; }
-        uint32_t k = t - local_base;
-        if (t >= local_base && k < local_cached) return local_cache[k];
-        return S.types[t];
+        constexpr uint32_t CACHE = sizeof(M::lds.types) / sizeof(TypeRec);
+        const uint32_t k = t - M::tbase, cached = M::ntypes < CACHE ? M::ntypes : CACHE;
+        if (t >= M::tbase && k < cached) return M::lds.types[k];
+        return gld(M::S.types + t);
     }
-    __device__ __forceinline__ uint8_t kind(uint32_t t) const { return t < TP_COUNT ? prim_kind(t) : rec(t).kind; }
-    __device__ __forceinline__ bool is_integral(uint32_t t) const { return kind_is_integral(kind(t)); }
+    __device__ __forceinline__ static uint8_t kind(uint32_t t) { return t < TP_COUNT ? prim_kind(t) : rec(t).kind; }
+    __device__ __forceinline__ static bool is_integral(uint32_t t) { return kind_is_integral(kind(t)); }
 
     // member lists of Record / Function types
-    __device__ uint32_t member_count(const TypeRec& r) const {
-        if (r.kind == TY_Record) return S.nodes[r.ref].nchild;
-        if (r.kind == TY_Function) return r.src == TS_FUNC ? S.funcs[r.ref].nargs : (uint32_t)S.nodes[r.ref].nchild - 1u;
+    __device__ static uint32_t member_count(const TypeRec& r) {
+        if (r.kind == TY_Record) return M::S.nodes[r.ref].nchild;
+        if (r.kind == TY_Function) return r.src == TS_FUNC ? M::S.funcs[r.ref].nargs : (uint32_t)M::S.nodes[r.ref].nchild - 1u;
         return 0;
     }
     // iterator over members: cursor is an AST node (X_NamedType for records and functions from definitions; Y_* for Proc types)
-    __device__ uint32_t member_first(const TypeRec& r) const {
-        if (r.kind == TY_Function && r.src == TS_FUNC) return S.funcs[r.ref].first_arg;
-        return S.nodes[r.ref].first_child;
+    __device__ static uint32_t member_first(const TypeRec& r) {
+        if (r.kind == TY_Function && r.src == TS_FUNC) return M::S.funcs[r.ref].first_arg;
+        return M::S.nodes[r.ref].first_child;
     }
-    __device__ uint32_t member_next(uint32_t cur) const { return S.nodes[cur].next; }
-    __device__ uint32_t member_type(uint32_t cur) const {
-        const opusfe_node& n = S.nodes[cur];
-        return n.kind == X_NamedType ? S.tid_of_node[n.first_child] : S.tid_of_node[cur];
+    __device__ static uint32_t member_next(uint32_t cur) { return M::S.nodes[cur].next; }
+    __device__ static uint32_t member_type(uint32_t cur) {
+        const opusfe_node& n = M::S.nodes[cur];
+        return n.kind == X_NamedType ? M::S.tid_of_node[n.first_child] : M::S.tid_of_node[cur];
     }
-    __device__ uint32_t member_name(uint32_t cur) const { return S.nodes[cur].payload; }
-    __device__ uint64_t array_size(const TypeRec& r) const {
-        const opusfe_token& t = S.tok[r.ref];
-        return (t.flags & OPUSFE_TF_INLINE) ? (uint64_t)t.payload : S.val64[t.payload];
+    __device__ static uint32_t member_name(uint32_t cur) { return M::S.nodes[cur].payload; }
+    __device__ static uint64_t array_size(const TypeRec& r) {
+        const opusfe_token& t = M::S.tok[r.ref];
+        return (t.flags & OPUSFE_TF_INLINE) ? (uint64_t)t.payload : M::S.val64[t.payload];
     }
 
     // compile.rs:698-751, recursion replaced by a bounded work list (the reference recurses without a
     // cycle check: on a self-referential record it overflows its stack; we report UNSUPPORTED instead)
-    __device__ bool types_match(uint32_t a0, uint32_t b0) const {
+    __device__ static bool types_match(uint32_t a0, uint32_t b0) {
         if (a0 < TP_COUNT && b0 < TP_COUNT) return a0 == b0;    // primitives: one id per kind
-        uint32_t* stack_a = match_stack; uint32_t* stack_b = match_stack + 48;
+        uint32_t* stack_a = M::lds.match_stack; uint32_t* stack_b = M::lds.match_stack + 48;
         int sp = 0;
         uint32_t a = a0, b = b0;
         uint32_t budget = 1u << 20;
         for (;;) {
-            if (--budget == 0) { *dev_status = DS_UNSUPPORTED_SEMANTIC; return false; }
+            if (--budget == 0) { M::dev_status = DS_UNSUPPORTED_SEMANTIC; return false; }
             bool descend = false;
             {
                 const TypeRec ra = rec(a), rb = rec(b);
@@ -226,8 +226,8 @@ struct TypeOps {
                         if (n != member_count(rb)) return false;
                         uint32_t ca = member_first(ra), cb = member_first(rb);
                         for (uint32_t i = 0; i < n; i++) {
-                            if (!name_eq(S.src, S.tok, key_tok(member_name(ca)), key_tok(member_name(cb)))) return false;
-                            if (sp >= 48) { *dev_status = DS_UNSUPPORTED_SEMANTIC; return false; }
+                            if (!name_eq(M::S.src, M::S.tok, key_tok(member_name(ca)), key_tok(member_name(cb)))) return false;
+                            if (sp >= 48) { M::dev_status = DS_UNSUPPORTED_SEMANTIC; return false; }
                             stack_a[sp] = member_type(ca); stack_b[sp] = member_type(cb); sp++;
                             ca = member_next(ca); cb = member_next(cb);
                         }
@@ -236,11 +236,11 @@ struct TypeOps {
                     case TY_Function: {
                         uint32_t n = member_count(ra);
                         if (n != member_count(rb)) return false;
-                        if (sp >= 48) { *dev_status = DS_UNSUPPORTED_SEMANTIC; return false; }
+                        if (sp >= 48) { M::dev_status = DS_UNSUPPORTED_SEMANTIC; return false; }
                         stack_a[sp] = ra.sub; stack_b[sp] = rb.sub; sp++;
                         uint32_t ca = member_first(ra), cb = member_first(rb);
                         for (uint32_t i = 0; i < n; i++) {
-                            if (sp >= 48) { *dev_status = DS_UNSUPPORTED_SEMANTIC; return false; }
+                            if (sp >= 48) { M::dev_status = DS_UNSUPPORTED_SEMANTIC; return false; }
                             stack_a[sp] = member_type(ca); stack_b[sp] = member_type(cb); sp++;
                             ca = member_next(ca); cb = member_next(cb);
                         }
@@ -255,14 +255,14 @@ struct TypeOps {
         }
     }
     // compile.rs:753-763
-    __device__ bool types_match_allow_generic(uint32_t a, uint32_t b) const {
+    __device__ static bool types_match_allow_generic(uint32_t a, uint32_t b) {
         uint8_t ka = kind(a), kb = kind(b);
         if ((ka == TY_GenericInteger && kind_is_integral(kb)) || (kb == TY_GenericInteger && kind_is_integral(ka))) return true;
         if (ka == TY_Generic || kb == TY_Generic) return true;
         return types_match(a, b);
     }
     // compile.rs:765-775
-    __device__ bool types_match_default_generic(uint32_t a, uint32_t b) const {
+    __device__ static bool types_match_default_generic(uint32_t a, uint32_t b) {
         uint8_t ka = kind(a), kb = kind(b);
         if ((ka == TY_GenericInteger && kb == TY_Integer32) || (ka == TY_Integer32 && kb == TY_GenericInteger)) return true;
         if (ka == TY_Generic || kb == TY_Generic) return false;
@@ -273,7 +273,7 @@ struct TypeOps {
         return from == to || (from == PT_Mutable && to == PT_Reference) || (from == PT_ArrayMutable && to == PT_Array);
     }
     // compile.rs:624-670; returns CastKind or -1
-    __device__ int can_autocast(uint32_t from, uint32_t to) const {
+    __device__ static int can_autocast(uint32_t from, uint32_t to) {
         if (from < TP_COUNT && to < TP_COUNT) {   // both primitive: no table access
             if (from == to) return CT_None;
             if (from == TP_Error || to == TP_Error) return CT_Error;
@@ -303,7 +303,7 @@ struct TypeOps {
         return -1;
     }
     // compile.rs:682-696
-    __device__ int can_cast(uint32_t from, uint32_t to) const {
+    __device__ static int can_cast(uint32_t from, uint32_t to) {
         int c = can_autocast(from, to);
         if (c >= 0) return c;
         const TypeRec t1 = rec(from), t2 = rec(to);
