@@ -75,16 +75,59 @@ template <class T> __device__ __forceinline__ void gst(T* p, const T& v) {
         union U { T v; uint8_t w; __device__ U() {} } u; u.v = v; *(OPUSFE_GLOBAL uint8_t*)p = u.w;
     }
 }
+#elif defined(OPUSFE_EMU_COUNT)   // tests/emu only: how many global accesses of each kind does a run make
+#include <map>
+#include <string>
+inline std::map<std::string, uint64_t>& emu_counts() { static std::map<std::string, uint64_t> m; return m; }
+template <class T> T gld(const T* p) { emu_counts()[__PRETTY_FUNCTION__]++; return *p; }
+template <class T> void gst(T* p, const T& v) { emu_counts()[__PRETTY_FUNCTION__]++; *p = v; }
 #else
 template <class T> __host__ __device__ __forceinline__ T gld(const T* p) { return *p; }
 template <class T> __host__ __device__ __forceinline__ void gst(T* p, const T& v) { *p = v; }
 #endif
+// Scalar loads.  The machines are wave-uniform, so what they read from the read-only tables (nodes, tokens, name table,
+// records written by EARLIER kernels) belongs in SGPRs: a load through a constant-address-space pointer with a
+// provably uniform address compiles to s_load_dwordxN (one instruction for a whole record, no VGPRs, no
+// v_readfirstlane afterwards).  Never use it for memory that the running kernel itself writes: the scalar cache is
+// not coherent with vector stores inside one kernel (it is invalidated between kernels).  Loads only: no scalar stores.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(OPUSFE_EMU)
+#define OPUSFE_CONST __attribute__((address_space(4)))
+template <class T> __device__ __forceinline__ T cld(const OPUSFE_CONST T* p) {
+    if constexpr (sizeof(T) % 4 == 0) {
+        union U { T v; uint32_t w[sizeof(T) / 4]; __device__ U() {} } u;
+        const OPUSFE_CONST uint32_t* g = (const OPUSFE_CONST uint32_t*)p;
+#pragma unroll
+        for (unsigned i = 0; i < sizeof(T) / 4; i++) u.w[i] = g[i];
+        return u.v;
+    } else {
+        static_assert(sizeof(T) == 1, "cld: unsupported size");
+        union U { T v; uint8_t w; __device__ U() {} } u; u.w = *(const OPUSFE_CONST uint8_t*)p; return u.v;
+    }
+}
+// read-only table read with scalar loads; the object (its base pointer) may live in LDS: pointer and index are made
+// provably uniform with v_readfirstlane.  (The kernel-argument segment pointer is no alternative for helpers that are
+// not inlined: llvm.amdgcn.kernarg.segment.ptr is null outside the kernel function itself.)
+template <class T> struct STable {
+    const T* p;
+    __device__ __forceinline__ const OPUSFE_CONST T* base() const {
+        const uint64_t a = (uint64_t)p;
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));
+        return (const OPUSFE_CONST T*)(((uint64_t)hi << 32) | lo);
+    }
+    __device__ __forceinline__ T operator[](uint32_t i) const { return cld(base() + (uint32_t)__builtin_amdgcn_readfirstlane((int)i)); }
+    __device__ __forceinline__ const T* ptr() const { return p; }     // generic pointer (vector accesses with a per-lane offset)
+};
+#elif !defined(OPUSFE_EMU)   // host pass of hipcc: declarations only have to parse
+template <class T> struct STable { const T* p; __device__ T operator[](uint32_t) const { return T{}; } __device__ const T* ptr() const { return p; } };
+#endif
+
 // read-only table in global memory: t[i] is a global load that returns the record by value
 template <class T> struct GTable {
     const T* p;
     GTable() = default;
     __host__ __device__ GTable(const T* q) : p(q) {}
     __host__ __device__ __forceinline__ T operator[](uint64_t i) const { return gld(p + i); }
+    __host__ __device__ __forceinline__ const T* ptr() const { return p; }
 };
 
 // parse.rs:5-67, same order as the reference's enum Token.

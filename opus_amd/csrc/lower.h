@@ -114,7 +114,22 @@ enum { IDX_PTR = 0, IDX_ARR = 1, IDX_FN = 2 };
 // them with ds_read/ds_write at constant addresses.  As fields of an object they were reached through a generic
 // `this` pointer (flat loads, or scratch when the object was private) in every helper the compiler keeps out of line.
 struct Lowerer {
+    // The tables: on the GPU `S.nodes[i]` etc. are scalar loads (defs.h STable); the host emulation keeps plain loads.
+#ifdef OPUSFE_EMU
     MACHINE_STATE SemView S;
+#else
+    struct View {
+        STable<uint8_t> src; STable<opusfe_token> tok; STable<uint64_t> val64; STable<opusfe_node> nodes; STable<uint32_t> tid_of_node;
+        STable<NameSlot> slots; STable<NameEntry> entries; STable<FuncRec> funcs; STable<GlobalRec> globals;
+        TypeRec* types; uint32_t slot_mask, n_gtypes;
+        __device__ void operator=(const SemView& v) {
+            src.p = v.src.p; tok.p = v.tok.p; val64.p = v.val64.p; nodes.p = v.nodes.p; tid_of_node.p = v.tid_of_node.p;
+            slots.p = v.slots.p; entries.p = v.entries.p; funcs.p = v.funcs.p; globals.p = v.globals.p;
+            types = v.types; slot_mask = v.slot_mask; n_gtypes = v.n_gtypes;
+        }
+    };
+    MACHINE_STATE View S;
+#endif
     MACHINE_STATE LowerLds lds;
     MACHINE_STATE uint32_t fidx; MACHINE_STATE FuncRec F;
     // sparse regions of this function
@@ -138,35 +153,38 @@ struct Lowerer {
 
     __device__ __forceinline__ void internal() { if (dev_status < DS_INTERNAL_CAPACITY) dev_status = DS_INTERNAL_CAPACITY; }
     __device__ __forceinline__ void unsupported() { if (dev_status < DS_UNSUPPORTED_SEMANTIC) dev_status = DS_UNSUPPORTED_SEMANTIC; }
-    __device__ __forceinline__ opusfe_node N(uint32_t i) const { LPROF(LP_NODE); return uni(S.nodes[i]); }
+    // (the machine state is shared by the wave, so the lane id cannot be part of it)
+    __device__ __forceinline__ static uint32_t lane_of() { return threadIdx.x % UNIT_LANES; }
+    // node / token i (wave-uniform index): scalar loads on the GPU
+    __device__ __forceinline__ opusfe_node N(uint32_t i) const { LPROF(LP_NODE); return S.nodes[i]; }
+    __device__ __forceinline__ opusfe_token TK(uint32_t i) const { return S.tok[i]; }
+    struct TokView { __device__ __forceinline__ opusfe_token operator[](uint32_t i) const { return Lowerer{}.TK(i); } };   // what the name helpers index
     __device__ __forceinline__ static TypeOps<Lowerer> T() { return TypeOps<Lowerer>{}; }
     __device__ __forceinline__ TypeRec trec(uint32_t t) { return T().rec(t); }
 
     // ---- names (wave-cooperative byte compare: one memory round trip instead of one per character) ----
-    // (the machine object is shared by the wave, so the lane id cannot be one of its fields)
-    __device__ __forceinline__ static uint32_t lane_of() { return threadIdx.x % UNIT_LANES; }
     __device__ bool neq(NameKey a, NameKey b) const {
-        uint8_t sa = name_sym(S.tok, a), sb = name_sym(S.tok, b);
+        uint8_t sa = name_sym(TokView{}, a), sb = name_sym(TokView{}, b);
         if (sa != sb) return false;
         if (sa != T_Identifier) return true;
-        const opusfe_token x = S.tok[a.tok], y = S.tok[b.tok];
+        const opusfe_token x = TK(a.tok), y = TK(b.tok);
         if (x.len != y.len || x.payload != y.payload) return false;
         if (x.low == y.low) return true;
 #ifdef OPUSFE_EMU
-        for (uint32_t i = 0; i < x.len; i++) if (S.src[x.low + i] != S.src[y.low + i]) return false;
+        for (uint32_t i = 0; i < x.len; i++) if (gld(S.src.ptr() + x.low + i) != gld(S.src.ptr() + y.low + i)) return false;
         return true;
 #else
         const uint32_t len = uni(x.len), xl = uni(x.low), yl = uni(y.low);
         for (uint32_t base = 0; base < len; base += 64) {
             uint32_t i = base + lane_of();
-            bool ne = i < len && S.src[xl + i] != S.src[yl + i];
+            bool ne = i < len && gld(S.src.ptr() + xl + i) != gld(S.src.ptr() + yl + i);
             if (__ballot(ne)) return false;
         }
         return true;
 #endif
     }
     __device__ uint32_t find_slot(NameKey k) const {
-        uint32_t h = name_hash(S.tok, k) & S.slot_mask;
+        uint32_t h = name_hash(TokView{}, k) & S.slot_mask;
         for (uint32_t probe = 0; probe <= S.slot_mask; probe++) {
             uint32_t rep = uni(S.slots[h].rep);
             if (rep == OPUSFE_NONE) return OPUSFE_NONE;
@@ -193,7 +211,7 @@ struct Lowerer {
         nerrs++;   // counting past the capacity is fine: has_errors is what matters, the list is clipped
     }
     __device__ void report_node(uint32_t kind, uint32_t node) { report(kind, N(node).low, N(node).high); }
-    __device__ void report_tok(uint32_t kind, uint32_t t) { const opusfe_token x = S.tok[t]; report(kind, x.low, x.low + x.len); }
+    __device__ void report_tok(uint32_t kind, uint32_t t) { const opusfe_token x = TK(t); report(kind, x.low, x.low + x.len); }
 
     // ---- variables / instructions / blocks (generate_ir.rs:118-131) -------------------------------
     __device__ uint32_t new_var(uint32_t type_id, bool is_temporary) {
@@ -205,7 +223,7 @@ struct Lowerer {
     }
     __device__ __forceinline__ uint32_t vtype(uint32_t v) const { return v < nvars ? uni(v < LDS_VARS ? lds.vtype[v] : gld(&vars[v].type_id)) : (uint32_t)TP_Error; }
     __device__ __forceinline__ void set_vtype(uint32_t v, uint32_t t) { if (v < nvars) { gst(&vars[v].type_id, t); if (v < LDS_VARS) lds.vtype[v] = t; } }
-    __device__ uint32_t push_to(uint32_t bb, const opusfe_instr& in) {
+    __device__ uint32_t push_to(uint32_t bb, opusfe_instr in) {   // by value: a reference would go through scratch memory
         LPROF(LP_PUSH);
         if (ninstrs >= icap || bb >= nbbs) { internal(); return 0; }
         uint32_t t = ninstrs++;
@@ -269,7 +287,7 @@ struct Lowerer {
     // match wins); a hash match is confirmed on the bytes.  Entries beyond LDS_LOCALS live in global memory.
     __device__ uint32_t local_find(NameKey k) const {
         LPROF(LP_LOCALFIND);
-        const uint32_t h = name_hash(S.tok, k);
+        const uint32_t h = name_hash(TokView{}, k);
         for (uint32_t j = nlocals; j > LDS_LOCALS; j--) {          // spilled entries (rare), newest first
             const uint32_t e = j - 1;
             if (l_var(e) != OPUSFE_NONE && neq(k, key_tok(l_name(e)))) return e;
@@ -301,13 +319,13 @@ struct Lowerer {
         uint32_t j = local_find(key_tok(name_tok));
         if (j != OPUSFE_NONE) { l_set_var(j, v); return; }
         if (nlocals >= lcap) { internal(); return; }
-        if (nlocals < LDS_LOCALS) { lds.lname[nlocals] = name_tok; lds.lvar[nlocals] = v; lds.lhash[nlocals] = name_hash(S.tok, key_tok(name_tok)); }
+        if (nlocals < LDS_LOCALS) { lds.lname[nlocals] = name_tok; lds.lvar[nlocals] = v; lds.lhash[nlocals] = name_hash(TokView{}, key_tok(name_tok)); }
         else { gst(lname + nlocals, name_tok); gst(lvar + nlocals, v); }
         nlocals++;
     }
     __device__ bool contains_local(uint32_t name_tok) const {
         const NameKey k = key_tok(name_tok);
-        const uint32_t h = name_hash(S.tok, k);
+        const uint32_t h = name_hash(TokView{}, k);
         for (uint32_t j = LDS_LOCALS; j < nstack; j++) if (neq(k, key_tok(l_stack(j)))) return true;
         const uint32_t n = nstack < LDS_LOCALS ? nstack : (uint32_t)LDS_LOCALS;
 #ifdef OPUSFE_EMU
@@ -328,7 +346,7 @@ struct Lowerer {
     }
     __device__ void stack_push(uint32_t name_tok) {
         if (nstack >= lcap) { internal(); return; }
-        if (nstack < LDS_LOCALS) { lds.lstack[nstack] = name_tok; lds.lshash[nstack] = name_hash(S.tok, key_tok(name_tok)); } else gst(lstack + nstack, name_tok);
+        if (nstack < LDS_LOCALS) { lds.lstack[nstack] = name_tok; lds.lshash[nstack] = name_hash(TokView{}, key_tok(name_tok)); } else gst(lstack + nstack, name_tok);
         nstack++;
     }
     __device__ void end_scope(uint32_t n) {
@@ -385,7 +403,7 @@ struct Lowerer {
 
     // Compiler::lookup_function (compile.rs:1083-1139) over builtins followed by the user overloads in definition order
     __device__ bool name_has_functions(NameKey name, uint32_t* slot_out) const {
-        uint8_t sym = name_sym(S.tok, name);
+        uint8_t sym = name_sym(TokView{}, name);
         uint32_t s = find_slot(name);
         *slot_out = s;
         if (sym != T_Identifier && builtin_count(sym) > 0) return true;
@@ -395,7 +413,7 @@ struct Lowerer {
         return false;
     }
     __device__ uint32_t candidate(NameKey name, uint32_t slot, uint32_t c, uint32_t* total) const {
-        uint8_t sym = name_sym(S.tok, name);
+        uint8_t sym = name_sym(TokView{}, name);
         uint32_t nb = sym != T_Identifier ? (uint32_t)builtin_count(sym) : 0u;
         uint32_t nu = slot != OPUSFE_NONE ? S.slots[slot].count : 0u;
         *total = nb + nu;
@@ -416,7 +434,7 @@ struct Lowerer {
         {   // builtin operator on primitive operands with no user overloads of that symbol: the general algorithm below
             // reduces to pure arithmetic (candidates have pairwise different parameter types, so nothing is "ignorable"
             // unless there is exactly one candidate)
-            const uint8_t sym = name_sym(S.tok, name);
+            const uint8_t sym = name_sym(TokView{}, name);
             if (sym != T_Identifier && !types_in && builtin_count(sym) > 0 && !((user_syms >> sym) & 1) && n == builtin_nargs(sym)) {
                 const uint32_t a0 = vtype(argv[0]), a1 = n > 1 ? vtype(argv[1]) : a0;
                 if (a0 < TP_COUNT && a1 < TP_COUNT && a0 != TP_Error && a1 != TP_Error) {
@@ -548,8 +566,8 @@ struct Lowerer {
         }
         if (r.kind == TY_String) {
             uint32_t idx, ft;
-            if (name_is(S.src, S.tok, field_tok, "data", 4)) { idx = 0; ft = type_pointer(PT_Array, TP_Natural8); }
-            else if (name_is(S.src, S.tok, field_tok, "length", 6)) { idx = 1; ft = TP_Size; }
+            if (name_is(S.src, TokView{}, field_tok, "data", 4)) { idx = 0; ft = type_pointer(PT_Array, TP_Natural8); }
+            else if (name_is(S.src, TokView{}, field_tok, "length", 6)) { idx = 1; ft = TP_Size; }
             else { report(SE_FieldDoesNotExist, sp_low, sp_high); return generate_error(); }
             uint32_t rvv = new_var(type_pointer(pt, ft), true);
             push(ins(I_BuiltinField, rvv, rec, 0, idx));
@@ -824,7 +842,7 @@ struct Lowerer {
             case LS_E:
                 switch (nd.kind) {
                     case E_Integer: {
-                        const opusfe_token t = S.tok[nd.payload];
+                        const opusfe_token t = TK(nd.payload);
                         uint32_t typ;
                         if (t.aux & 0x8000) {
                             uint32_t size = t.aux & 0xFF; bool sg = (t.aux & 0x100) != 0;
@@ -838,7 +856,7 @@ struct Lowerer {
                         rv = v; retn(); goto next;
                     }
                     case E_Float: {
-                        const opusfe_token t = S.tok[nd.payload];
+                        const opusfe_token t = TK(nd.payload);
                         uint64_t bits = S.val64[t.payload];
                         uint32_t v = new_var(t.aux == 32 ? TP_Float32 : TP_Float64, true);
                         push(ins(I_Float, v, 0, 0, (uint32_t)bits, (uint32_t)(bits >> 32)));
@@ -1071,7 +1089,7 @@ struct Lowerer {
                 if (il) { const TypeRec r = trec(it); if (r.kind == TY_Pointer) indexee_type = r.sub; else { if (r.kind != TY_Error) unsupported(); indexee_type = TP_Error; } }
                 const TypeRec r = trec(indexee_type);
                 uint32_t isl, ish;
-                if (nd.kind == E_NamedCall) { isl = S.tok[nd.payload].low; ish = isl + S.tok[nd.payload].len; } else { isl = N(nd.first_child).low; ish = N(nd.first_child).high; }
+                if (nd.kind == E_NamedCall) { const opusfe_token ct = TK(nd.payload); isl = ct.low; ish = isl + ct.len; } else { isl = N(nd.first_child).low; ish = N(nd.first_child).high; }
                 if (r.kind == TY_Pointer) { if (il) cur.a = dereference_pointer(cur.a); cur.b = (IDX_PTR << 1); }
                 else if (r.kind == TY_Array) {
                     if (!il) { report_node(SE_InvalidLvalue, cur.node); p_finish(generate_error(), true); goto next; }
@@ -1091,7 +1109,7 @@ struct Lowerer {
                 if (cur.c != OPUSFE_NONE) CALL_E(cur.c, mode == IDX_FN ? OPUSFE_NONE : (uint32_t)TP_Size, LS_P_IDX_ITEM);
                 const uint8_t pt = cur.aux & 3;
                 uint32_t isl, ish;
-                if (nd.kind == E_NamedCall) { isl = S.tok[nd.payload].low; ish = isl + S.tok[nd.payload].len; } else { isl = N(nd.first_child).low; ish = N(nd.first_child).high; }
+                if (nd.kind == E_NamedCall) { const opusfe_token ct = TK(nd.payload); isl = ct.low; ish = isl + ct.len; } else { isl = N(nd.first_child).low; ish = N(nd.first_child).high; }
                 if (mode == IDX_FN) {
                     const TypeRec r = trec(vtype(cur.a));
                     uint32_t out = new_var(r.sub, true);
@@ -1172,7 +1190,7 @@ __global__ void k_sem_user_syms(SemView S, uint64_t* __restrict__ out) {
 
 // one lane per function definition
 __global__ MACHINE_ATTR(OPUSFE_LOWER_WAVES) __launch_bounds__(64) void k_lower_functions(SemView S, LowerBuffers B, const uint8_t* __restrict__ undefined_flag, const uint32_t* __restrict__ def_nodes,
-                                                         uint32_t n_defs, uint32_t n_nodes, const DefCnt* __restrict__ def_excl, FuncIr* __restrict__ out,
+                                                         uint32_t n_defs, uint32_t n_nodes, uint32_t n_tokens, const DefCnt* __restrict__ def_excl, FuncIr* __restrict__ out,
                                                          uint32_t* __restrict__ status, uint64_t* __restrict__ prof_out, const uint64_t* __restrict__ user_syms) {
     const uint32_t d = blockIdx.x * (blockDim.x / UNIT_LANES) + threadIdx.x / UNIT_LANES;
     const uint32_t lane = threadIdx.x % UNIT_LANES;
@@ -1400,7 +1418,7 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
     LAUNCH(ctx, "sem_user_syms", k_sem_user_syms, 1, 64, S, user_syms);
     uint64_t* prof_buf = tmp.get<uint64_t>(LP_COUNT);
     HIP_TRY(hipMemsetAsync(prof_buf, 0, LP_COUNT * 8, st));
-    LAUNCH(ctx, "lower_functions", k_lower_functions, grid_for((uint64_t)n_defs * UNIT_LANES, 64), 64, S, B, undefined_flag, u->d_def_nodes, n_defs, n_nodes, def_excl, R->d_funcs,
+    LAUNCH(ctx, "lower_functions", k_lower_functions, grid_for((uint64_t)n_defs * UNIT_LANES, 64), 64, S, B, undefined_flag, u->d_def_nodes, n_defs, n_nodes, (uint32_t)u->n_tokens, def_excl, R->d_funcs,
            ctx->d_status + WL_STATUS, prof_buf, user_syms);
 #ifdef OPUSFE_LOWER_PROF
     {

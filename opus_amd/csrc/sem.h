@@ -144,24 +144,30 @@ __host__ __device__ __forceinline__ int builtin_count(uint8_t sym) {
         default: return 0;
     }
 }
+// overload idx of a symbol -> its (single) parameter type.  Arithmetic, not a table: a constant array in device
+// code is a load from memory.  Overloads 0..7 are Integer8..Natural64 == primitive ids 0..7; then
+//   arithmetic (12): Size Offset Float32 Float64;   comparison (14): Size Offset Bool Null Float32 Float64
 __host__ __device__ __forceinline__ uint32_t builtin_arg_type(uint8_t sym, int idx) {
-    const uint32_t ARITH[12] = {TP_Integer8, TP_Integer16, TP_Integer32, TP_Integer64, TP_Natural8, TP_Natural16, TP_Natural32, TP_Natural64,
-                                TP_Size, TP_Offset, TP_Float32, TP_Float64};
-    const uint32_t CMP[14] = {TP_Integer8, TP_Integer16, TP_Integer32, TP_Integer64, TP_Natural8, TP_Natural16, TP_Natural32, TP_Natural64,
-                              TP_Size, TP_Offset, TP_Bool, TP_Null, TP_Float32, TP_Float64};
-    int n = builtin_count(sym);
-    if (n == 12) return ARITH[idx];
-    if (n == 14) return CMP[idx];
+    static_assert(TP_Integer8 == 0 && TP_Natural64 == 7 && TP_Bool == 8 && TP_Null == 9 && TP_Size == 14 && TP_Offset == 15 && TP_Float32 == 16 && TP_Float64 == 17, "primitive ids");
+    const int n = builtin_count(sym);
+    const uint32_t i = (uint32_t)idx;
+    if (n == 12) return i < 8 ? i : i + 6;
+    if (n == 14) return i < 8 ? i : i < 10 ? i + 6 : i < 12 ? i - 2 : i + 4;
     return TP_Bool;
 }
 __host__ __device__ __forceinline__ uint32_t builtin_ret_type(uint8_t sym, int idx) { return builtin_count(sym) == 12 ? builtin_arg_type(sym, idx) : (uint32_t)TP_Bool; }
 __host__ __device__ __forceinline__ uint32_t builtin_nargs(uint8_t sym) { return sym == T_Not ? 1u : 2u; }
 
 // ---- type algebra -------------------------------------------------------------------------------
-__host__ __device__ __forceinline__ uint8_t prim_kind(uint32_t p) {
-    const uint8_t K[TP_COUNT] = {TY_Integer8, TY_Integer16, TY_Integer32, TY_Integer64, TY_Natural8, TY_Natural16, TY_Natural32, TY_Natural64,
-                                 TY_Bool, TY_Null, TY_Error, TY_GenericInteger, TY_Generic, TY_String, TY_Size, TY_Offset, TY_Float32, TY_Float64};
-    return K[p];
+__host__ __device__ __forceinline__ uint8_t prim_kind(uint32_t p) {   // a byte of a packed constant (no table in memory)
+    constexpr uint64_t K0 = (uint64_t)TY_Integer8 | (uint64_t)TY_Integer16 << 8 | (uint64_t)TY_Integer32 << 16 | (uint64_t)TY_Integer64 << 24 |
+                            (uint64_t)TY_Natural8 << 32 | (uint64_t)TY_Natural16 << 40 | (uint64_t)TY_Natural32 << 48 | (uint64_t)TY_Natural64 << 56;
+    constexpr uint64_t K1 = (uint64_t)TY_Bool | (uint64_t)TY_Null << 8 | (uint64_t)TY_Error << 16 | (uint64_t)TY_GenericInteger << 24 |
+                            (uint64_t)TY_Generic << 32 | (uint64_t)TY_String << 40 | (uint64_t)TY_Size << 48 | (uint64_t)TY_Offset << 56;
+    constexpr uint64_t K2 = (uint64_t)TY_Float32 | (uint64_t)TY_Float64 << 8;
+    static_assert(TP_Bool == 8 && TP_Error == 10 && TP_GenericInteger == 11 && TP_Generic == 12 && TP_String == 13 && TP_COUNT == 18, "primitive ids");
+    const uint64_t w = p < 8 ? K0 : p < 16 ? K1 : K2;
+    return (uint8_t)(w >> ((p & 7) * 8));
 }
 __host__ __device__ __forceinline__ bool kind_is_integral(uint8_t k) {   // compile.rs:172-180
     return k <= TY_Natural64 || k == TY_Size || k == TY_Offset;

@@ -218,7 +218,7 @@ void emu_lower(EmuUnit& E) {
     uint32_t lstatus[2] = {0, 0};
     uint64_t user_syms = 0;
     emu_launch(k_sem_user_syms, 1, 1, S, &user_syms);
-    emu_launch(k_lower_functions, grid_for(n_defs, 64), 64, S, B, (const uint8_t*)undefined_flag.data(), def_nodes, n_defs, n_nodes, (const DefCnt*)def_excl.data(),
+    emu_launch(k_lower_functions, grid_for(n_defs, 64), 64, S, B, (const uint8_t*)undefined_flag.data(), def_nodes, n_defs, n_nodes, (uint32_t)u.n_tokens, (const DefCnt*)def_excl.data(),
                R->funcs.data(), lstatus, (uint64_t*)nullptr, (const uint64_t*)&user_syms);
     std::vector<IrCnt> cnt(n_funcs);
     emu_launch(k_ir_counts, grid_for(n_funcs, 256), 256, (const FuncIr*)R->funcs.data(), n_funcs, cnt.data());
@@ -308,6 +308,9 @@ int main(int argc, char** argv) {
         fwrite(s, 1, n, stdout);
         emu_free(s);
     }
+#ifdef OPUSFE_EMU_COUNT
+    for (auto& kv : emu_counts()) fprintf(stderr, "%12llu %s\n", (unsigned long long)kv.second, kv.first.c_str());
+#endif
     return 0;
 }
 #endif

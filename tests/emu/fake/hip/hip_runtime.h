@@ -12,7 +12,11 @@
 #define __device__
 #define __host__
 #define __global__
+#ifdef EMU_NOINLINE
+#define __forceinline__ inline
+#else
 #define __forceinline__ inline __attribute__((always_inline))
+#endif
 #define __shared__ static
 #define __noinline__
 #define __launch_bounds__(...)
