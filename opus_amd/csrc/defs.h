@@ -34,6 +34,13 @@
 #define MACHINE_STATE inline static __shared__
 #endif
 
+#ifdef OPUSFE_EMU
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return v; }
+#else
+// value known to be identical in every lane -> SGPR (scalar branches, fewer VGPRs)
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+#endif
+
 // ---- explicit global-memory accesses ------------------------------------------------------------
 // A pointer that device code reads back from LDS (machine state) or from a by-value struct is a generic pointer, and
 // the compiler then emits FLAT instructions for it (they tie up the LDS counter as well as the memory counter).  These

@@ -68,12 +68,13 @@ struct LowerLds {
     uint32_t match_stack[96];   // work list of TypeOps::types_match
 };
 
-#ifdef OPUSFE_EMU
-__device__ __forceinline__ uint32_t uni(uint32_t v) { return v; }
-#else
-// value known to be identical in every lane -> SGPR (scalar branches, fewer VGPRs)
-__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-#endif
+using ::uni;
+__device__ __forceinline__ uint8_t uni(uint8_t v) { return (uint8_t)uni((uint32_t)v); }
+__device__ __forceinline__ uint16_t uni(uint16_t v) { return (uint16_t)uni((uint32_t)v); }
+__device__ __forceinline__ bool uni(bool v) { return uni((uint32_t)v) != 0; }
+__device__ __forceinline__ NameKey uni(NameKey k) { return NameKey{uni(k.tok), uni(k.sym)}; }
+// Arguments of a helper that is not inlined arrive in VGPRs and the compiler has to assume that they differ between
+// lanes (every `if` becomes a compare + exec-mask sequence).  They never do here: say so once at the top of the helper.
 __device__ __forceinline__ LFrame uni(const LFrame& f) {
     union { LFrame f; uint32_t w[8]; } a, b;
     a.f = f;
@@ -184,6 +185,7 @@ struct Lowerer {
 #endif
     }
     __device__ uint32_t find_slot(NameKey k) const {
+        k = uni(k);
         uint32_t h = name_hash(TokView{}, k) & S.slot_mask;
         for (uint32_t probe = 0; probe <= S.slot_mask; probe++) {
             uint32_t rep = uni(S.slots[h].rep);
@@ -194,6 +196,7 @@ struct Lowerer {
         return OPUSFE_NONE;
     }
     __device__ uint32_t last_entry(NameKey k, uint32_t kind) const {
+        k = uni(k); kind = uni(kind);
         uint32_t s = find_slot(k);
         if (s == OPUSFE_NONE) return OPUSFE_NONE;
         const NameSlot sl = S.slots[s];
@@ -207,14 +210,16 @@ struct Lowerer {
 
     // ---- spans / errors -------------------------------------------------------------------------
     __device__ void report(uint32_t kind, uint32_t low, uint32_t high) {
+        kind = uni(kind); low = uni(low); high = uni(high);
         if (nerrs < ecap) gst(errs + nerrs, SemErr{kind, low, high - low});
         nerrs++;   // counting past the capacity is fine: has_errors is what matters, the list is clipped
     }
-    __device__ void report_node(uint32_t kind, uint32_t node) { report(kind, N(node).low, N(node).high); }
-    __device__ void report_tok(uint32_t kind, uint32_t t) { const opusfe_token x = TK(t); report(kind, x.low, x.low + x.len); }
+    __device__ void report_node(uint32_t kind, uint32_t node) { kind = uni(kind); node = uni(node); report(kind, N(node).low, N(node).high); }
+    __device__ void report_tok(uint32_t kind, uint32_t t) { kind = uni(kind); t = uni(t); const opusfe_token x = TK(t); report(kind, x.low, x.low + x.len); }
 
     // ---- variables / instructions / blocks (generate_ir.rs:118-131) -------------------------------
     __device__ uint32_t new_var(uint32_t type_id, bool is_temporary) {
+        type_id = uni(type_id); is_temporary = uni(is_temporary);
         LPROF(LP_NEWVAR);
         if (nvars >= vcap) { internal(); return 0; }
         gst(vars + nvars, opusfe_variable{type_id, is_temporary ? 1u : 0u});
@@ -224,6 +229,7 @@ struct Lowerer {
     __device__ __forceinline__ uint32_t vtype(uint32_t v) const { return v < nvars ? uni(v < LDS_VARS ? lds.vtype[v] : gld(&vars[v].type_id)) : (uint32_t)TP_Error; }
     __device__ __forceinline__ void set_vtype(uint32_t v, uint32_t t) { if (v < nvars) { gst(&vars[v].type_id, t); if (v < LDS_VARS) lds.vtype[v] = t; } }
     __device__ uint32_t push_to(uint32_t bb, opusfe_instr in) {   // by value: a reference would go through scratch memory
+        bb = uni(bb);
         LPROF(LP_PUSH);
         if (ninstrs >= icap || bb >= nbbs) { internal(); return 0; }
         uint32_t t = ninstrs++;
@@ -251,26 +257,28 @@ struct Lowerer {
         gst(S.types + id, r);
         return id;
     }
-    __device__ uint32_t type_pointer(uint8_t pt, uint32_t sub) { TypeRec r{}; r.kind = TY_Pointer; r.ptr = pt; r.sub = sub; r.alias = OPUSFE_NONE; return new_type(r); }
-    __device__ uint32_t type_mut(uint32_t sub) { return type_pointer(PT_Mutable, sub); }
-    __device__ uint32_t reserve_cargs(uint32_t n) { if (ncargs + n > ccap) { internal(); return 0; } uint32_t o = ncargs; ncargs += n; return o; }
+    __device__ uint32_t type_pointer(uint8_t pt, uint32_t sub) { pt = uni(pt); sub = uni(sub); TypeRec r{}; r.kind = TY_Pointer; r.ptr = pt; r.sub = sub; r.alias = OPUSFE_NONE; return new_type(r); }
+    __device__ uint32_t type_mut(uint32_t sub) { sub = uni(sub); return type_pointer(PT_Mutable, sub); }
+    __device__ uint32_t reserve_cargs(uint32_t n) { n = uni(n); if (ncargs + n > ccap) { internal(); return 0; } uint32_t o = ncargs; ncargs += n; return o; }
 
     // ---- functions as values --------------------------------------------------------------------
     __device__ __forceinline__ bool fn_is_builtin(uint32_t f) const { return (f & FN_BUILTIN) != 0; }
-    __device__ uint32_t fn_nargs(uint32_t f) const { return fn_is_builtin(f) ? builtin_nargs((f >> 8) & 0xFF) : S.funcs[f].nargs; }
-    __device__ uint32_t fn_ret(uint32_t f) const { return fn_is_builtin(f) ? builtin_ret_type((f >> 8) & 0xFF, f & 0xFF) : S.funcs[f].ret; }
-    __device__ uint32_t fn_arg_cursor(uint32_t f) const { return fn_is_builtin(f) ? 0u : S.funcs[f].first_arg; }
+    __device__ uint32_t fn_nargs(uint32_t f) const { f = uni(f); return fn_is_builtin(f) ? builtin_nargs((f >> 8) & 0xFF) : S.funcs[f].nargs; }
+    __device__ uint32_t fn_ret(uint32_t f) const { f = uni(f); return fn_is_builtin(f) ? builtin_ret_type((f >> 8) & 0xFF, f & 0xFF) : S.funcs[f].ret; }
+    __device__ uint32_t fn_arg_cursor(uint32_t f) const { f = uni(f); return fn_is_builtin(f) ? 0u : S.funcs[f].first_arg; }
     __device__ uint32_t fn_arg_type(uint32_t f, uint32_t& cursor) const {   // returns the type and advances
+        f = uni(f);
         if (fn_is_builtin(f)) return builtin_arg_type((f >> 8) & 0xFF, f & 0xFF);
         uint32_t t = S.tid_of_node[N(cursor).first_child];
         cursor = N(cursor).next;
         return t;
     }
-    __device__ uint32_t type_function(uint32_t f) { TypeRec r{}; r.kind = TY_Function; r.src = TS_FUNC; r.ref = f; r.sub = S.funcs[f].ret; r.alias = OPUSFE_NONE; return new_type(r); }
+    __device__ uint32_t type_function(uint32_t f) { f = uni(f); TypeRec r{}; r.kind = TY_Function; r.src = TS_FUNC; r.ref = f; r.sub = S.funcs[f].ret; r.alias = OPUSFE_NONE; return new_type(r); }
 
     // resolve_type of a parse-tree type node (compile.rs:919-966): precomputed id; UndefinedType errors are raised
     // here, when the reference would resolve it, in source order (the subtree is a contiguous node range)
     __device__ uint32_t resolve_type(uint32_t y, const uint8_t* undefined_flag) {
+        y = uni(y);
         uint32_t last = y;
         while (N(last).nchild > 0) { uint32_t c = N(last).first_child; while (N(c).next != OPUSFE_NONE) c = N(c).next; last = c; }
         for (uint32_t k = y; k <= last; k++) if (gld(undefined_flag + k)) report_node(SE_UndefinedType, k);
@@ -286,6 +294,7 @@ struct Lowerer {
     // The LDS-resident part of the table is searched by all lanes at once (lane j looks at entry base + j; the newest
     // match wins); a hash match is confirmed on the bytes.  Entries beyond LDS_LOCALS live in global memory.
     __device__ uint32_t local_find(NameKey k) const {
+        k = uni(k);
         LPROF(LP_LOCALFIND);
         const uint32_t h = name_hash(TokView{}, k);
         for (uint32_t j = nlocals; j > LDS_LOCALS; j--) {          // spilled entries (rare), newest first
@@ -316,6 +325,7 @@ struct Lowerer {
 #endif
     }
     __device__ void local_set(uint32_t name_tok, uint32_t v) {
+        name_tok = uni(name_tok); v = uni(v);
         uint32_t j = local_find(key_tok(name_tok));
         if (j != OPUSFE_NONE) { l_set_var(j, v); return; }
         if (nlocals >= lcap) { internal(); return; }
@@ -324,6 +334,7 @@ struct Lowerer {
         nlocals++;
     }
     __device__ bool contains_local(uint32_t name_tok) const {
+        name_tok = uni(name_tok);
         const NameKey k = key_tok(name_tok);
         const uint32_t h = name_hash(TokView{}, k);
         for (uint32_t j = LDS_LOCALS; j < nstack; j++) if (neq(k, key_tok(l_stack(j)))) return true;
@@ -345,16 +356,19 @@ struct Lowerer {
 #endif
     }
     __device__ void stack_push(uint32_t name_tok) {
+        name_tok = uni(name_tok);
         if (nstack >= lcap) { internal(); return; }
         if (nstack < LDS_LOCALS) { lds.lstack[nstack] = name_tok; lds.lshash[nstack] = name_hash(TokView{}, key_tok(name_tok)); } else gst(lstack + nstack, name_tok);
         nstack++;
     }
     __device__ void end_scope(uint32_t n) {
+        n = uni(n);
         while (nstack > n) { uint32_t name = l_stack(--nstack); uint32_t j = local_find(key_tok(name)); if (j != OPUSFE_NONE) l_set_var(j, OPUSFE_NONE); }
     }
 
     // ---- generate_ir.rs:207-231 -------------------------------------------------------------------
     __device__ uint32_t autocast(uint32_t variable, uint32_t expected, uint32_t span_node) {
+        variable = uni(variable); expected = uni(expected); span_node = uni(span_node);
         LPROF(LP_AUTOCAST);
         uint32_t found = vtype(variable);
         if (T().types_match(found, expected)) return variable;
@@ -371,16 +385,18 @@ struct Lowerer {
     }
     // :235-242
     __device__ uint32_t get_lvalue_type(uint32_t v) {
+        v = uni(v);
         const TypeRec r = trec(vtype(v));
         if (r.kind == TY_Pointer) return r.sub;
         if (r.kind != TY_Error) unsupported();   // reference: unreachable!()
         return TP_Error;
     }
     // :495-503
-    __device__ uint32_t dereference_pointer(uint32_t p) { uint32_t v = new_var(get_lvalue_type(p), true); push(ins(I_Load, v, p)); return v; }
+    __device__ uint32_t dereference_pointer(uint32_t p) { p = uni(p); uint32_t v = new_var(get_lvalue_type(p), true); push(ins(I_Load, v, p)); return v; }
 
     // :808-855; `sp_low/sp_high` is the span for errors
     __device__ uint32_t try_cast_pointer(uint32_t v, uint8_t pt, uint32_t sp_low, uint32_t sp_high) {
+        v = uni(v); pt = uni(pt); sp_low = uni(sp_low); sp_high = uni(sp_high);
         LPROF(LP_TRYCAST);
         const TypeRec r = trec(vtype(v));
         if (r.kind == TY_Pointer) {
@@ -403,6 +419,7 @@ struct Lowerer {
 
     // Compiler::lookup_function (compile.rs:1083-1139) over builtins followed by the user overloads in definition order
     __device__ bool name_has_functions(NameKey name, uint32_t* slot_out) const {
+        name = uni(name);
         uint8_t sym = name_sym(TokView{}, name);
         uint32_t s = find_slot(name);
         *slot_out = s;
@@ -413,6 +430,7 @@ struct Lowerer {
         return false;
     }
     __device__ uint32_t candidate(NameKey name, uint32_t slot, uint32_t c, uint32_t* total) const {
+        name = uni(name); slot = uni(slot); c = uni(c);
         uint8_t sym = name_sym(TokView{}, name);
         uint32_t nb = sym != T_Identifier ? (uint32_t)builtin_count(sym) : 0u;
         uint32_t nu = slot != OPUSFE_NONE ? S.slots[slot].count : 0u;
@@ -423,6 +441,7 @@ struct Lowerer {
         return e.kind_index & 0x3FFFFFFFu;
     }
     __device__ bool candidate_ok(uint32_t f, const uint32_t* argv, const uint32_t* types_in, uint32_t n) {
+        f = uni(f); n = uni(n);
         if (fn_nargs(f) != n) return false;
         uint32_t cur = fn_arg_cursor(f);
         for (uint32_t i = 0; i < n; i++) if (T().can_autocast(types_in ? types_in[i] : vtype(argv[i]), fn_arg_type(f, cur)) < 0) return false;
@@ -430,6 +449,7 @@ struct Lowerer {
     }
     // arg types are read through `argv` (variable ids) unless `types` is given (Proc)
     __device__ uint32_t compiler_lookup_function(uint32_t sp_low, uint32_t sp_high, NameKey name, const uint32_t* argv, const uint32_t* types_in, uint32_t n) {
+        sp_low = uni(sp_low); sp_high = uni(sp_high); name = uni(name); n = uni(n);
         LPROF(LP_LOOKUPFN);
         {   // builtin operator on primitive operands with no user overloads of that symbol: the general algorithm below
             // reduces to pure arithmetic (candidates have pairwise different parameter types, so nothing is "ignorable"
@@ -496,6 +516,7 @@ struct Lowerer {
     // `same_span`) else the i-th node of the sibling chain starting there.  Returns false when there is no callee.
     struct Callee { uint32_t fv; uint32_t out; bool builtin; };
     __device__ bool call_variables(uint32_t sp_low, uint32_t sp_high, NameKey name, uint32_t* argv, uint32_t n, uint32_t span_node, bool same_span, Callee* res) {
+        sp_low = uni(sp_low); sp_high = uni(sp_high); name = uni(name); n = uni(n); span_node = uni(span_node); same_span = uni(same_span);
         LPROF(LP_CALLVARS);
         for (uint32_t i = 0; i < n; i++) if (trec(vtype(argv[i])).kind == TY_Error) return false;
         // lookup_function: a local of that name shadows the global functions
@@ -540,6 +561,7 @@ struct Lowerer {
 
     // get_field_type (:1090-1101) -> type id or NONE
     __device__ uint32_t get_field_type(uint32_t rec, uint32_t field_tok) {
+        rec = uni(rec); field_tok = uni(field_tok);
         const TypeRec r = trec(get_lvalue_type(rec));
         if (r.kind != TY_Record) return OPUSFE_NONE;
         uint32_t n = T().member_count(r), c = T().member_first(r);
@@ -548,6 +570,7 @@ struct Lowerer {
     }
     // generate_ir_for_field_access (:1103-1149)
     __device__ uint32_t field_access(uint32_t rec, uint32_t field_tok, uint8_t pt, uint32_t sp_low, uint32_t sp_high) {
+        rec = uni(rec); field_tok = uni(field_tok); pt = uni(pt); sp_low = uni(sp_low); sp_high = uni(sp_high);
         LPROF(LP_FIELD);
         if (pt == PT_Array || pt == PT_ArrayMutable) { report(SE_ArrayPointerToNonArray, sp_low, sp_high); return generate_error(); }
         const TypeRec r = trec(get_lvalue_type(rec));
@@ -579,6 +602,7 @@ struct Lowerer {
 
     // lookup_name (:857-893).  Returns false for "None" (the name is a constant global)
     __device__ bool lookup_name(uint32_t name_tok, uint32_t sp_low, uint32_t sp_high, uint8_t pt, uint32_t* var, bool* is_lvalue) {
+        name_tok = uni(name_tok); sp_low = uni(sp_low); sp_high = uni(sp_high); pt = uni(pt);
         LPROF(LP_LOOKUPNAME);
         *is_lvalue = true;
         NameKey key = key_tok(name_tok);
@@ -626,6 +650,7 @@ struct Lowerer {
     __device__ __forceinline__ LFrame pop_raw() { if (sp == 0) { internal(); return LFrame{}; } --sp; return uni(sp < LDS_FRAMES ? lds.frames[sp] : gld(frames + sp)); }
 
     __device__ void p_finish(uint32_t var, bool lv) {
+        var = uni(var); lv = uni(lv);
         if ((cur.aux & PF_MUSTLV) && !lv) { report_node(SE_InvalidLvalue, cur.f); var = generate_error(); }   // generate_pointer_from_expression :970-979
         if (cur.aux & PF_DEREF) var = lv ? dereference_pointer(var) : var;                                   // :577-585
         rv = var; rl = lv;

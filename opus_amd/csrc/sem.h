@@ -213,6 +213,7 @@ template <class M> struct TypeOps {
     // compile.rs:698-751, recursion replaced by a bounded work list (the reference recurses without a
     // cycle check: on a self-referential record it overflows its stack; we report UNSUPPORTED instead)
     __device__ static bool types_match(uint32_t a0, uint32_t b0) {
+        a0 = uni(a0); b0 = uni(b0);
         if (a0 < TP_COUNT && b0 < TP_COUNT) return a0 == b0;    // primitives: one id per kind
         uint32_t* stack_a = M::lds.match_stack; uint32_t* stack_b = M::lds.match_stack + 48;
         int sp = 0;
@@ -262,6 +263,7 @@ template <class M> struct TypeOps {
     }
     // compile.rs:753-763
     __device__ static bool types_match_allow_generic(uint32_t a, uint32_t b) {
+        a = uni(a); b = uni(b);
         uint8_t ka = kind(a), kb = kind(b);
         if ((ka == TY_GenericInteger && kind_is_integral(kb)) || (kb == TY_GenericInteger && kind_is_integral(ka))) return true;
         if (ka == TY_Generic || kb == TY_Generic) return true;
@@ -269,6 +271,7 @@ template <class M> struct TypeOps {
     }
     // compile.rs:765-775
     __device__ static bool types_match_default_generic(uint32_t a, uint32_t b) {
+        a = uni(a); b = uni(b);
         uint8_t ka = kind(a), kb = kind(b);
         if ((ka == TY_GenericInteger && kb == TY_Integer32) || (ka == TY_Integer32 && kb == TY_GenericInteger)) return true;
         if (ka == TY_Generic || kb == TY_Generic) return false;
@@ -280,6 +283,7 @@ template <class M> struct TypeOps {
     }
     // compile.rs:624-670; returns CastKind or -1
     __device__ static int can_autocast(uint32_t from, uint32_t to) {
+        from = uni(from); to = uni(to);
         if (from < TP_COUNT && to < TP_COUNT) {   // both primitive: no table access
             if (from == to) return CT_None;
             if (from == TP_Error || to == TP_Error) return CT_Error;
@@ -310,6 +314,7 @@ template <class M> struct TypeOps {
     }
     // compile.rs:682-696
     __device__ static int can_cast(uint32_t from, uint32_t to) {
+        from = uni(from); to = uni(to);
         int c = can_autocast(from, to);
         if (c >= 0) return c;
         const TypeRec t1 = rec(from), t2 = rec(to);
