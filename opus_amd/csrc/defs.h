@@ -10,7 +10,7 @@
 // instead of 64.  The host emulation (tests/emu) runs one lane per unit.
 // occupancy hint of the two sequential-machine kernels (waves per SIMD the register allocator must leave room for)
 #ifndef OPUSFE_PARSE_WAVES
-#define OPUSFE_PARSE_WAVES 6
+#define OPUSFE_PARSE_WAVES 5
 #endif
 #ifndef OPUSFE_LOWER_WAVES
 #define OPUSFE_LOWER_WAVES 4
@@ -91,6 +91,9 @@ template <class T> void gst(T* p, const T& v) { emu_counts()[__PRETTY_FUNCTION__
 #else
 template <class T> __host__ __device__ __forceinline__ T gld(const T* p) { return *p; }
 template <class T> __host__ __device__ __forceinline__ void gst(T* p, const T& v) { *p = v; }
+#endif
+#ifndef OPUSFE_GLOBAL
+#define OPUSFE_GLOBAL
 #endif
 // Scalar loads.  The machines are wave-uniform, so what they read from the read-only tables (nodes, tokens, name table,
 // records written by EARLIER kernels) belongs in SGPRs: a load through a constant-address-space pointer with a

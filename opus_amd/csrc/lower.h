@@ -148,6 +148,7 @@ struct Lowerer {
     MACHINE_STATE uint32_t dev_status;
     MACHINE_STATE LFrame cur;
     MACHINE_STATE uint32_t rv; MACHINE_STATE bool rl; MACHINE_STATE bool rdiv;
+    MACHINE_STATE bool sym_locals;   // some local is named by an operator symbol (`operator +` as a variable name): only then can a symbol key hit a local
 #ifdef OPUSFE_LOWER_PROF
     MACHINE_STATE uint64_t prof[LP_COUNT];
 #endif
@@ -326,6 +327,7 @@ struct Lowerer {
     }
     __device__ void local_set(uint32_t name_tok, uint32_t v) {
         name_tok = uni(name_tok); v = uni(v);
+        if (name_sym(TokView{}, key_tok(name_tok)) != T_Identifier) sym_locals = true;
         uint32_t j = local_find(key_tok(name_tok));
         if (j != OPUSFE_NONE) { l_set_var(j, v); return; }
         if (nlocals >= lcap) { internal(); return; }
@@ -418,16 +420,16 @@ struct Lowerer {
     }
 
     // Compiler::lookup_function (compile.rs:1083-1139) over builtins followed by the user overloads in definition order
-    __device__ bool name_has_functions(NameKey name, uint32_t* slot_out) const {
+    struct NameFns { uint32_t slot; bool has; };   // (results travel in registers: an out-parameter of a helper that is not inlined lives in scratch memory)
+    __device__ NameFns name_has_functions(NameKey name) const {
         name = uni(name);
         uint8_t sym = name_sym(TokView{}, name);
         uint32_t s = find_slot(name);
-        *slot_out = s;
-        if (sym != T_Identifier && builtin_count(sym) > 0) return true;
-        if (s == OPUSFE_NONE) return false;
+        if (sym != T_Identifier && builtin_count(sym) > 0) return NameFns{s, true};
+        if (s == OPUSFE_NONE) return NameFns{s, false};
         const NameSlot sl = S.slots[s];
-        for (uint32_t j = 0; j < sl.count; j++) if ((S.entries[sl.offset + j].kind_index >> 30) == NK_FUNCTION) return true;
-        return false;
+        for (uint32_t j = 0; j < sl.count; j++) if ((S.entries[sl.offset + j].kind_index >> 30) == NK_FUNCTION) return NameFns{s, true};
+        return NameFns{s, false};
     }
     __device__ uint32_t candidate(NameKey name, uint32_t slot, uint32_t c, uint32_t* total) const {
         name = uni(name); slot = uni(slot); c = uni(c);
@@ -440,47 +442,50 @@ struct Lowerer {
         if ((e.kind_index >> 30) != NK_FUNCTION) return FN_NONE;
         return e.kind_index & 0x3FFFFFFFu;
     }
-    __device__ bool candidate_ok(uint32_t f, const uint32_t* argv, const uint32_t* types_in, uint32_t n) {
+    // call arguments: variable ids in the call-argument pool (`mem`, global memory) or, for operator calls, the two
+    // operands by value: a stack array handed to a helper that is not inlined would live in scratch memory
+    struct Args {
+        uint32_t* mem; uint32_t a0, a1;
+        __device__ __forceinline__ uint32_t get(uint32_t i) const { return mem ? uni(gld(mem + i)) : (i == 0 ? a0 : a1); }
+        __device__ __forceinline__ void set(uint32_t i, uint32_t v) { if (mem) gst(mem + i, v); else if (i == 0) a0 = v; else a1 = v; }
+    };
+    __device__ bool candidate_ok(uint32_t f, Args argv, const uint32_t* types_in, uint32_t n) {
         f = uni(f); n = uni(n);
         if (fn_nargs(f) != n) return false;
         uint32_t cur = fn_arg_cursor(f);
-        for (uint32_t i = 0; i < n; i++) if (T().can_autocast(types_in ? types_in[i] : vtype(argv[i]), fn_arg_type(f, cur)) < 0) return false;
+        for (uint32_t i = 0; i < n; i++) if (T().can_autocast(types_in ? uni(gld(types_in + i)) : vtype(argv.get(i)), fn_arg_type(f, cur)) < 0) return false;
         return true;
     }
     // arg types are read through `argv` (variable ids) unless `types` is given (Proc)
-    __device__ uint32_t compiler_lookup_function(uint32_t sp_low, uint32_t sp_high, NameKey name, const uint32_t* argv, const uint32_t* types_in, uint32_t n) {
+    __device__ uint32_t compiler_lookup_function(uint32_t sp_low, uint32_t sp_high, NameKey name, Args argv, const uint32_t* types_in, uint32_t n) {
         sp_low = uni(sp_low); sp_high = uni(sp_high); name = uni(name); n = uni(n);
         LPROF(LP_LOOKUPFN);
         {   // builtin operator on primitive operands with no user overloads of that symbol: the general algorithm below
-            // reduces to pure arithmetic (candidates have pairwise different parameter types, so nothing is "ignorable"
-            // unless there is exactly one candidate)
+            // reduces to arithmetic.  The candidates have pairwise different parameter types, so with ok_i(t) = "operand i
+            // autocasts to t" (a_i == t, GenericInteger -> integral t, Generic -> any t) the set of viable overloads is
+            //   both concrete: {a0} if a0 == a1;   concrete + GenericInteger: {a0} if a0 is integral;   concrete + Generic: {a0}
+            //   (one viable overload is returned as it is, :cnt == 1)
+            //   GenericInteger twice: the ten integral overloads, of which Integer32 matches with default generics
+            //   anything else with Generic: several viable, none matches with default generics -> general path (Ambiguous)
             const uint8_t sym = name_sym(TokView{}, name);
             if (sym != T_Identifier && !types_in && builtin_count(sym) > 0 && !((user_syms >> sym) & 1) && n == builtin_nargs(sym)) {
-                const uint32_t a0 = vtype(argv[0]), a1 = n > 1 ? vtype(argv[1]) : a0;
+                const uint32_t a0 = vtype(argv.get(0)), a1 = n > 1 ? vtype(argv.get(1)) : a0;
                 if (a0 < TP_COUNT && a1 < TP_COUNT && a0 != TP_Error && a1 != TP_Error) {
-                    int cnt = 0, first = -1, pick = -1;
-                    const int total = builtin_count(sym);
-                    for (int idx = 0; idx < total; idx++) {
-                        const uint32_t t = builtin_arg_type(sym, idx);
-                        const bool integral = kind_is_integral(prim_kind(t));
-                        const bool ok0 = a0 == t || (a0 == TP_GenericInteger && integral) || a0 == TP_Generic;
-                        const bool ok1 = a1 == t || (a1 == TP_GenericInteger && integral) || a1 == TP_Generic;
-                        if (!(ok0 && ok1)) continue;
-                        cnt++;
-                        if (first < 0) first = idx;
-                        const bool d0 = a0 == TP_GenericInteger ? t == TP_Integer32 : (a0 != TP_Generic && t == a0);
-                        const bool d1 = a1 == TP_GenericInteger ? t == TP_Integer32 : (a1 != TP_Generic && t == a1);
-                        if (pick < 0 && d0 && d1) pick = idx;
-                    }
-                    if (cnt == 1) return FN_BUILTIN | ((uint32_t)sym << 8) | (uint32_t)first;
-                    if (cnt > 1 && pick >= 0) return FN_BUILTIN | ((uint32_t)sym << 8) | (uint32_t)pick;
+                    const bool g0 = a0 == TP_GenericInteger || a0 == TP_Generic, g1 = a1 == TP_GenericInteger || a1 == TP_Generic;
+                    int idx = -1;
+                    if (!g0 && !g1) { if (a0 == a1) idx = builtin_index_of(sym, a0); }
+                    else if (!g0) { if (a1 == TP_Generic || kind_is_integral(prim_kind(a0))) idx = builtin_index_of(sym, a0); }
+                    else if (!g1) { if (a0 == TP_Generic || kind_is_integral(prim_kind(a1))) idx = builtin_index_of(sym, a1); }
+                    else if (a0 == TP_GenericInteger && a1 == TP_GenericInteger) idx = builtin_index_of(sym, TP_Integer32);
+                    if (idx >= 0) return FN_BUILTIN | ((uint32_t)sym << 8) | (uint32_t)idx;
                 }
             }
         }
-        uint32_t slot;
-        if (!name_has_functions(name, &slot)) { report(SE_UndefinedFunction, sp_low, sp_high); return FN_NONE; }
+        const NameFns nf = name_has_functions(name);
+        const uint32_t slot = nf.slot;
+        if (!nf.has) { report(SE_UndefinedFunction, sp_low, sp_high); return FN_NONE; }
         if (n > 64) { unsupported(); return FN_NONE; }
-#define ARG_T(i) (types_in ? types_in[i] : vtype(argv[i]))
+#define ARG_T(i) (types_in ? uni(gld(types_in + (i))) : vtype(argv.get(i)))
         uint32_t total = 0; candidate(name, slot, 0, &total);
         uint32_t first = FN_NONE; uint64_t ignorable = ~0ull;
         for (uint32_t c = 0; c < total; c++) {
@@ -514,27 +519,28 @@ struct Lowerer {
     // IrGenerator::lookup_function + get_function_call_variables (generate_ir.rs:1151-1198).
     // argv[0..n) are updated in place by the autocasts; span of argument i = node `span_node` (same for all when
     // `same_span`) else the i-th node of the sibling chain starting there.  Returns false when there is no callee.
-    struct Callee { uint32_t fv; uint32_t out; bool builtin; };
-    __device__ bool call_variables(uint32_t sp_low, uint32_t sp_high, NameKey name, uint32_t* argv, uint32_t n, uint32_t span_node, bool same_span, Callee* res) {
+    struct Callee { uint32_t fv, out, a0, a1; bool builtin, ok; };   // a0 / a1: the operands after their autocasts (operator calls)
+    __device__ Callee call_variables(uint32_t sp_low, uint32_t sp_high, NameKey name, Args argv, uint32_t n, uint32_t span_node, bool same_span) {
+        Callee res{}; res.ok = false;
         sp_low = uni(sp_low); sp_high = uni(sp_high); name = uni(name); n = uni(n); span_node = uni(span_node); same_span = uni(same_span);
         LPROF(LP_CALLVARS);
-        for (uint32_t i = 0; i < n; i++) if (trec(vtype(argv[i])).kind == TY_Error) return false;
+        for (uint32_t i = 0; i < n; i++) if (trec(vtype(argv.get(i))).kind == TY_Error) return res;
         // lookup_function: a local of that name shadows the global functions
         uint32_t fv, ret; bool builtin = false;
         uint32_t arg_src = 0;        // 0: function id `fid`; 1: members of function type `ftype`
         uint32_t fid = FN_NONE; TypeRec ftype{};
-        uint32_t lj = local_find(name);
+        uint32_t lj = (name.tok == OPUSFE_NONE && !sym_locals) ? OPUSFE_NONE : local_find(name);
         if (lj != OPUSFE_NONE) {
             uint32_t variable = l_var(lj);
             uint32_t typ = get_lvalue_type(variable);
             uint32_t nv = new_var(typ, true);
             push(ins(I_Load, nv, variable));
             ftype = trec(typ);
-            if (ftype.kind != TY_Function) { report(SE_CallOfNonFunction, sp_low, sp_high); return false; }
+            if (ftype.kind != TY_Function) { report(SE_CallOfNonFunction, sp_low, sp_high); return res; }
             fv = nv; ret = ftype.sub; arg_src = 1;
         } else {
             fid = compiler_lookup_function(sp_low, sp_high, name, argv, nullptr, n);
-            if (fid == FN_NONE) return false;
+            if (fid == FN_NONE) return res;
             ret = fn_ret(fid);
             if (fn_is_builtin(fid)) { fv = OPUSFE_NONE; builtin = true; }
             else {
@@ -552,11 +558,11 @@ struct Lowerer {
             uint32_t want;
             if (arg_src == 1) { want = T().member_type(cursor); cursor = T().member_next(cursor); }
             else want = fn_arg_type(fid, cursor);
-            argv[i] = autocast(argv[i], want, sn);
+            argv.set(i, autocast(argv.get(i), want, sn));
             if (!same_span && sn != OPUSFE_NONE && N(sn).next != OPUSFE_NONE) sn = N(sn).next;
         }
-        res->fv = fv; res->out = new_var(ret, true); res->builtin = builtin;
-        return true;
+        res.fv = fv; res.out = new_var(ret, true); res.builtin = builtin; res.a0 = argv.a0; res.a1 = argv.a1; res.ok = true;
+        return res;
     }
 
     // get_field_type (:1090-1101) -> type id or NONE
@@ -601,38 +607,35 @@ struct Lowerer {
     }
 
     // lookup_name (:857-893).  Returns false for "None" (the name is a constant global)
-    __device__ bool lookup_name(uint32_t name_tok, uint32_t sp_low, uint32_t sp_high, uint8_t pt, uint32_t* var, bool* is_lvalue) {
+    struct Looked { uint32_t var; bool found, lv; };
+    __device__ Looked lookup_name(uint32_t name_tok, uint32_t sp_low, uint32_t sp_high, uint8_t pt) {
         name_tok = uni(name_tok); sp_low = uni(sp_low); sp_high = uni(sp_high); pt = uni(pt);
         LPROF(LP_LOOKUPNAME);
-        *is_lvalue = true;
         NameKey key = key_tok(name_tok);
         uint32_t lj = local_find(key);
-        if (lj != OPUSFE_NONE) { *var = try_cast_pointer(l_var(lj), pt, sp_low, sp_high); return true; }
+        if (lj != OPUSFE_NONE) return Looked{try_cast_pointer(l_var(lj), pt, sp_low, sp_high), true, true};
         uint32_t ge = last_entry(key, NK_GLOBAL);
         if (ge != OPUSFE_NONE) {
             uint32_t gid = S.entries[ge].kind_index & 0x3FFFFFFFu;
-            if (S.globals[gid].is_const) return false;
+            if (S.globals[gid].is_const) return Looked{0, false, true};
             uint32_t v = new_var(type_mut(S.globals[gid].type_id), true);
             push(ins(I_GlobalVariable, v, 0, 0, gid));
-            *var = try_cast_pointer(v, pt, sp_low, sp_high);
-            return true;
+            return Looked{try_cast_pointer(v, pt, sp_low, sp_high), true, true};
         }
-        uint32_t slot;
-        if (name_has_functions(key, &slot)) {
+        const NameFns nf = name_has_functions(key);
+        const uint32_t slot = nf.slot;
+        if (nf.has) {
             uint32_t total = 0, count = 0, only = FN_NONE;
             candidate(key, slot, 0, &total);
             for (uint32_t c = 0; c < total; c++) { uint32_t f = candidate(key, slot, c, &total); if (f != FN_NONE) { count++; only = f; } }
-            if (count > 1) { report_tok(SE_AmbiguousFunctionReference, name_tok); *var = generate_error(); return true; }
-            if (fn_is_builtin(only)) { unsupported(); *var = generate_error(); return true; }   // single builtin (`not`): the reference builds a function value of a builtin
-            *is_lvalue = false;
+            if (count > 1) { report_tok(SE_AmbiguousFunctionReference, name_tok); return Looked{generate_error(), true, true}; }
+            if (fn_is_builtin(only)) { unsupported(); return Looked{generate_error(), true, true}; }   // single builtin (`not`): the reference builds a function value of a builtin
             uint32_t v = new_var(type_function(only), true);
             push(ins(I_Function, v, 0, 0, only));
-            *var = v;
-            return true;
+            return Looked{v, true, false};
         }
         report_tok(SE_UndefinedVariable, name_tok);
-        *var = generate_error();
-        return true;
+        return Looked{generate_error(), true, true};
     }
 
     // ---- machine ----------------------------------------------------------------------------------
@@ -640,7 +643,7 @@ struct Lowerer {
         LPROF(LP_FRAMES);
         cur.st = resume;
         if (sp + 1 >= fcap) { internal(); return false; }
-        if (sp < LDS_FRAMES) lds.frames[sp] = cur; else frames[sp] = cur;
+        if (sp < LDS_FRAMES) lds.frames[sp] = cur; else gst(frames + sp, (LFrame)cur);
         sp++;
         cur.st = entry; cur.aux = aux; cur.cnt = 0; cur.node = node; cur.a = a; cur.b = cur.c = cur.d = cur.e = 0; cur.f = f;
         return true;
@@ -789,8 +792,9 @@ struct Lowerer {
                 const uint32_t elow = N(inode).low, ehigh = N(inode).high;
                 uint32_t off = reserve_cargs(1);
                 gst(cargs + off, rv);
-                Callee cl; uint32_t for_fn, ret_var;
-                if (call_variables(elow, ehigh, key_sym(T_For), cargs + off, 1, inode, true, &cl)) { for_fn = cl.fv; ret_var = cl.out; }
+                uint32_t for_fn, ret_var;
+                Callee cl = call_variables(elow, ehigh, key_sym(T_For), Args{cargs + off, 0, 0}, 1, inode, true);
+                if (cl.ok) { for_fn = cl.fv; ret_var = cl.out; }
                 else { for_fn = generate_error(); ret_var = generate_error(); }
                 uint32_t iterator_variable = new_var(type_mut(vtype(ret_var)), true);
                 push(ins(I_Call, ret_var, for_fn, 0, off, 0, 1));
@@ -812,7 +816,8 @@ struct Lowerer {
                 uint32_t off2 = reserve_cargs(2);
                 gst(cargs + off2, iterator_variable); gst(cargs + off2 + 1, iteration_variable);
                 uint32_t cont_fn, cond;
-                if (call_variables(elow, ehigh, key_sym(T_Continue), cargs + off2, 2, inode, true, &cl)) { cont_fn = cl.fv; cond = cl.out; }
+                cl = call_variables(elow, ehigh, key_sym(T_Continue), Args{cargs + off2, 0, 0}, 2, inode, true);
+                if (cl.ok) { cont_fn = cl.fv; cond = cl.out; }
                 else { cont_fn = generate_error(); cond = generate_error(); }
                 push(ins(I_Call, cond, cont_fn, 0, off2, 0, 2));
                 cond = autocast(cond, TP_Bool, inode);
@@ -898,7 +903,7 @@ struct Lowerer {
                         uint32_t* types = cargs + reserve_cargs(nd.nchild);    // scratch use of the pool, released below
                         uint32_t c = nd.first_child;
                         for (uint32_t i = 0; i < nd.nchild; i++) { types[i] = resolve_type(c, undefined_flag); c = N(c).next; }
-                        uint32_t f = compiler_lookup_function(nd.low, nd.high, key_tok(nd.payload), nullptr, types, nd.nchild);
+                        uint32_t f = compiler_lookup_function(nd.low, nd.high, key_tok(nd.payload), Args{nullptr, 0, 0}, types, nd.nchild);
                         ncargs = saved_cargs;
                         if (f == FN_NONE) { rv = generate_error(); retn(); goto next; }
                         if (fn_is_builtin(f)) { report_node(SE_ReferenceToBuiltinFunction, cur.node); rv = generate_error(); retn(); goto next; }
@@ -965,21 +970,19 @@ struct Lowerer {
                 rv = out; retn(); goto next;
             }
             case LS_OP_NOT_1: {
-                uint32_t argv[1] = {rv};
                 uint32_t right = N(nd.first_child).next;
-                Callee cl;
-                if (call_variables(nd.low, nd.high, key_sym(T_Not), argv, 1, right, true, &cl)) {
-                    if (cl.builtin) push(ins(I_Not, cl.out, argv[0]));
-                    else { uint32_t off = reserve_cargs(1); gst(cargs + off, argv[0]); push(ins(I_Call, cl.out, cl.fv, 0, off, 0, 1)); }
+                const Callee cl = call_variables(nd.low, nd.high, key_sym(T_Not), Args{nullptr, rv, 0}, 1, right, true);
+                if (cl.ok) {
+                    if (cl.builtin) push(ins(I_Not, cl.out, cl.a0));
+                    else { uint32_t off = reserve_cargs(1); gst(cargs + off, cl.a0); push(ins(I_Call, cl.out, cl.fv, 0, off, 0, 1)); }
                     rv = cl.out;
                 } else rv = generate_error();
                 retn(); goto next;
             }
             case LS_OP_BIN_1: cur.b = rv; CALL_E(N(nd.first_child).next, TP_GenericInteger, LS_OP_BIN_2);
             case LS_OP_BIN_2: {
-                uint32_t argv[2] = {cur.b, rv};
-                Callee cl;
-                if (call_variables(nd.low, nd.high, key_sym(sym_of_op(nd.sub)), argv, 2, nd.first_child, false, &cl)) {
+                const Callee cl = call_variables(nd.low, nd.high, key_sym(sym_of_op(nd.sub)), Args{nullptr, cur.b, rv}, 2, nd.first_child, false);
+                if (cl.ok) {
                     if (cl.builtin) {
                         uint16_t op;
                         switch (nd.sub) {
@@ -988,8 +991,8 @@ struct Lowerer {
                             case OP_LessThan: op = I_LessThan; break; case OP_GreaterThan: op = I_GreaterThan; break;
                             case OP_LessThanEquals: op = I_LessThanEquals; break; default: op = I_GreaterThanEquals; break;
                         }
-                        push(ins(op, cl.out, argv[0], argv[1]));
-                    } else { uint32_t off = reserve_cargs(2); gst(cargs + off, argv[0]); gst(cargs + off + 1, argv[1]); push(ins(I_Call, cl.out, cl.fv, 0, off, 0, 2)); }
+                        push(ins(op, cl.out, cl.a0, cl.a1));
+                    } else { uint32_t off = reserve_cargs(2); gst(cargs + off, cl.a0); gst(cargs + off + 1, cl.a1); push(ins(I_Call, cl.out, cl.fv, 0, off, 0, 2)); }
                     rv = cl.out;
                 } else rv = generate_error();
                 retn(); goto next;
@@ -1030,8 +1033,8 @@ struct Lowerer {
                 const uint8_t pt = cur.aux & 3;
                 switch (nd.kind) {
                     case E_Variable: {
-                        uint32_t var; bool lv;
-                        if (lookup_name(nd.payload, nd.low, nd.high, pt, &var, &lv)) { p_finish(var, lv); goto next; }
+                        const Looked lk = lookup_name(nd.payload, nd.low, nd.high, pt);
+                        if (lk.found) { p_finish(lk.var, lk.lv); goto next; }
                         // constant global (:993-998)
                         uint32_t ge = last_entry(key_tok(nd.payload), NK_GLOBAL);
                         uint32_t gid = S.entries[ge].kind_index & 0x3FFFFFFFu;
@@ -1055,19 +1058,18 @@ struct Lowerer {
                     case E_Dereference: CALL_E(nd.first_child, OPUSFE_NONE, LS_P_DEREF_1);
                     case E_Field: CALL_P(nd.first_child, pt | PF_MUSTLV, LS_P_FIELD_1);
                     case E_NamedCall: {
-                        uint32_t slot;
-                        if (name_has_functions(key_tok(nd.payload), &slot)) {
+                        if (name_has_functions(key_tok(nd.payload)).has) {
                             cur.a = reserve_cargs(nd.nchild);          // arguments are evaluated straight into the call-argument pool
                             cur.b = nd.first_child; cur.c = 0;
                             cur.st = LS_P_NC_LOOP;
                             goto next;
                         }
-                        uint32_t var; bool lv;
-                        if (!lookup_name(nd.payload, nd.low, nd.high, pt, &var, &lv)) {
+                        const Looked lk = lookup_name(nd.payload, nd.low, nd.high, pt);
+                        if (!lk.found) {
                             report_node(SE_AttemptToCallOrIndexConstant, cur.node);
                             p_finish(generate_error(), true); goto next;
                         }
-                        cur.a = var; cur.b = lv ? 1 : 0; cur.c = nd.first_child;
+                        cur.a = lk.var; cur.b = lk.lv ? 1 : 0; cur.c = nd.first_child;
                         cur.st = LS_P_IDX_0;
                         goto next;
                     }
@@ -1097,8 +1099,9 @@ struct Lowerer {
             case LS_P_NC_LOOP:
                 if (cur.b != OPUSFE_NONE) CALL_E(cur.b, TP_GenericInteger, LS_P_NC_ITEM);
                 {
-                    Callee cl; uint32_t var;
-                    if (call_variables(nd.low, nd.high, key_tok(nd.payload), cargs + cur.a, nd.nchild, nd.first_child, false, &cl)) {
+                    uint32_t var;
+                    const Callee cl = call_variables(nd.low, nd.high, key_tok(nd.payload), Args{cargs + cur.a, 0, 0}, nd.nchild, nd.first_child, false);
+                    if (cl.ok) {
                         push(ins(I_Call, cl.out, cl.fv, 0, cur.a, 0, nd.nchild));
                         var = cl.out;
                     } else var = generate_error();
@@ -1243,7 +1246,7 @@ __global__ MACHINE_ATTR(OPUSFE_LOWER_WAVES) __launch_bounds__(64) void k_lower_f
     L.frames = B.frames + lower_base(CAP_FRAMES, dn, fidx); L.sp = 0; L.fcap = (uint32_t)lower_cap(CAP_FRAMES, nn);
     L.errs = B.errs + lower_base(CAP_ERRS, dn, fidx); L.nerrs = 0; L.ecap = (uint32_t)lower_cap(CAP_ERRS, nn);
     L.bb_index = 0; L.break_head = OPUSFE_NONE; L.loop_begin = OPUSFE_NONE; L.dev_status = DS_OK;
-    L.rv = 0; L.rl = false; L.rdiv = false;
+    L.rv = 0; L.rl = false; L.rdiv = false; L.sym_locals = false;
     // body = last child of the definition
     uint32_t c = S.nodes[dn].first_child;
     while (S.nodes[c].next != OPUSFE_NONE) c = S.nodes[c].next;

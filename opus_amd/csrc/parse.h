@@ -64,7 +64,11 @@ enum PState : uint8_t {
 
 struct SegParser {
     // registers of the machine: static LDS variables, one machine per workgroup (defs.h MACHINE_STATE)
-    MACHINE_STATE const opusfe_token* tok;
+#ifdef OPUSFE_EMU
+    MACHINE_STATE GTable<opusfe_token> tok;
+#else
+    MACHINE_STATE STable<opusfe_token> tok;     // tokens are read-only here: scalar loads
+#endif
     MACHINE_STATE opusfe_node* nodes;     // sparse array
     MACHINE_STATE PFrame* stack;
     MACHINE_STATE uint64_t nbase, ncap, fcap;
@@ -84,10 +88,11 @@ struct SegParser {
 
     // Every access is range checked: on malformed input (the part of a file after its first syntax error is
     // still parsed by other lanes) a wrong index becomes an internal-error status, never a GPU memory fault.
-    __device__ __forceinline__ opusfe_node& N(uint32_t id) {
+    // (a reference into global memory: field reads and writes compile to global_load / global_store)
+    __device__ __forceinline__ OPUSFE_GLOBAL opusfe_node& N(uint32_t id) {
         uint64_t off = (uint64_t)id - nbase;
         if (off >= ncap) { dev_status = DS_INTERNAL_CAPACITY; off = ncap - 1; }   // last slot is a dummy
-        return nodes[nbase + off];
+        return ((OPUSFE_GLOBAL opusfe_node*)nodes)[nbase + off];
     }
     __device__ __forceinline__ uint32_t tk(uint32_t k) const { return k < n_tokens ? k : n_tokens - 1; }   // clamps to EndOfFile
     __device__ __forceinline__ uint8_t kind_at(uint32_t k) const { return tok[tk(k)].kind; }
@@ -109,7 +114,7 @@ struct SegParser {
         if (nn + 1 >= ncap) { dev_status = DS_INTERNAL_CAPACITY; return (uint32_t)(nbase + ncap - 1); }
         uint32_t id = (uint32_t)(nbase + nn++);
         opusfe_node n; n.kind = kind; n.sub = sub; n.nchild = 0; n.first_child = OPUSFE_NONE; n.next = OPUSFE_NONE; n.payload = payload; n.low = low; n.high = low;
-        N(id) = n;
+        gst(&nodes[id], n);
         return id;
     }
     // append `c` to the child list of cur.a (frame keeps last child in cur.c, count in cur.cnt)
@@ -157,6 +162,7 @@ struct SegParser {
 
     // parse.rs:837-869 (recursion on the new left child unrolled into a loop)
     __device__ void correct_precedence(uint32_t e) {
+        e = uni(e);
         for (;;) {
             if (N(e).kind != E_Operator) return;
             uint32_t L = N(e).first_child;
@@ -190,6 +196,7 @@ struct SegParser {
 
     // Runs until the segment's tokens are used up or the first error.  Returns false on error.
     __device__ bool run(uint32_t seg_end, uint32_t* first_def, uint32_t* def_count) {
+        seg_end = uni(seg_end);
 #define CALL(entry, resume) do { if (!call(entry, resume)) return false; goto next; } while (0)
 #define TRY(x) do { if (!(x)) return false; } while (0)
         uint32_t last_def = OPUSFE_NONE;
@@ -621,10 +628,10 @@ __global__ MACHINE_ATTR(OPUSFE_PARSE_WAVES) __launch_bounds__(64) void k_parse_s
     if (s >= n_segs) return;
     uint32_t tb = seg_start[s], te = (s + 1 < n_segs) ? seg_start[s + 1] : n_tokens;
     SegParser P;    // no fields of its own: the state is static LDS (see lower.h)
-    P.tok = tok; P.nodes = nodes; P.n_tokens = n_tokens;
+    P.tok.p = tok; P.nodes = nodes; P.n_tokens = n_tokens;
     P.nbase = seg_node_base(tb, s); P.ncap = seg_node_cap(tb, te);
     P.stack = frames + seg_frame_base(tb, s); P.fcap = seg_frame_cap(tb, te);
-    P.i = tb; P.peeked = false; P.position = tb > 0 ? tok[tb - 1].low + tok[tb - 1].len : 0u;
+    P.i = tb; P.peeked = false; P.position = tb > 0 ? P.end_at(tb - 1) : 0u;
     P.nn = 0; P.sp = 0; P.max_sp = 0; P.ret = OPUSFE_NONE;
     P.err_kind = OPUSFE_NONE; P.err_tok = 0; P.err_low = 0; P.err_len = 0; P.err_expected = 0; P.dev_status = DS_OK; P.unsup_pos = OPUSFE_NONE;
     { opusfe_node d{}; d.kind = X_Block; d.first_child = OPUSFE_NONE; d.next = OPUSFE_NONE; nodes[P.nbase + P.ncap - 1] = d; }

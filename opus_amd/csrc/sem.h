@@ -155,6 +155,17 @@ __host__ __device__ __forceinline__ uint32_t builtin_arg_type(uint8_t sym, int i
     if (n == 14) return i < 8 ? i : i < 10 ? i + 6 : i < 12 ? i - 2 : i + 4;
     return TP_Bool;
 }
+// inverse of builtin_arg_type: index of the overload of `sym` whose parameter type is primitive t, or -1
+__host__ __device__ __forceinline__ int builtin_index_of(uint8_t sym, uint32_t t) {
+    const int n = builtin_count(sym);
+    if (n == 1) return t == TP_Bool ? 0 : -1;
+    if (n != 12 && n != 14) return -1;
+    if (t < 8) return (int)t;
+    if (t == TP_Size || t == TP_Offset) return (int)t - 6;
+    if (t == TP_Float32 || t == TP_Float64) return n == 12 ? (int)t - 6 : (int)t - 4;
+    if (n == 14 && (t == TP_Bool || t == TP_Null)) return (int)t + 2;
+    return -1;
+}
 __host__ __device__ __forceinline__ uint32_t builtin_ret_type(uint8_t sym, int idx) { return builtin_count(sym) == 12 ? builtin_arg_type(sym, idx) : (uint32_t)TP_Bool; }
 __host__ __device__ __forceinline__ uint32_t builtin_nargs(uint8_t sym) { return sym == T_Not ? 1u : 2u; }
 
