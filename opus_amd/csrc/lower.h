@@ -97,7 +97,8 @@ struct ProfScope { uint64_t* p; int id; uint64_t t0; __device__ ProfScope(uint64
 #else
 #define LPROF(id) do { } while (0)
 #endif
-enum { LP_TOTAL = 0, LP_NODE, LP_LOCALFIND, LP_CALLVARS, LP_AUTOCAST, LP_TRYCAST, LP_LOOKUPNAME, LP_FIELD, LP_PUSH, LP_NEWVAR, LP_FRAMES, LP_LOOKUPFN, LP_COUNT };
+enum { LP_TOTAL = 0, LP_NODE, LP_LOCALFIND, LP_CALLVARS, LP_AUTOCAST, LP_TRYCAST, LP_LOOKUPNAME, LP_FIELD, LP_PUSH, LP_NEWVAR, LP_FRAMES, LP_LOOKUPFN, LP_NAMED,
+       LP_STATE_CYCLES = LP_NAMED, LP_STATE_STEPS = LP_STATE_CYCLES + 48, LP_COUNT = LP_STATE_STEPS + 48 };   // + per machine state: cycles and steps
 
 enum LState : uint8_t {
     LS_BLOCK, LS_BLOCK_LOOP, LS_BLOCK_ITEM,
@@ -369,7 +370,17 @@ struct Lowerer {
     }
 
     // ---- generate_ir.rs:207-231 -------------------------------------------------------------------
-    __device__ uint32_t autocast(uint32_t variable, uint32_t expected, uint32_t span_node) {
+    // The common cases are decided in the caller; the general algorithm stays out of line (a helper of that size pays
+    // for its register saves on every call, even when it returns at once).
+    __device__ __forceinline__ uint32_t autocast(uint32_t variable, uint32_t expected, uint32_t span_node) {
+        const uint32_t found = vtype(variable);
+        if (found < TP_COUNT && expected < TP_COUNT && found != TP_Error && expected != TP_Error) {      // both primitive: types_match is id equality
+            if (found == expected) return variable;
+            if ((found == TP_GenericInteger && kind_is_integral(prim_kind(expected))) || found == TP_Generic) { set_vtype(variable, expected); return variable; }
+        }
+        return autocast_general(variable, expected, span_node);
+    }
+    __device__ uint32_t autocast_general(uint32_t variable, uint32_t expected, uint32_t span_node) {
         variable = uni(variable); expected = uni(expected); span_node = uni(span_node);
         LPROF(LP_AUTOCAST);
         uint32_t found = vtype(variable);
@@ -397,7 +408,12 @@ struct Lowerer {
     __device__ uint32_t dereference_pointer(uint32_t p) { p = uni(p); uint32_t v = new_var(get_lvalue_type(p), true); push(ins(I_Load, v, p)); return v; }
 
     // :808-855; `sp_low/sp_high` is the span for errors
-    __device__ uint32_t try_cast_pointer(uint32_t v, uint8_t pt, uint32_t sp_low, uint32_t sp_high) {
+    __device__ __forceinline__ uint32_t try_cast_pointer(uint32_t v, uint8_t pt, uint32_t sp_low, uint32_t sp_high) {
+        const TypeRec r = trec(vtype(v));
+        if (r.kind == TY_Pointer && r.ptr == pt) return v;     // the common case, decided in the caller
+        return try_cast_pointer_general(v, pt, sp_low, sp_high);
+    }
+    __device__ uint32_t try_cast_pointer_general(uint32_t v, uint8_t pt, uint32_t sp_low, uint32_t sp_high) {
         v = uni(v); pt = uni(pt); sp_low = uni(sp_low); sp_high = uni(sp_high);
         LPROF(LP_TRYCAST);
         const TypeRec r = trec(vtype(v));
@@ -444,6 +460,7 @@ struct Lowerer {
     }
     // call arguments: variable ids in the call-argument pool (`mem`, global memory) or, for operator calls, the two
     // operands by value: a stack array handed to a helper that is not inlined would live in scratch memory
+    struct Callee { uint32_t fv, out, a0, a1; bool builtin, ok; };   // a0 / a1: the operands after their autocasts (operator calls)
     struct Args {
         uint32_t* mem; uint32_t a0, a1;
         __device__ __forceinline__ uint32_t get(uint32_t i) const { return mem ? uni(gld(mem + i)) : (i == 0 ? a0 : a1); }
@@ -471,12 +488,7 @@ struct Lowerer {
             if (sym != T_Identifier && !types_in && builtin_count(sym) > 0 && !((user_syms >> sym) & 1) && n == builtin_nargs(sym)) {
                 const uint32_t a0 = vtype(argv.get(0)), a1 = n > 1 ? vtype(argv.get(1)) : a0;
                 if (a0 < TP_COUNT && a1 < TP_COUNT && a0 != TP_Error && a1 != TP_Error) {
-                    const bool g0 = a0 == TP_GenericInteger || a0 == TP_Generic, g1 = a1 == TP_GenericInteger || a1 == TP_Generic;
-                    int idx = -1;
-                    if (!g0 && !g1) { if (a0 == a1) idx = builtin_index_of(sym, a0); }
-                    else if (!g0) { if (a1 == TP_Generic || kind_is_integral(prim_kind(a0))) idx = builtin_index_of(sym, a0); }
-                    else if (!g1) { if (a0 == TP_Generic || kind_is_integral(prim_kind(a1))) idx = builtin_index_of(sym, a1); }
-                    else if (a0 == TP_GenericInteger && a1 == TP_GenericInteger) idx = builtin_index_of(sym, TP_Integer32);
+                    const int idx = builtin_pick(sym, a0, a1);
                     if (idx >= 0) return FN_BUILTIN | ((uint32_t)sym << 8) | (uint32_t)idx;
                 }
             }
@@ -516,10 +528,35 @@ struct Lowerer {
 #undef ARG_T
     }
 
+    // An operator applied to primitive operands when no user overload of that symbol exists: call_variables below reduces
+    // to this (no local can shadow a symbol unless sym_locals; overload choice as in compiler_lookup_function's first
+    // block; the autocasts of primitives create no variables).  Everything else goes through the general helper.
+    __device__ __forceinline__ Callee call_op(uint32_t sp_low, uint32_t sp_high, uint8_t sym, uint32_t a0, uint32_t a1, uint32_t n, uint32_t span_node, bool same_span) {
+        if (!sym_locals && !((user_syms >> sym) & 1) && builtin_count(sym) > 0 && n == builtin_nargs(sym)) {
+            const uint32_t t0 = vtype(a0), t1 = n > 1 ? vtype(a1) : t0;
+            if (t0 < TP_COUNT && t1 < TP_COUNT && t0 != TP_Error && t1 != TP_Error) {
+                const int idx = builtin_pick(sym, t0, t1);
+                if (idx >= 0) {
+                    const uint32_t want = builtin_arg_type(sym, idx);
+                    Callee res{};
+                    res.a0 = autocast(a0, want, span_node);
+                    res.a1 = a1;
+                    if (n > 1) {
+                        uint32_t sn = span_node;
+                        if (!same_span && sn != OPUSFE_NONE && N(sn).next != OPUSFE_NONE) sn = N(sn).next;
+                        res.a1 = autocast(a1, want, sn);
+                    }
+                    res.fv = OPUSFE_NONE; res.builtin = true; res.ok = true;
+                    res.out = new_var(builtin_ret_type(sym, idx), true);
+                    return res;
+                }
+            }
+        }
+        return call_variables(sp_low, sp_high, key_sym(sym), Args{nullptr, a0, a1}, n, span_node, same_span);
+    }
     // IrGenerator::lookup_function + get_function_call_variables (generate_ir.rs:1151-1198).
     // argv[0..n) are updated in place by the autocasts; span of argument i = node `span_node` (same for all when
     // `same_span`) else the i-th node of the sibling chain starting there.  Returns false when there is no callee.
-    struct Callee { uint32_t fv, out, a0, a1; bool builtin, ok; };   // a0 / a1: the operands after their autocasts (operator calls)
     __device__ Callee call_variables(uint32_t sp_low, uint32_t sp_high, NameKey name, Args argv, uint32_t n, uint32_t span_node, bool same_span) {
         Callee res{}; res.ok = false;
         sp_low = uni(sp_low); sp_high = uni(sp_high); name = uni(name); n = uni(n); span_node = uni(span_node); same_span = uni(same_span);
@@ -683,7 +720,13 @@ struct Lowerer {
         const bool returns_null = trec(F.ret).kind == TY_Null;
         cur.st = LS_BLOCK; cur.aux = 0; cur.cnt = 0; cur.node = body; cur.a = cur.b = cur.c = cur.d = cur.e = cur.f = 0;
         sp = 0;
+#ifdef OPUSFE_LOWER_PROF
+        uint64_t step_t0 = __builtin_readcyclecounter(); uint32_t step_state = 47;
+#endif
         for (;;) {
+#ifdef OPUSFE_LOWER_PROF
+            { const uint64_t t = __builtin_readcyclecounter(); prof[LP_STATE_CYCLES + step_state] += t - step_t0; prof[LP_STATE_STEPS + step_state]++; step_t0 = t; step_state = cur.st < 47 ? cur.st : 47; }
+#endif
             if (dev_status >= DS_INTERNAL_CAPACITY) return;
             const opusfe_node nd = cur.node != OPUSFE_NONE ? N(cur.node) : opusfe_node{};
             switch (cur.st) {
@@ -971,7 +1014,7 @@ struct Lowerer {
             }
             case LS_OP_NOT_1: {
                 uint32_t right = N(nd.first_child).next;
-                const Callee cl = call_variables(nd.low, nd.high, key_sym(T_Not), Args{nullptr, rv, 0}, 1, right, true);
+                const Callee cl = call_op(nd.low, nd.high, T_Not, rv, 0, 1, right, true);
                 if (cl.ok) {
                     if (cl.builtin) push(ins(I_Not, cl.out, cl.a0));
                     else { uint32_t off = reserve_cargs(1); gst(cargs + off, cl.a0); push(ins(I_Call, cl.out, cl.fv, 0, off, 0, 1)); }
@@ -981,7 +1024,7 @@ struct Lowerer {
             }
             case LS_OP_BIN_1: cur.b = rv; CALL_E(N(nd.first_child).next, TP_GenericInteger, LS_OP_BIN_2);
             case LS_OP_BIN_2: {
-                const Callee cl = call_variables(nd.low, nd.high, key_sym(sym_of_op(nd.sub)), Args{nullptr, cur.b, rv}, 2, nd.first_child, false);
+                const Callee cl = call_op(nd.low, nd.high, sym_of_op(nd.sub), cur.b, rv, 2, nd.first_child, false);
                 if (cl.ok) {
                     if (cl.builtin) {
                         uint16_t op;
@@ -1453,10 +1496,13 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
         uint64_t h[LP_COUNT];
         HIP_TRY(hipMemcpyAsync(h, prof_buf, sizeof h, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        static const char* const NAMES[LP_COUNT] = {"total", "node loads", "local_find", "call_variables", "autocast", "try_cast_pointer", "lookup_name", "field_access",
+        static const char* const NAMES[LP_NAMED] = {"total", "node loads", "local_find", "call_variables", "autocast", "try_cast_pointer", "lookup_name", "field_access",
                                                     "push", "new_var", "frames", "compiler_lookup_function"};
         fprintf(stderr, "lowering cycle accounting (inclusive, summed over functions):\n");
-        for (int i = 0; i < LP_COUNT; i++) fprintf(stderr, "  %-26s %14llu  %5.1f%%\n", NAMES[i], (unsigned long long)h[i], 100.0 * h[i] / (double)h[0]);
+        for (int i = 0; i < LP_NAMED; i++) fprintf(stderr, "  %-26s %14llu  %5.1f%%\n", NAMES[i], (unsigned long long)h[i], 100.0 * h[i] / (double)h[0]);
+        fprintf(stderr, "per machine state (index into enum LState): share of cycles, steps, cycles per step\n");
+        for (int i = 0; i < 48; i++) if (h[LP_STATE_STEPS + i]) fprintf(stderr, "  state %2d  %5.1f%%  %12llu steps  %8.0f cycles/step\n", i, 100.0 * h[LP_STATE_CYCLES + i] / (double)h[0],
+                                                                       (unsigned long long)h[LP_STATE_STEPS + i], (double)h[LP_STATE_CYCLES + i] / (double)h[LP_STATE_STEPS + i]);
     }
 #endif
     IrCnt* cnt = tmp.get<IrCnt>(n_funcs);

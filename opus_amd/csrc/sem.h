@@ -166,6 +166,9 @@ __host__ __device__ __forceinline__ int builtin_index_of(uint8_t sym, uint32_t t
     if (n == 14 && (t == TP_Bool || t == TP_Null)) return (int)t + 2;
     return -1;
 }
+// overload of `sym` chosen for primitive, non-Error operand types a0 / a1 when only the builtins are candidates
+// (derivation: lower.h compiler_lookup_function), or -1 when the general algorithm has to decide
+__host__ __device__ __forceinline__ int builtin_pick(uint8_t sym, uint32_t a0, uint32_t a1);
 __host__ __device__ __forceinline__ uint32_t builtin_ret_type(uint8_t sym, int idx) { return builtin_count(sym) == 12 ? builtin_arg_type(sym, idx) : (uint32_t)TP_Bool; }
 __host__ __device__ __forceinline__ uint32_t builtin_nargs(uint8_t sym) { return sym == T_Not ? 1u : 2u; }
 
@@ -182,6 +185,15 @@ __host__ __device__ __forceinline__ uint8_t prim_kind(uint32_t p) {   // a byte 
 }
 __host__ __device__ __forceinline__ bool kind_is_integral(uint8_t k) {   // compile.rs:172-180
     return k <= TY_Natural64 || k == TY_Size || k == TY_Offset;
+}
+
+__host__ __device__ __forceinline__ int builtin_pick(uint8_t sym, uint32_t a0, uint32_t a1) {
+    const bool g0 = a0 == TP_GenericInteger || a0 == TP_Generic, g1 = a1 == TP_GenericInteger || a1 == TP_Generic;
+    if (!g0 && !g1) return a0 == a1 ? builtin_index_of(sym, a0) : -1;
+    if (!g0) return (a1 == TP_Generic || kind_is_integral(prim_kind(a0))) ? builtin_index_of(sym, a0) : -1;
+    if (!g1) return (a0 == TP_Generic || kind_is_integral(prim_kind(a1))) ? builtin_index_of(sym, a1) : -1;
+    if (a0 == TP_GenericInteger && a1 == TP_GenericInteger) return builtin_index_of(sym, TP_Integer32);
+    return -1;
 }
 
 // M: the machine whose static LDS state the operations work on (lower.h Lowerer): M::S (tables), M::dev_status
