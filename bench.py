@@ -7,10 +7,15 @@ One "step" = one pass of the hot path over one synthetic source that is already 
   all result arrays left complete in HBM.  Result buffers are released between steps (the library's caching
   allocator keeps the blocks, so steady-state steps do not call hipMalloc).
 
-Workload (config.workload): BASELINE.json configs[2] — ONE synthetic source of --bytes (default 1e9) per GPU
-produced by the seeded generator G (tools/gen), with the three depth-1000 regions injected.  With N>1 every
-rank owns its own equally sized shard made of whole top-level definitions (weak scaling; SURVEY §8e file/segment
-sharding: no data-path collective); `value` = total source bytes of all ranks / max-over-ranks time.
+Workload (config.workload):
+  N=1 ("c3"): BASELINE.json configs[2] — ONE synthetic source of --bytes (default 1e9) produced by the seeded
+        generator G (tools/gen), with the three depth-1000 regions injected.
+  N>1 ("c4", default): BASELINE.json configs[3] — ONE logical source of N x --bytes cut at ARBITRARY byte positions
+        (rank r holds bytes [r*B+12345, (r+1)*B+12345): cuts fall inside lines, strings and blocks); the ranks
+        exchange lexer-context / token-tail / bracket-depth / cut carries, the prefix halo and the definition
+        headers by all-gather (opus_amd/shard.py) and each lowers the definitions it owns.  Weak scaling:
+        `value` = N x --bytes / max-over-ranks time.  `--workload c3` at N>1 gives independent sources per rank
+        (no collective at all).
 
 Extra objects on the JSON line:
   roofline     — the dominant kernel (largest share of HIP-event time, measured by the library on its own
@@ -176,8 +181,22 @@ def main():
             avg_ms = ms / max(1, launches)
             per_step = launches / args.steps
             a = alg[stage_of(name)] / max(1.0, per_step) / (avg_ms * 1e-3) / 1e9
+            # HBM traffic per launch: PMC counters cannot be read from inside this process; the committed rocprofv3 passes
+            # (tools/profile.sh -> profiles/*_traffic.json) hold FETCH_SIZE + WRITE_SIZE per launch for one source size:
+            # reported only when this run is that same workload, else null
+            traffic = None
+            try:
+                tdir = os.path.join(ROOT, "profiles")
+                for fn in sorted(os.listdir(tdir), reverse=True):
+                    if fn.endswith("_traffic.json"):
+                        tj = json.load(open(os.path.join(tdir, fn)))
+                        if workload == "c3" and tj.get("source_bytes") == nbytes and name in tj["kernels"]:
+                            traffic = int(tj["kernels"][name]["fetch"] + tj["kernels"][name]["write"])
+                            break
+            except OSError:
+                pass
             roofline = {"bound": "hbm", "kernel": name, "achieved": round(a, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(a / HBM_PEAK_GBS, 5), "traffic": None, "avg_ms": round(avg_ms, 4),
+                        "frac": round(a / HBM_PEAK_GBS, 5), "traffic": traffic, "avg_ms": round(avg_ms, 4),
                         "launches_per_step": per_step, "algorithmic_bytes_per_launch": int(alg[stage_of(name)] / max(1.0, per_step))}
         cpu = None
         if world == 1 and not args.no_cpu:

@@ -43,4 +43,16 @@ with open(os.path.join("profiles", f"{tag}_summary.md"), "w") as f:
         fs = fetch[k][1] / fetch[k][0] / 1e3 if fetch[k][0] else float("nan")
         ws = write[k][1] / write[k][0] / 1e3 if write[k][0] else float("nan")
         f.write(f"| {k} | {r['Calls']} | {float(r['AverageNs']) / 1e6:.4f} | {float(r['Percentage']):.2f} | {fs:.1f} | {ws:.1f} |\n")
+# machine-readable per-launch traffic for bench.py's roofline.traffic (same workload only): bytes = FETCH_SIZE + WRITE_SIZE
+# as rocprofv3 reports them (KB -> B); the 2x correction of the guide applies to wide coalesced reads only and is NOT applied
+import json
+import re
+m = re.search(r"--bytes\s+(\S+)", " ".join(sys.argv[2:]))
+traffic = {"tag": tag, "source_bytes": int(float(m.group(1))) if m else None, "unit": "bytes per launch", "kernels": {}}
+for r in stats:
+    k = short(r["Name"])
+    if fetch[k][0] and write[k][0]:
+        name = k[2:] if k.startswith("k_") else k
+        traffic["kernels"][name] = {"fetch": fetch[k][1] / fetch[k][0] * 1e3, "write": write[k][1] / write[k][0] * 1e3, "avg_ms": float(r["AverageNs"]) / 1e6}
+json.dump(traffic, open(os.path.join("profiles", f"{tag}_traffic.json"), "w"), indent=1)
 print(open(os.path.join("profiles", f"{tag}_summary.md")).read())
