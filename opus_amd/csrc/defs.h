@@ -13,7 +13,7 @@
 #define OPUSFE_PARSE_WAVES 5
 #endif
 #ifndef OPUSFE_LOWER_WAVES
-#define OPUSFE_LOWER_WAVES 4
+#define OPUSFE_LOWER_WAVES 6
 #endif
 #ifdef OPUSFE_EMU
 #define MACHINE_ATTR(w)

@@ -50,13 +50,13 @@ struct LowerBuffers {
 // larger functions spill to the sparse global regions.  All lanes execute the same instruction stream on the same
 // addresses, so an LDS read is a broadcast and a global access touches one cache line.
 #ifndef OPUSFE_LDS_VARS
-#define OPUSFE_LDS_VARS 512
+#define OPUSFE_LDS_VARS 320
 #endif
 #ifndef OPUSFE_LDS_BBS
-#define OPUSFE_LDS_BBS 256
+#define OPUSFE_LDS_BBS 96
 #endif
 #ifndef OPUSFE_LDS_TYPES
-#define OPUSFE_LDS_TYPES 192
+#define OPUSFE_LDS_TYPES 64
 #endif
 enum { LDS_FRAMES = 32, LDS_VARS = OPUSFE_LDS_VARS, LDS_BBS = OPUSFE_LDS_BBS, LDS_LOCALS = 64, LDS_TYPES = OPUSFE_LDS_TYPES };
 struct LowerLds {
@@ -247,7 +247,7 @@ struct Lowerer {
     }
     __device__ uint32_t new_bb() {
         if (nbbs >= bcap) { internal(); return 0; }
-        if (nbbs < LDS_BBS) { lds.bbcnt[nbbs] = 0; lds.bblast[nbbs] = OPUSFE_NONE; } else { bbcnt[nbbs] = 0; bblast[nbbs] = OPUSFE_NONE; }
+        if (nbbs < LDS_BBS) { lds.bbcnt[nbbs] = 0; lds.bblast[nbbs] = OPUSFE_NONE; } else { gst(bbcnt + nbbs, 0u); gst(bblast + nbbs, (uint32_t)OPUSFE_NONE); }
         return nbbs++;
     }
     __device__ __forceinline__ uint32_t bb_last(uint32_t bb) const { return uni(bb < LDS_BBS ? lds.bblast[bb] : gld(bblast + bb)); }

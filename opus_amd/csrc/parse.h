@@ -22,6 +22,10 @@ namespace opusfe {
 enum { SI_NODE_BASE = 0, SI_NODE_COUNT, SI_DEF_COUNT, SI_FIRST_DEF, SI_ERR_KIND, SI_ERR_TOK, SI_ERR_LOW, SI_ERR_LEN, SI_ERR_EXPECTED,
        SI_END_TOK, SI_MAX_DEPTH, SI_WORDS = 12 };
 
+#ifndef OPUSFE_PARSE_LDS_FRAMES
+#define OPUSFE_PARSE_LDS_FRAMES 48
+#endif
+enum { PARSE_LDS_FRAMES = OPUSFE_PARSE_LDS_FRAMES };
 struct PFrame { uint8_t st; uint8_t aux; uint16_t cnt; uint32_t a, b, c; };
 static_assert(sizeof(PFrame) == 16, "frame is one 16-byte store");
 
@@ -70,7 +74,8 @@ struct SegParser {
     MACHINE_STATE STable<opusfe_token> tok;     // tokens are read-only here: scalar loads
 #endif
     MACHINE_STATE opusfe_node* nodes;     // sparse array
-    MACHINE_STATE PFrame* stack;
+    MACHINE_STATE PFrame* stack;          // frames deeper than PARSE_LDS_FRAMES (global memory)
+    MACHINE_STATE PFrame lframes[PARSE_LDS_FRAMES];   // the top of the frame stack lives in LDS
     MACHINE_STATE uint64_t nbase, ncap, fcap;
     MACHINE_STATE uint32_t i;          // next token to consume
     MACHINE_STATE bool peeked;         // token i has been lexed by the reference at this point (peek_token)
@@ -183,7 +188,8 @@ struct SegParser {
     __device__ __forceinline__ bool call(uint8_t entry, uint8_t resume) {
         cur.st = resume;
         if (sp + 1 >= fcap) { dev_status = DS_INTERNAL_CAPACITY; err_kind = 0x200u | DS_INTERNAL_CAPACITY; err_tok = tk(i); return false; }
-        stack[sp++] = cur;
+        if (sp < PARSE_LDS_FRAMES) lframes[sp] = cur; else gst(stack + sp, (PFrame)cur);
+        sp++;
         if (sp > max_sp) max_sp = sp;
         cur.st = entry; cur.aux = 0; cur.cnt = 0; cur.a = cur.b = cur.c = 0;
         return true;
@@ -191,7 +197,8 @@ struct SegParser {
     __device__ __forceinline__ void retn(uint32_t value) {
         ret = value;
         if (sp == 0) { dev_status = DS_INTERNAL_SEGMENT; cur.st = PS_ROOT; return; }
-        cur = stack[--sp];
+        --sp;
+        cur = sp < PARSE_LDS_FRAMES ? (PFrame)lframes[sp] : gld(stack + sp);
     }
 
     // Runs until the segment's tokens are used up or the first error.  Returns false on error.
