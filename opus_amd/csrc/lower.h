@@ -728,7 +728,10 @@ struct Lowerer {
             { const uint64_t t = __builtin_readcyclecounter(); prof[LP_STATE_CYCLES + step_state] += t - step_t0; prof[LP_STATE_STEPS + step_state]++; step_t0 = t; step_state = cur.st < 47 ? cur.st : 47; }
 #endif
             if (dev_status >= DS_INTERNAL_CAPACITY) return;
-            const opusfe_node nd = cur.node != OPUSFE_NONE ? N(cur.node) : opusfe_node{};
+            // the node of the current frame, loaded where a state uses it (several states never look at it; the loads are
+            // scalar and invariant, so repeated uses inside one state are merged by the compiler)
+            const uint32_t cnode = uni(cur.node);
+#define nd (cnode != OPUSFE_NONE ? N(cnode) : opusfe_node{})
             switch (cur.st) {
             case LS_DONE: goto finished;
             // ---- generate_ir_from_block (:189-203) ----
@@ -1238,6 +1241,7 @@ struct Lowerer {
             }
         } else report_node(SE_FunctionMightNotReturn, def);
 #undef CALL_E
+#undef nd
 #undef CALL_P
 #undef CALL_BLOCK
 #undef CALL_STMT

@@ -76,7 +76,7 @@ struct SegParser {
     MACHINE_STATE opusfe_node* nodes;     // sparse array
     MACHINE_STATE PFrame* stack;          // frames deeper than PARSE_LDS_FRAMES (global memory)
     MACHINE_STATE PFrame lframes[PARSE_LDS_FRAMES];   // the top of the frame stack lives in LDS
-    MACHINE_STATE uint64_t nbase, ncap, fcap;
+    MACHINE_STATE uint32_t nbase, ncap, fcap;     // (the host refuses units whose sparse regions do not fit 32-bit indices)
     MACHINE_STATE uint32_t i;          // next token to consume
     MACHINE_STATE bool peeked;         // token i has been lexed by the reference at this point (peek_token)
     MACHINE_STATE uint32_t position;   // parse.rs `position`: end of the last consumed token
@@ -95,7 +95,7 @@ struct SegParser {
     // still parsed by other lanes) a wrong index becomes an internal-error status, never a GPU memory fault.
     // (a reference into global memory: field reads and writes compile to global_load / global_store)
     __device__ __forceinline__ OPUSFE_GLOBAL opusfe_node& N(uint32_t id) {
-        uint64_t off = (uint64_t)id - nbase;
+        uint32_t off = id - nbase;
         if (off >= ncap) { dev_status = DS_INTERNAL_CAPACITY; off = ncap - 1; }   // last slot is a dummy
         return ((OPUSFE_GLOBAL opusfe_node*)nodes)[nbase + off];
     }
@@ -636,8 +636,8 @@ __global__ MACHINE_ATTR(OPUSFE_PARSE_WAVES) __launch_bounds__(64) void k_parse_s
     uint32_t tb = seg_start[s], te = (s + 1 < n_segs) ? seg_start[s + 1] : n_tokens;
     SegParser P;    // no fields of its own: the state is static LDS (see lower.h)
     P.tok.p = tok; P.nodes = nodes; P.n_tokens = n_tokens;
-    P.nbase = seg_node_base(tb, s); P.ncap = seg_node_cap(tb, te);
-    P.stack = frames + seg_frame_base(tb, s); P.fcap = seg_frame_cap(tb, te);
+    P.nbase = (uint32_t)seg_node_base(tb, s); P.ncap = (uint32_t)seg_node_cap(tb, te);
+    P.stack = frames + seg_frame_base(tb, s); P.fcap = (uint32_t)seg_frame_cap(tb, te);
     P.i = tb; P.peeked = false; P.position = tb > 0 ? P.end_at(tb - 1) : 0u;
     P.nn = 0; P.sp = 0; P.max_sp = 0; P.ret = OPUSFE_NONE;
     P.err_kind = OPUSFE_NONE; P.err_tok = 0; P.err_low = 0; P.err_len = 0; P.err_expected = 0; P.dev_status = DS_OK; P.unsup_pos = OPUSFE_NONE;
