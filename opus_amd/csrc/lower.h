@@ -689,18 +689,55 @@ struct Lowerer {
     __device__ __forceinline__ void push_raw(const LFrame& fr) { if (sp + 1 >= fcap) { internal(); return; } if (sp < LDS_FRAMES) lds.frames[sp] = fr; else gst(frames + sp, fr); sp++; }
     __device__ __forceinline__ LFrame pop_raw() { if (sp == 0) { internal(); return LFrame{}; } --sp; return uni(sp < LDS_FRAMES ? lds.frames[sp] : gld(frames + sp)); }
 
-    __device__ void p_finish(uint32_t var, bool lv) {
-        var = uni(var); lv = uni(lv);
-        if ((cur.aux & PF_MUSTLV) && !lv) { report_node(SE_InvalidLvalue, cur.f); var = generate_error(); }   // generate_pointer_from_expression :970-979
-        if (cur.aux & PF_DEREF) var = lv ? dereference_pointer(var) : var;                                   // :577-585
+    // result of a P frame with flags `aux` (f = node for InvalidLvalue) -> rv / rl
+    __device__ void p_result(uint32_t var, bool lv, uint8_t aux, uint32_t f) {
+        var = uni(var); lv = uni(lv); aux = uni(aux); f = uni(f);
+        if ((aux & PF_MUSTLV) && !lv) { report_node(SE_InvalidLvalue, f); var = generate_error(); }   // generate_pointer_from_expression :970-979
+        if (aux & PF_DEREF) var = lv ? dereference_pointer(var) : var;                             // :577-585
         rv = var; rl = lv;
-        retn();
+    }
+    __device__ __forceinline__ void p_finish(uint32_t var, bool lv) { p_result(var, lv, cur.aux, cur.f); retn(); }
+
+    // Leaves of the expression tree are lowered where their parent asks for them: no frame push / pop, no machine step.
+    // (Same code as the E_Variable case of LS_P and the E_Integer case of LS_E, which call these too.)
+    __device__ void p_variable(uint32_t node, uint8_t aux, uint32_t f) {
+        node = uni(node); aux = uni(aux); f = uni(f);
+        const opusfe_node vn = N(node);
+        const Looked lk = lookup_name(vn.payload, vn.low, vn.high, aux & 3);
+        if (lk.found) { p_result(lk.var, lk.lv, aux, f); return; }
+        // constant global (:993-998)
+        uint32_t ge = last_entry(key_tok(vn.payload), NK_GLOBAL);
+        uint32_t gid = S.entries[ge].kind_index & 0x3FFFFFFFu;
+        uint32_t v = new_var(S.globals[gid].type_id, true);
+        push(ins(I_GlobalConstant, v, 0, 0, gid));
+        p_result(v, false, aux, f);
+    }
+    __device__ uint32_t e_integer(uint32_t node, uint32_t expected) {
+        node = uni(node); expected = uni(expected);
+        const opusfe_token t = TK(N(node).payload);
+        uint32_t typ;
+        if (t.aux & 0x8000) {
+            uint32_t size = t.aux & 0xFF; bool sg = (t.aux & 0x100) != 0;
+            if (!sg) typ = size == 8 ? TP_Natural8 : size == 16 ? TP_Natural16 : size == 32 ? TP_Natural32 : size == 64 ? TP_Natural64 : TP_Size;
+            else typ = size == 8 ? TP_Integer8 : size == 16 ? TP_Integer16 : size == 32 ? TP_Integer32 : size == 64 ? TP_Integer64 : TP_Offset;
+        } else if (expected != OPUSFE_NONE && (kind_is_integral(trec(expected).kind) || trec(expected).kind == TY_GenericInteger)) typ = expected;
+        else typ = TP_Integer32;
+        uint64_t val = (t.flags & OPUSFE_TF_INLINE) ? (uint64_t)t.payload : S.val64[t.payload];
+        uint32_t v = new_var(typ, true);
+        push(ins(I_Integer, v, 0, 0, (uint32_t)val, (uint32_t)(val >> 32)));
+        return v;
     }
 
     // generate_ir_from_function (:133-174)
     __device__ void run(uint32_t body) {
-#define CALL_E(node, exp, resume) do { if (!call(LS_E, resume, node, 0, exp)) return; goto next; } while (0)
-#define CALL_P(node, ptflags, resume) do { if (!call(LS_P, resume, node, ptflags, 0, node)) return; goto next; } while (0)
+#define CALL_E(node, exp, resume) do { const uint32_t n_ = uni(node); \
+        if (n_ != OPUSFE_NONE) { const uint8_t k_ = N(n_).kind; \
+            if (k_ == E_Variable) { p_variable(n_, PT_Reference | PF_DEREF, n_); cur.st = resume; goto next; } \
+            if (k_ == E_Integer) { rv = e_integer(n_, exp); cur.st = resume; goto next; } } \
+        if (!call(LS_E, resume, n_, 0, exp)) return; goto next; } while (0)
+#define CALL_P(node, ptflags, resume) do { const uint32_t n_ = uni(node); \
+        if (n_ != OPUSFE_NONE && N(n_).kind == E_Variable) { p_variable(n_, ptflags, n_); cur.st = resume; goto next; } \
+        if (!call(LS_P, resume, n_, ptflags, 0, n_)) return; goto next; } while (0)
 #define CALL_BLOCK(node, resume) do { if (!call(LS_BLOCK, resume, node, 0, 0)) return; goto next; } while (0)
 #define CALL_STMT(node, resume) do { if (!call(LS_STMT, resume, node, 0, 0)) return; goto next; } while (0)
         const uint32_t def = F.def_node;
@@ -917,20 +954,7 @@ struct Lowerer {
             // ---- generate_ir_from_expression (:510-806); frame.a = expected type or NONE ----
             case LS_E:
                 switch (nd.kind) {
-                    case E_Integer: {
-                        const opusfe_token t = TK(nd.payload);
-                        uint32_t typ;
-                        if (t.aux & 0x8000) {
-                            uint32_t size = t.aux & 0xFF; bool sg = (t.aux & 0x100) != 0;
-                            if (!sg) typ = size == 8 ? TP_Natural8 : size == 16 ? TP_Natural16 : size == 32 ? TP_Natural32 : size == 64 ? TP_Natural64 : TP_Size;
-                            else typ = size == 8 ? TP_Integer8 : size == 16 ? TP_Integer16 : size == 32 ? TP_Integer32 : size == 64 ? TP_Integer64 : TP_Offset;
-                        } else if (cur.a != OPUSFE_NONE && (kind_is_integral(trec(cur.a).kind) || trec(cur.a).kind == TY_GenericInteger)) typ = cur.a;
-                        else typ = TP_Integer32;
-                        uint64_t val = (t.flags & OPUSFE_TF_INLINE) ? (uint64_t)t.payload : S.val64[t.payload];
-                        uint32_t v = new_var(typ, true);
-                        push(ins(I_Integer, v, 0, 0, (uint32_t)val, (uint32_t)(val >> 32)));
-                        rv = v; retn(); goto next;
-                    }
+                    case E_Integer: rv = e_integer(cnode, cur.a); retn(); goto next;
                     case E_Float: {
                         const opusfe_token t = TK(nd.payload);
                         uint64_t bits = S.val64[t.payload];
@@ -1078,16 +1102,7 @@ struct Lowerer {
             case LS_P: {
                 const uint8_t pt = cur.aux & 3;
                 switch (nd.kind) {
-                    case E_Variable: {
-                        const Looked lk = lookup_name(nd.payload, nd.low, nd.high, pt);
-                        if (lk.found) { p_finish(lk.var, lk.lv); goto next; }
-                        // constant global (:993-998)
-                        uint32_t ge = last_entry(key_tok(nd.payload), NK_GLOBAL);
-                        uint32_t gid = S.entries[ge].kind_index & 0x3FFFFFFFu;
-                        uint32_t v = new_var(S.globals[gid].type_id, true);
-                        push(ins(I_GlobalConstant, v, 0, 0, gid));
-                        p_finish(v, false); goto next;
-                    }
+                    case E_Variable: p_variable(cnode, cur.aux, cur.f); retn(); goto next;
                     case E_VariableDefinition: {
                         uint32_t var;
                         if (contains_local(nd.payload)) { report_node(SE_ShadowedName, cur.node); var = generate_error(); }
