@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo lets several ranks share one GPU (rehearsal only)")
     ap.add_argument("--cpu-sample-bytes", type=float, default=48e6)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--gen-flags", type=int, default=1, help="generator flags (bit 0: inject the three depth-1000 regions of BASELINE configs[2]); diagnostics only")
     args = ap.parse_args()
 
     import torch
@@ -91,7 +92,7 @@ def main():
     t0 = time.time()
     gen_threads = max(1, threads // max(1, min(world, 8))) if world > 1 else threads
     if workload == "c3":
-        src = O.generate(args.seed + 1000 * rank, nbytes, flags=1, threads=gen_threads)
+        src = O.generate(args.seed + 1000 * rank, nbytes, flags=args.gen_flags, threads=gen_threads)
     else:
         # rank r holds bytes [r*B + shift, (r+1)*B + shift) of ONE generated source of world*B bytes (rank 0 from byte 0):
         # the cuts fall in the middle of lines, strings and blocks on purpose

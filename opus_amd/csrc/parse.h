@@ -26,6 +26,10 @@ enum { SI_NODE_BASE = 0, SI_NODE_COUNT, SI_DEF_COUNT, SI_FIRST_DEF, SI_ERR_KIND,
 #define OPUSFE_PARSE_LDS_FRAMES 48
 #endif
 enum { PARSE_LDS_FRAMES = OPUSFE_PARSE_LDS_FRAMES };
+#ifndef OPUSFE_PARSE_RING
+#define OPUSFE_PARSE_RING 256
+#endif
+enum { PARSE_RING = OPUSFE_PARSE_RING };
 struct PFrame { uint8_t st; uint8_t aux; uint16_t cnt; uint32_t a, b, c; };
 static_assert(sizeof(PFrame) == 16, "frame is one 16-byte store");
 
@@ -66,6 +70,10 @@ enum PState : uint8_t {
     PS_BL_0, PS_BL_SINGLE, PS_BL_LOOP, PS_BL_ITEM
 };
 
+#ifdef OPUSFE_PARSE_PROF
+// optional cycle accounting per parser state (build with -DOPUSFE_PARSE_PROF): [0..63] cycles, [64..127] steps
+__device__ unsigned long long g_parse_prof[128];
+#endif
 struct SegParser {
     // registers of the machine: static LDS variables, one machine per workgroup (defs.h MACHINE_STATE)
 #ifdef OPUSFE_EMU
@@ -93,11 +101,23 @@ struct SegParser {
 
     // Every access is range checked: on malformed input (the part of a file after its first syntax error is
     // still parsed by other lanes) a wrong index becomes an internal-error status, never a GPU memory fault.
-    // (a reference into global memory: field reads and writes compile to global_load / global_store)
-    __device__ __forceinline__ OPUSFE_GLOBAL opusfe_node& N(uint32_t id) {
+    // The newest PARSE_RING nodes of the segment live in an LDS ring (write-back: a node goes to the sparse global array
+    // when its slot is reused, the rest when the segment is done).  A node is linked, spanned and rotated
+    // (correct_precedence) shortly after it is created: those reads and read-modify-writes used to be dependent global
+    // round trips on addresses the wave had just stored to.
+    MACHINE_STATE opusfe_node ring[PARSE_RING];
+#ifdef OPUSFE_PARSE_PROF
+    MACHINE_STATE uint32_t pprof[128];     // per state: cycles / 16, steps
+#endif
+    __device__ __forceinline__ opusfe_node& N(uint32_t id) {
         uint32_t off = id - nbase;
-        if (off >= ncap) { dev_status = DS_INTERNAL_CAPACITY; off = ncap - 1; }   // last slot is a dummy
-        return ((OPUSFE_GLOBAL opusfe_node*)nodes)[nbase + off];
+        if (off >= ncap) { dev_status = DS_INTERNAL_CAPACITY; return nodes[nbase + ncap - 1]; }   // last slot is a dummy
+        if (off < nn && nn - off <= PARSE_RING) return ring[off % PARSE_RING];
+        return nodes[nbase + off];
+    }
+    __device__ void flush_ring() {     // all lanes: the nodes still in the ring -> global
+        const uint32_t first = nn > PARSE_RING ? nn - PARSE_RING : 0u;
+        for (uint32_t j = first + threadIdx.x % UNIT_LANES; j < nn; j += UNIT_LANES) gst(&nodes[nbase + j], (opusfe_node)ring[j % PARSE_RING]);
     }
     __device__ __forceinline__ uint32_t tk(uint32_t k) const { return k < n_tokens ? k : n_tokens - 1; }   // clamps to EndOfFile
     __device__ __forceinline__ uint8_t kind_at(uint32_t k) const { return tok[tk(k)].kind; }
@@ -117,10 +137,11 @@ struct SegParser {
 
     __device__ __forceinline__ uint32_t new_node(uint8_t kind, uint8_t sub, uint32_t payload, uint32_t low) {
         if (nn + 1 >= ncap) { dev_status = DS_INTERNAL_CAPACITY; return (uint32_t)(nbase + ncap - 1); }
-        uint32_t id = (uint32_t)(nbase + nn++);
+        const uint32_t off = nn++;
+        if (off >= PARSE_RING) gst(&nodes[nbase + off - PARSE_RING], (opusfe_node)ring[off % PARSE_RING]);   // the slot's previous node leaves the ring
         opusfe_node n; n.kind = kind; n.sub = sub; n.nchild = 0; n.first_child = OPUSFE_NONE; n.next = OPUSFE_NONE; n.payload = payload; n.low = low; n.high = low;
-        gst(&nodes[id], n);
-        return id;
+        ring[off % PARSE_RING] = n;
+        return nbase + off;
     }
     // append `c` to the child list of cur.a (frame keeps last child in cur.c, count in cur.cnt)
     __device__ __forceinline__ void append(uint32_t c) {
@@ -168,19 +189,24 @@ struct SegParser {
     // parse.rs:837-869 (recursion on the new left child unrolled into a loop)
     __device__ void correct_precedence(uint32_t e) {
         e = uni(e);
-        for (;;) {
-            if (N(e).kind != E_Operator) return;
-            uint32_t L = N(e).first_child;
-            uint32_t r = N(L).next;
-            if (N(r).kind != E_Operator) return;
-            uint8_t oe = N(e).sub, orr = N(r).sub;
+        for (;;) {   // (no node is created here, so the references stay valid; each N() costs a range check and a ring lookup)
+            opusfe_node& ne = N(e);
+            if (ne.kind != E_Operator) return;
+            const uint32_t L = ne.first_child;
+            opusfe_node& nL = N(L);
+            const uint32_t r = nL.next;
+            opusfe_node& nr = N(r);
+            if (nr.kind != E_Operator) return;
+            const uint8_t oe = ne.sub, orr = nr.sub;
             if (op_prec(oe) < op_prec(orr)) return;
-            uint32_t RL = N(r).first_child, RR = N(RL).next;
-            uint32_t low = N(L).low, high = N(RL).high;
-            N(e).sub = orr; N(r).sub = oe;
-            N(r).first_child = L; N(L).next = RL; N(RL).next = OPUSFE_NONE;
-            N(e).first_child = r; N(r).next = RR; N(RR).next = OPUSFE_NONE;
-            N(r).low = low; N(r).high = high;
+            const uint32_t RL = nr.first_child;
+            opusfe_node& nRL = N(RL);
+            const uint32_t RR = nRL.next;
+            const uint32_t low = nL.low, high = nRL.high;
+            ne.sub = orr; nr.sub = oe;
+            nr.first_child = L; nL.next = RL; nRL.next = OPUSFE_NONE;
+            ne.first_child = r; nr.next = RR; N(RR).next = OPUSFE_NONE;
+            nr.low = low; nr.high = high;
             e = r;
         }
     }
@@ -209,8 +235,15 @@ struct SegParser {
         uint32_t last_def = OPUSFE_NONE;
         *first_def = OPUSFE_NONE; *def_count = 0;
         cur.st = PS_ROOT; cur.aux = 0; cur.cnt = 0; cur.a = cur.b = cur.c = 0;
+#ifdef OPUSFE_PARSE_PROF
+        uint64_t step_t0 = __builtin_readcyclecounter(); uint32_t step_state = 63;
+#endif
         for (;;) {
             uint8_t k;
+#ifdef OPUSFE_PARSE_PROF
+            { const uint64_t t = __builtin_readcyclecounter(); pprof[step_state] += (uint32_t)((t - step_t0) >> 4); pprof[64 + step_state]++;   // LDS, flushed once per segment
+              step_t0 = __builtin_readcyclecounter(); step_state = cur.st < 63 ? cur.st : 63; }
+#endif
             if (dev_status >= DS_INTERNAL_CAPACITY) { err_kind = 0x200u | dev_status; err_tok = tk(i); return false; }
             switch (cur.st) {
             // ---- frontend.rs:125-135: while !parser.is_at_end_of_file() { parse_definition()? } ----
@@ -530,10 +563,11 @@ struct SegParser {
             }
             case PS_EX_2: {
                 uint32_t left = cur.b, right = ret;
-                uint32_t e = new_node(E_Operator, cur.aux, 0, N(left).low);
-                N(e).first_child = left; N(left).next = right; N(right).next = OPUSFE_NONE; N(e).nchild = 2;
+                const uint32_t e = new_node(E_Operator, cur.aux, 0, N(left).low);
+                opusfe_node& ne = N(e);                // (taken after new_node: creating a node may reuse a ring slot)
+                ne.first_child = left; N(left).next = right; N(right).next = OPUSFE_NONE; ne.nchild = 2;
                 correct_precedence(e);
-                N(e).high = position;
+                ne.high = position;
                 retn(e);
                 goto next;
             }
@@ -642,11 +676,18 @@ __global__ MACHINE_ATTR(OPUSFE_PARSE_WAVES) __launch_bounds__(64) void k_parse_s
     P.nn = 0; P.sp = 0; P.max_sp = 0; P.ret = OPUSFE_NONE;
     P.err_kind = OPUSFE_NONE; P.err_tok = 0; P.err_low = 0; P.err_len = 0; P.err_expected = 0; P.dev_status = DS_OK; P.unsup_pos = OPUSFE_NONE;
     { opusfe_node d{}; d.kind = X_Block; d.first_child = OPUSFE_NONE; d.next = OPUSFE_NONE; nodes[P.nbase + P.ncap - 1] = d; }
+#ifdef OPUSFE_PARSE_PROF
+    for (uint32_t j = lane; j < 128; j += UNIT_LANES) P.pprof[j] = 0;
+#endif
     uint32_t first_def, def_count;
     bool ok = P.run(te, &first_def, &def_count);
+#ifdef OPUSFE_PARSE_PROF
+    for (uint32_t j = lane; j < 128; j += UNIT_LANES) if (P.pprof[j]) atomicAdd(&g_parse_prof[j], (unsigned long long)P.pprof[j]);
+#endif
     if (ok && P.i != te) {   // a definition straddled a segment boundary: the segmentation rule did not hold
         ok = false; P.err_kind = 0x200u | DS_INTERNAL_SEGMENT; P.err_tok = P.tk(P.i);
     }
+    P.flush_ring();
     if (lane != 0) return;
     uint32_t* si = seg_info + (uint64_t)s * SI_WORDS;
     si[SI_NODE_BASE] = 0; si[SI_NODE_COUNT] = P.nn; si[SI_DEF_COUNT] = def_count; si[SI_FIRST_DEF] = first_def;
@@ -755,6 +796,18 @@ inline void run_parser(opusfe_ctx* ctx, opusfe_unit* u) {
     HIP_TRY(hipMemcpyAsync(ctx->d_status + WP_FIRST_ERR, init, sizeof init, hipMemcpyHostToDevice, st));
     LAUNCH(ctx, "parse_segments", k_parse_segments, grid_for((uint64_t)n_segs * UNIT_LANES, 64), 64, u->d_tokens, n_tok, u->d_seg_start, n_segs, sparse, frames,
            u->d_seg_info, ctx->d_status, ctx->d_status + WP_FIRST_ERR);
+#ifdef OPUSFE_PARSE_PROF
+    {
+        unsigned long long h[128];
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_parse_prof), sizeof h));
+        unsigned long long z[128] = {0};
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_parse_prof), z, sizeof z));
+        double tot = 0; for (int i = 0; i < 64; i++) tot += (double)h[i];
+        fprintf(stderr, "parser cycle accounting per state (index into enum PState): share, steps, cycles per step\n");
+        for (int i = 0; i < 64; i++) if (h[64 + i]) fprintf(stderr, "  state %2d  %5.1f%%  %12llu steps  %8.0f cycles/step\n", i, 100.0 * h[i] / tot, h[64 + i], 16.0 * (double)h[i] / (double)h[64 + i]);
+    }
+#endif
     LAUNCH(ctx, "ast_counts", k_ast_counts, grid_for(n_segs, 256), 256, u->d_seg_info, n_segs, cnt);
     prof_begin(ctx, "ast_scan");
     device_scan<true>(cnt, cnt, n_segs, OpAddCnt2(), Cnt2{0, 0}, scan_tmp, (Cnt2*)(ctx->d_status + WP_TOTALS), st);
