@@ -334,12 +334,12 @@ struct SegParser {
             case PS_DEF_VAR_1:
                 append(ret);
                 TRY(peek(&k));
-                if (k == T_Equals) { consume(); CALL(PS_EX_0, PS_DEF_FIN); }
+                if (k == T_Equals) { consume(); do { if (!call(PS_EX_0, PS_DEF_FIN)) return false; goto l_ex_0; } while (0); }
                 finish(cur.a); retn(cur.a); goto next;
             case PS_DEF_CONST_1:
                 append(ret);
                 TRY(expect(T_Equals));
-                CALL(PS_EX_0, PS_DEF_FIN);
+                do { if (!call(PS_EX_0, PS_DEF_FIN)) return false; goto l_ex_0; } while (0);
             case PS_DEF_FIN: append(ret); finish(cur.a); retn(cur.a); goto next;
 
             // ---- parse_type  parse.rs:899-969 ----
@@ -396,7 +396,7 @@ struct SegParser {
                 TRY(peek(&k));
                 if (k == T_RightParenthesis) {
                     consume();
-                    if (cur.b == 1) { cur.st = PS_AT_POST; goto next; }
+                    if (cur.b == 1) { goto l_at_post; }
                     CALL(PS_TY_0, PS_TY_WRAP);
                 }
                 if (!saw_comma) return fail(PE_UnexpectedToken, low_at(i), end_at(i), i);
@@ -416,35 +416,35 @@ struct SegParser {
             case PS_TY_REC_ITEM: wrap_single(cur.b, ret); cur.st = PS_TY_REC_LOOP; goto next;
 
             // ---- parse_atom  parse.rs:971-1124 ----
-            case PS_AT_0: {
+            case PS_AT_0: l_at_0: {
                 k = kind_at(i);
                 if (k == T_Error) return fail_lex(i);
                 consume();
                 uint32_t low = low_at(i - 1);
                 uint32_t name;
                 switch (k) {
-                    case T_Integer: cur.a = new_node(E_Integer, 0, i - 1, low); cur.st = PS_AT_POST; goto next;
-                    case T_Float: cur.a = new_node(E_Float, 0, i - 1, low); cur.st = PS_AT_POST; goto next;
-                    case T_String: cur.a = new_node(E_String, 0, i - 1, low); cur.st = PS_AT_POST; goto next;
-                    case T_Identifier: cur.a = new_node(E_Variable, 0, i - 1, low); cur.st = PS_AT_POST; goto next;
-                    case T_LeftParenthesis: cur.a = new_node(E_Parentheses, 0, 0, low); CALL(PS_EX_0, PS_AT_PAREN);
-                    case T_Minus: cur.a = new_node(E_Negate, 0, 0, low); CALL(PS_AT_0, PS_AT_PREFIX);
-                    case T_Ref: cur.a = new_node(E_Reference, 0, 0, low); CALL(PS_AT_0, PS_AT_PREFIX);
-                    case T_Mut: cur.a = new_node(E_MutableReference, 0, 0, low); CALL(PS_AT_0, PS_AT_PREFIX);
-                    case T_Refs: cur.a = new_node(E_ArrayReference, 0, 0, low); CALL(PS_AT_0, PS_AT_PREFIX);
-                    case T_Muts: cur.a = new_node(E_MutableArrayReference, 0, 0, low); CALL(PS_AT_0, PS_AT_PREFIX);
+                    case T_Integer: cur.a = new_node(E_Integer, 0, i - 1, low); goto l_at_post;
+                    case T_Float: cur.a = new_node(E_Float, 0, i - 1, low); goto l_at_post;
+                    case T_String: cur.a = new_node(E_String, 0, i - 1, low); goto l_at_post;
+                    case T_Identifier: cur.a = new_node(E_Variable, 0, i - 1, low); goto l_at_post;
+                    case T_LeftParenthesis: cur.a = new_node(E_Parentheses, 0, 0, low); do { if (!call(PS_EX_0, PS_AT_PAREN)) return false; goto l_ex_0; } while (0);
+                    case T_Minus: cur.a = new_node(E_Negate, 0, 0, low); do { if (!call(PS_AT_0, PS_AT_PREFIX)) return false; goto l_at_0; } while (0);
+                    case T_Ref: cur.a = new_node(E_Reference, 0, 0, low); do { if (!call(PS_AT_0, PS_AT_PREFIX)) return false; goto l_at_0; } while (0);
+                    case T_Mut: cur.a = new_node(E_MutableReference, 0, 0, low); do { if (!call(PS_AT_0, PS_AT_PREFIX)) return false; goto l_at_0; } while (0);
+                    case T_Refs: cur.a = new_node(E_ArrayReference, 0, 0, low); do { if (!call(PS_AT_0, PS_AT_PREFIX)) return false; goto l_at_0; } while (0);
+                    case T_Muts: cur.a = new_node(E_MutableArrayReference, 0, 0, low); do { if (!call(PS_AT_0, PS_AT_PREFIX)) return false; goto l_at_0; } while (0);
                     case T_Var:
                         TRY(parse_identifier(&name));
                         cur.a = new_node(E_VariableDefinition, 0, name, low);
                         CALL(PS_TY_0, PS_AT_PREFIX);
-                    case T_Null: cur.a = new_node(E_Null, 0, 0, low); cur.st = PS_AT_POST; goto next;
-                    case T_False: cur.a = new_node(E_Bool, 0, 0, low); cur.st = PS_AT_POST; goto next;
-                    case T_True: cur.a = new_node(E_Bool, 1, 0, low); cur.st = PS_AT_POST; goto next;
+                    case T_Null: cur.a = new_node(E_Null, 0, 0, low); goto l_at_post;
+                    case T_False: cur.a = new_node(E_Bool, 0, 0, low); goto l_at_post;
+                    case T_True: cur.a = new_node(E_Bool, 1, 0, low); goto l_at_post;
                     case T_Not: {
                         cur.a = new_node(E_Operator, OP_Not, 0, low);
                         uint32_t nul = new_node(E_Null, 0, 0, low);      // virtual Null, empty span at `not` (parse.rs:1032)
                         append(nul);
-                        CALL(PS_EX_0, PS_AT_NOT);
+                        do { if (!call(PS_EX_0, PS_AT_NOT)) return false; goto l_ex_0; } while (0);
                     }
                     case T_Sizeof: cur.a = new_node(E_Sizeof, 0, 0, low); CALL(PS_TY_0, PS_AT_PREFIX);
                     case T_Alignof: cur.a = new_node(E_Alignof, 0, 0, low); CALL(PS_TY_0, PS_AT_PREFIX);
@@ -467,8 +467,8 @@ struct SegParser {
                     default: return fail(PE_UnexpectedToken, low, position, i - 1);
                 }
             }
-            case PS_AT_PAREN: append(ret); TRY(expect(T_RightParenthesis)); cur.st = PS_AT_POST; goto next;
-            case PS_AT_PREFIX: append(ret); cur.st = PS_AT_POST; goto next;
+            case PS_AT_PAREN: append(ret); TRY(expect(T_RightParenthesis)); goto l_at_post;
+            case PS_AT_PREFIX: append(ret); goto l_at_post;
             case PS_AT_NOT:   // parse.rs:1027-1038: returns immediately, no postfix loop
                 append(ret);
                 N(cur.a).nchild = 2;
@@ -485,14 +485,15 @@ struct SegParser {
                     append(fi);
                     cur.b = fi;
                     TRY(expect(T_Equals));
-                    CALL(PS_EX_0, PS_AT_REC_ITEM);
+                    do { if (!call(PS_EX_0, PS_AT_REC_ITEM)) return false; goto l_ex_0; } while (0);
                 }
-                if (k == T_RightBrace) { cur.st = PS_AT_POST; goto next; }
+                if (k == T_RightBrace) { goto l_at_post; }
                 return fail(PE_UnexpectedToken, low_at(i - 1), position, i - 1);
             }
             case PS_AT_REC_ITEM: wrap_single(cur.b, ret); cur.st = PS_AT_REC_LOOP; goto next;
-            case PS_AT_POST: finish(cur.a); cur.st = PS_AT_POST_LOOP; goto next;
-            case PS_AT_POST_LOOP: {   // parse.rs:1087-1121
+            // (states that always continue in one known state jump there directly instead of going through the dispatch)
+            case PS_AT_POST: l_at_post: finish(cur.a);
+            case PS_AT_POST_LOOP: l_at_post_loop: {   // parse.rs:1087-1121
                 TRY(peek(&k));
                 uint32_t low = N(cur.a).low;
                 if (k == T_At) {
@@ -500,7 +501,7 @@ struct SegParser {
                     uint32_t w = new_node(E_Dereference, 0, 0, low);
                     wrap_single(w, cur.a);
                     cur.a = w;
-                    goto next;
+                    goto l_at_post_loop;
                 }
                 if (k == T_Dot) {
                     consume();
@@ -509,7 +510,7 @@ struct SegParser {
                     uint32_t w = new_node(E_Field, 0, name, low);
                     wrap_single(w, cur.a);
                     cur.a = w;
-                    goto next;
+                    goto l_at_post_loop;
                 }
                 if (k == T_LeftParenthesis) {
                     consume();
@@ -544,22 +545,22 @@ struct SegParser {
                     if (saw_comma) consume();
                 }
                 TRY(peek(&k));
-                if (k == T_RightParenthesis) { consume(); finish(cur.a); cur.st = PS_AT_POST_LOOP; goto next; }
+                if (k == T_RightParenthesis) { consume(); finish(cur.a); goto l_at_post_loop; }
                 if (!saw_comma) return fail(PE_UnexpectedToken, low_at(i), end_at(i), i);
-                CALL(PS_EX_0, PS_AT_CALL_ITEM);
+                do { if (!call(PS_EX_0, PS_AT_CALL_ITEM)) return false; goto l_ex_0; } while (0);
             }
             case PS_AT_CALL_ITEM: append(ret); cur.st = PS_AT_CALL_LIST; cur.aux = 1; goto next;
-            case PS_AT_CAST: append(ret); finish(cur.a); cur.st = PS_AT_POST_LOOP; goto next;
+            case PS_AT_CAST: append(ret); finish(cur.a); goto l_at_post_loop;
 
             // ---- parse_expression  parse.rs:815-835 ----
-            case PS_EX_0: CALL(PS_AT_0, PS_EX_1);
+            case PS_EX_0: l_ex_0: if (!call(PS_AT_0, PS_EX_1)) return false; goto l_at_0;
             case PS_EX_1: {
                 TRY(peek(&k));
                 uint8_t op = binop_of(k);
                 if (op == OP_None) { retn(ret); goto next; }
                 consume();
                 cur.b = ret; cur.aux = op;
-                CALL(PS_EX_0, PS_EX_2);
+                do { if (!call(PS_EX_0, PS_EX_2)) return false; goto l_ex_0; } while (0);
             }
             case PS_EX_2: {
                 uint32_t left = cur.b, right = ret;
@@ -586,14 +587,14 @@ struct SegParser {
                         if (k2 == T_Equals) {
                             consume();
                             cur.a = new_node(S_VariableDefinition, 0, name, low);
-                            CALL(PS_EX_0, PS_ST_FIN1);
+                            do { if (!call(PS_EX_0, PS_ST_FIN1)) return false; goto l_ex_0; } while (0);
                         }
                         cur.a = new_node(S_Expression, 0, name, low);   // kind / payload fixed in PS_ST_VAR_T
                         CALL(PS_TY_0, PS_ST_VAR_T);
                     }
-                    case T_Return: consume(); cur.a = new_node(S_Return, 0, 0, low); CALL(PS_EX_0, PS_ST_FIN1);
-                    case T_If: consume(); cur.a = new_node(S_If, 0, 0, low); CALL(PS_EX_0, PS_ST_IF_1);
-                    case T_While: consume(); cur.a = new_node(S_While, 0, 0, low); CALL(PS_EX_0, PS_ST_IF_1);
+                    case T_Return: consume(); cur.a = new_node(S_Return, 0, 0, low); do { if (!call(PS_EX_0, PS_ST_FIN1)) return false; goto l_ex_0; } while (0);
+                    case T_If: consume(); cur.a = new_node(S_If, 0, 0, low); do { if (!call(PS_EX_0, PS_ST_IF_1)) return false; goto l_ex_0; } while (0);
+                    case T_While: consume(); cur.a = new_node(S_While, 0, 0, low); do { if (!call(PS_EX_0, PS_ST_IF_1)) return false; goto l_ex_0; } while (0);
                     case T_For: {
                         consume();
                         TRY(parse_identifier(&name));
@@ -602,11 +603,11 @@ struct SegParser {
                         TRY(peek(&k2));
                         if (k2 != T_In) { N(cur.a).sub = 1; CALL(PS_TY_0, PS_ST_FOR_T); }
                         TRY(expect(T_In));
-                        CALL(PS_EX_0, PS_ST_IF_1);
+                        do { if (!call(PS_EX_0, PS_ST_IF_1)) return false; goto l_ex_0; } while (0);
                     }
                     case T_Break: consume(); cur.a = new_node(S_Break, 0, 0, low); N(cur.a).high = position; retn(cur.a); goto next;
                     case T_Continue: consume(); cur.a = new_node(S_Continue, 0, 0, low); N(cur.a).high = position; retn(cur.a); goto next;
-                    default: cur.a = new_node(S_Expression, 0, 0, low); CALL(PS_EX_0, PS_ST_EXPR_1);
+                    default: cur.a = new_node(S_Expression, 0, 0, low); do { if (!call(PS_EX_0, PS_ST_EXPR_1)) return false; goto l_ex_0; } while (0);
                 }
             }
             case PS_ST_FIN1: append(ret); finish(cur.a); retn(cur.a); goto next;
@@ -617,10 +618,10 @@ struct SegParser {
                 N(cur.a).payload = 0;
                 append(vd);
                 TRY(peek(&k));
-                if (k == T_Equals) { consume(); N(cur.a).kind = S_Assignment; CALL(PS_EX_0, PS_ST_FIN1); }
+                if (k == T_Equals) { consume(); N(cur.a).kind = S_Assignment; do { if (!call(PS_EX_0, PS_ST_FIN1)) return false; goto l_ex_0; } while (0); }
                 finish(cur.a); retn(cur.a); goto next;
             }
-            case PS_ST_FOR_T: append(ret); TRY(expect(T_In)); CALL(PS_EX_0, PS_ST_IF_1);
+            case PS_ST_FOR_T: append(ret); TRY(expect(T_In)); do { if (!call(PS_EX_0, PS_ST_IF_1)) return false; goto l_ex_0; } while (0);
             case PS_ST_IF_1: append(ret); CALL(PS_BL_0, PS_ST_IF_2);
             case PS_ST_IF_2: {
                 append(ret);
@@ -636,7 +637,7 @@ struct SegParser {
             case PS_ST_EXPR_1:
                 append(ret);
                 TRY(peek(&k));
-                if (k == T_Equals) { consume(); N(cur.a).kind = S_Assignment; CALL(PS_EX_0, PS_ST_FIN1); }
+                if (k == T_Equals) { consume(); N(cur.a).kind = S_Assignment; do { if (!call(PS_EX_0, PS_ST_FIN1)) return false; goto l_ex_0; } while (0); }
                 finish(cur.a); retn(cur.a); goto next;
 
             // ---- parse_block  parse.rs:1238-1260 ----
