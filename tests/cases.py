@@ -95,3 +95,26 @@ IR_CASES = [
     # finalize errors: no IR
     "f(a Undefined) null\n\treturn null\n", "var g int32 = 1 + 2\n", "var g bool = 1\n", "type A = Undefined\n",
 ]
+
+
+def big_function(n_locals=150, n_ifs=140, chain=90, depth=70):
+    """One function that overflows every LDS-resident table of the lowering machine (scope table 64, variable types 320,
+    basic blocks 96, own types 64, frame stack 32) and of the parser (frame stack 48, node ring 256): the spill paths to the
+    sparse global regions must give the same IR as the oracle."""
+    L = ["big(a int32, b int64) int32"]
+    for i in range(n_locals):
+        L.append(f"\tvar v{i} = a + {i}")
+    for i in range(n_ifs):
+        L.append(f"\tif v{i % n_locals} < v{(i * 7 + 3) % n_locals}")
+        L.append(f"\t\tv{(i * 5) % n_locals} = v{(i * 11) % n_locals} * {i + 1} - a")
+        L.append("\telse")
+        L.append(f"\t\tv{(i * 3) % n_locals} = v{i % n_locals} % {i + 2}")
+    L.append("\tvar s = " + " + ".join(f"v{i % n_locals} * {i}" for i in range(chain)))
+    L.append("\tvar d = " + "(" * depth + "a" + " + 1)" * depth)
+    L.append("\twhile s < d")
+    for i in range(40):
+        L.append(f"\t\tvar w{i} = mut v{i}")
+        L.append(f"\t\tw{i}@ = w{i}@ + s")
+    L.append("\t\ts = s + 1")
+    L.append("\treturn s + d")
+    return "\n".join(L) + "\n"

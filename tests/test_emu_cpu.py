@@ -6,7 +6,7 @@ import pytest
 
 import emu_lib as E
 import oracle_lib as O
-from cases import IR_CASES, LEX_CASES, PARSE_CASES
+from cases import IR_CASES, LEX_CASES, PARSE_CASES, big_function
 
 
 def compare_parse(cases):
@@ -84,3 +84,8 @@ def test_emu_ir_hand_cases():
 
 def test_emu_ir_generated_and_deep():
     compare_ir([O.generate(1, 4096), O.generate(2, 70000), O.generate(3, 2 << 20, flags=1)])
+
+
+def test_emu_ir_big_function_spill_paths():
+    """every LDS-resident table of the two machines overflows into its sparse global region (AddressSanitizer watches)"""
+    compare_ir([big_function().encode(), big_function(70, 40, 300, 20).encode()])

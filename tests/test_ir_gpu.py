@@ -6,7 +6,7 @@ import os
 import pytest
 
 import oracle_lib as O
-from cases import IR_CASES, PARSE_CASES
+from cases import IR_CASES, PARSE_CASES, big_function as _big_function
 
 pytestmark = pytest.mark.gpu
 
@@ -86,3 +86,20 @@ def test_lowering_twice_is_idempotent(fe):
     a = u.dump_ir()
     assert u.compile_source() == 0
     assert u.dump_ir() == a == O.dump(src, O.IR)
+
+
+def test_ir_big_function_spills_every_lds_table(fe):
+    src = _big_function().encode()
+    u = check_ir(fe, src)
+    assert u is not None, "the stress source must be well formed"
+    c = u.counts()
+    assert c["vars"] > 1500 and c["bbs"] > 300, c
+
+
+def test_ir_many_big_functions(fe):
+    """several oversized functions side by side (one wave each) plus small ones in between"""
+    parts = []
+    for j in range(6):
+        parts.append(_big_function(80 + 20 * j, 100 + 10 * j, 60, 40).replace("big(", f"big{j}("))
+        parts.append(f"small{j}(x int32) int32\n\treturn x + {j}\n")
+    check_ir(fe, "".join(parts).encode())
