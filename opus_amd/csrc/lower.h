@@ -220,8 +220,7 @@ struct Lowerer {
     __device__ void report_tok(uint32_t kind, uint32_t t) { kind = uni(kind); t = uni(t); const opusfe_token x = TK(t); report(kind, x.low, x.low + x.len); }
 
     // ---- variables / instructions / blocks (generate_ir.rs:118-131) -------------------------------
-    __device__ uint32_t new_var(uint32_t type_id, bool is_temporary) {
-        type_id = uni(type_id); is_temporary = uni(is_temporary);
+    __device__ __forceinline__ uint32_t new_var(uint32_t type_id, bool is_temporary) {
         LPROF(LP_NEWVAR);
         if (nvars >= vcap) { internal(); return 0; }
         gst(vars + nvars, opusfe_variable{type_id, is_temporary ? 1u : 0u});
