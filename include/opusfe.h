@@ -111,7 +111,8 @@ int opusfe_lex(opusfe_ctx* ctx, const uint8_t* src, uint64_t len, int force_dent
 
 /* corpus of independent files (one reference run per file, frontend.rs:23-118 without imports): parses (and lowers when
    `lower` != 0) every file; units[i] / statuses[i] receive the unit and its return code; the call itself only fails on
-   device / argument errors.  Each unit is released with opusfe_free_unit. */
+   device / argument errors.  Several files are in flight at a time on worker contexts owned by `ctx` (host threads,
+   OPUSFE_BATCH_WORKERS, default 8): release every unit with opusfe_free_unit before opusfe_destroy(ctx). */
 int opusfe_parse_batch(opusfe_ctx* ctx, uint32_t n, const uint8_t* const* srcs, const uint64_t* lens, int lower,
                        opusfe_unit** units, int* statuses);
 

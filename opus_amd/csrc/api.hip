@@ -1,5 +1,7 @@
 // libopusfe: C ABI entry points (include/opusfe.h) and host drivers of the HIP pipeline.
 #include <hip/hip_runtime.h>
+#include <atomic>
+#include <thread>
 #include "defs.h"
 #include "runtime.h"
 #include "unit.h"
@@ -337,6 +339,8 @@ int opusfe_create(opusfe_ctx** out, int device) {
 
 void opusfe_destroy(opusfe_ctx* ctx) {
     if (!ctx) return;
+    for (opusfe_ctx* w : ctx->workers) opusfe_destroy(w);
+    ctx->workers.clear();
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& kv : ctx->free_blocks) (void)hipFree(kv.second);
@@ -406,24 +410,55 @@ int opusfe_parse_device(opusfe_ctx* ctx, const uint8_t* d_src, uint64_t len, opu
 }
 
 int opusfe_lower(opusfe_ctx* ctx, opusfe_unit* unit) {
-    if (!unit || unit->ctx != ctx) return OPUSFE_ERR_ARG;
+    if (!unit || !ctx) return OPUSFE_ERR_ARG;
+    opusfe_ctx* owner = unit->ctx;       // a unit made by opusfe_parse_batch belongs to one of ctx's worker contexts
+    if (owner != ctx) {
+        bool mine = false;
+        for (opusfe_ctx* w : ctx->workers) mine = mine || w == owner;
+        if (!mine) return OPUSFE_ERR_ARG;
+    }
     if (!unit->parsed || unit->status != OPUSFE_OK) return fail(ctx, OPUSFE_ERR_ARG, "opusfe_lower needs a successfully parsed unit");
-    return guarded(ctx, [&] { run_lower(ctx, unit); return unit->status; });
+    int rc = guarded(owner, [&] { run_lower(owner, unit); return unit->status; });
+    if (owner != ctx) ctx->msg = owner->msg;
+    return rc;
 }
 
 // Corpus of independent files (BASELINE config 5): every file is its own compilation universe like one run of the
-// reference (frontend.rs:52-55).  Round-1 implementation: the files go through the single-source pipeline one after
-// the other on ctx's stream (launch-bound for small files; a segmented multi-file pipeline is DESIGN.md §8 work).
+// reference (frontend.rs:52-55).  Round-1 implementation: every file goes through the single-source pipeline, several
+// files at a time on worker contexts (a segmented multi-file pipeline with one launch per stage is DESIGN.md §8 work).
 int opusfe_parse_batch(opusfe_ctx* ctx, uint32_t n, const uint8_t* const* srcs, const uint64_t* lens, int lower, opusfe_unit** units, int* statuses) {
     if (!ctx || (n && (!srcs || !lens || !units || !statuses))) return OPUSFE_ERR_ARG;
-    int worst = OPUSFE_OK;
-    for (uint32_t i = 0; i < n; i++) {
-        units[i] = nullptr;
-        int rc = opusfe_parse(ctx, srcs[i], lens[i], &units[i]);
-        if (rc == OPUSFE_OK && lower) rc = opusfe_lower(ctx, units[i]);
-        statuses[i] = rc;
-        if (rc >= OPUSFE_ERR_HIP && rc != OPUSFE_SEMANTIC) worst = rc;
+    // A small file keeps only a few waves busy and its per-function / per-segment machines are sequential, so one file
+    // after the other is latency-bound (milliseconds per file whatever its size).  Files are independent: W host threads,
+    // each with a context (stream, allocator) of its own, run the single-source pipeline on different files at once.
+    uint32_t want = 8;
+    if (const char* e = getenv("OPUSFE_BATCH_WORKERS")) { int v = atoi(e); if (v >= 1 && v <= 64) want = (uint32_t)v; }
+    const uint32_t W = n < want ? (n ? n : 1) : want;
+    while (ctx->workers.size() + 1 < W) {
+        opusfe_ctx* w = nullptr;
+        int rc = opusfe_create(&w, ctx->device);
+        if (rc != OPUSFE_OK) { ctx->msg = "opusfe_parse_batch: cannot create a worker context"; return rc; }
+        ctx->workers.push_back(w);
     }
+    for (uint32_t i = 0; i < n; i++) { units[i] = nullptr; statuses[i] = OPUSFE_ERR_INTERNAL; }
+    std::atomic<uint32_t> next{0};
+    auto work = [&](opusfe_ctx* c) {
+        (void)hipSetDevice(c->device);
+        for (;;) {
+            const uint32_t i = next.fetch_add(1);
+            if (i >= n) break;
+            int rc = opusfe_parse(c, srcs[i], lens[i], &units[i]);
+            if (rc == OPUSFE_OK && lower) rc = opusfe_lower(c, units[i]);
+            statuses[i] = rc;
+        }
+    };
+    std::vector<std::thread> threads;
+    for (uint32_t w = 1; w < W; w++) threads.emplace_back(work, ctx->workers[w - 1]);
+    work(ctx);
+    for (auto& t : threads) t.join();
+    int worst = OPUSFE_OK;
+    for (uint32_t i = 0; i < n; i++) if (statuses[i] >= OPUSFE_ERR_HIP && statuses[i] != OPUSFE_SEMANTIC) worst = statuses[i];
+    if (worst != OPUSFE_OK) ctx->msg = "opusfe_parse_batch: a file failed with a device / argument error (see statuses)";
     return worst;
 }
 

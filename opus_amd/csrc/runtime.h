@@ -32,6 +32,9 @@ struct opusfe_ctx {
     std::vector<hipEvent_t> event_pool;
     uint32_t* d_status = nullptr;   // DevStatus word + scratch totals (64 words)
     uint32_t* h_status = nullptr;   // pinned mirror
+    // opusfe_parse_batch: worker contexts (own stream and allocator each) owned by this context; units they created
+    // are released before the context is destroyed
+    std::vector<opusfe_ctx*> workers;
 };
 
 namespace opusfe {
