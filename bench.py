@@ -90,7 +90,8 @@ def main():
     nbytes = int(args.bytes)
     threads = min(16, os.cpu_count() or 8)
     t0 = time.time()
-    gen_threads = max(1, threads // max(1, min(world, 8))) if world > 1 else threads
+    # N ranks generate at the same time: share the host's cores (os.cpu_count() is the whole machine on the GPU boxes)
+    gen_threads = max(2, min(16, (os.cpu_count() or 16) // world)) if world > 1 else threads
     if workload == "c3":
         src = O.generate(args.seed + 1000 * rank, nbytes, flags=args.gen_flags, threads=gen_threads)
     else:
