@@ -50,7 +50,7 @@ struct LowerBuffers {
 // larger functions spill to the sparse global regions.  All lanes execute the same instruction stream on the same
 // addresses, so an LDS read is a broadcast and a global access touches one cache line.
 #ifndef OPUSFE_LDS_VARS
-#define OPUSFE_LDS_VARS 320
+#define OPUSFE_LDS_VARS 304
 #endif
 #ifndef OPUSFE_LDS_BBS
 #define OPUSFE_LDS_BBS 96
@@ -58,14 +58,23 @@ struct LowerBuffers {
 #ifndef OPUSFE_LDS_TYPES
 #define OPUSFE_LDS_TYPES 64
 #endif
+#ifndef OPUSFE_ISTAGE
+#define OPUSFE_ISTAGE 8
+#endif
+enum { ISTAGE = OPUSFE_ISTAGE };
+static_assert(sizeof(opusfe_instr) == 24, "instruction staging copies records as 6 words");
 enum { LDS_FRAMES = 32, LDS_VARS = OPUSFE_LDS_VARS, LDS_BBS = OPUSFE_LDS_BBS, LDS_LOCALS = 64, LDS_TYPES = OPUSFE_LDS_TYPES };
 struct LowerLds {
     LFrame frames[LDS_FRAMES];
     uint32_t vtype[LDS_VARS];
+    uint32_t vnamed[(LDS_VARS + 31) / 32];     // bit v: variable v is not a temporary
     uint32_t bbcnt[LDS_BBS], bblast[LDS_BBS];
     uint32_t lname[LDS_LOCALS], lvar[LDS_LOCALS], lhash[LDS_LOCALS], lstack[LDS_LOCALS], lshash[LDS_LOCALS];
     TypeRec types[LDS_TYPES];
     uint32_t match_stack[96];   // work list of TypeOps::types_match
+    // the newest instructions, staged as {6 instruction words, bb, rank}: they reach the sparse global arrays ISTAGE at a
+    // time as whole lines (one instruction at a time was three partial-line stores and a store wait in every push)
+    uint32_t istage[ISTAGE][8];
 };
 
 using ::uni;
@@ -137,6 +146,7 @@ struct Lowerer {
     // sparse regions of this function
     MACHINE_STATE opusfe_variable* vars; MACHINE_STATE uint32_t nvars, vcap;
     MACHINE_STATE opusfe_instr* instrs; MACHINE_STATE uint32_t* ibb; MACHINE_STATE uint32_t* irank; MACHINE_STATE uint32_t ninstrs, icap;
+    MACHINE_STATE uint32_t iflushed;   // instructions [iflushed, ninstrs) are still in lds.istage
     MACHINE_STATE uint32_t* bbcnt; MACHINE_STATE uint32_t* bblast; MACHINE_STATE uint32_t nbbs, bcap;
     MACHINE_STATE uint32_t tbase, ntypes, tcap;
     MACHINE_STATE uint32_t* cargs; MACHINE_STATE uint32_t ncargs, ccap;
@@ -223,21 +233,55 @@ struct Lowerer {
     __device__ __forceinline__ uint32_t new_var(uint32_t type_id, bool is_temporary) {
         LPROF(LP_NEWVAR);
         if (nvars >= vcap) { internal(); return 0; }
-        gst(vars + nvars, opusfe_variable{type_id, is_temporary ? 1u : 0u});
-        if (nvars < LDS_VARS) lds.vtype[nvars] = type_id;
+        // the first LDS_VARS variables exist only in LDS (type id; one bit for the few that are not temporaries) until flush_vars() writes them out as
+        // one contiguous run when the function is done; later ones go straight to the sparse global array
+        if (nvars < LDS_VARS) { lds.vtype[nvars] = type_id; if (!is_temporary) lds.vnamed[nvars >> 5] |= 1u << (nvars & 31); }
+        else gst(vars + nvars, opusfe_variable{type_id, is_temporary ? 1u : 0u});
         return nvars++;
     }
     __device__ __forceinline__ uint32_t vtype(uint32_t v) const { return v < nvars ? uni(v < LDS_VARS ? lds.vtype[v] : gld(&vars[v].type_id)) : (uint32_t)TP_Error; }
-    __device__ __forceinline__ void set_vtype(uint32_t v, uint32_t t) { if (v < nvars) { gst(&vars[v].type_id, t); if (v < LDS_VARS) lds.vtype[v] = t; } }
+    __device__ __forceinline__ void set_vtype(uint32_t v, uint32_t t) { if (v < nvars) { if (v < LDS_VARS) lds.vtype[v] = t; else gst(&vars[v].type_id, t); } }
+    __device__ void flush_vars() {     // all lanes
+        const uint32_t n = nvars < LDS_VARS ? nvars : (uint32_t)LDS_VARS;
+        for (uint32_t j = lane_of(); j < n; j += UNIT_LANES) gst(vars + j, opusfe_variable{lds.vtype[j], ((lds.vnamed[j >> 5] >> (j & 31)) & 1u) ^ 1u});
+    }
+    // staged instructions -> sparse global arrays (all lanes; the instruction words of the stage are one contiguous run)
+    __device__ __noinline__ void flush_instrs() {
+        const uint32_t n = ninstrs - iflushed, lane = lane_of();
+        uint32_t* dst = (uint32_t*)(instrs + iflushed);
+        for (uint32_t w = lane; w < n * 6; w += UNIT_LANES) gst(dst + w, lds.istage[w / 6][w % 6]);
+        for (uint32_t j = lane; j < n; j += UNIT_LANES) { gst(ibb + iflushed + j, lds.istage[j][6]); gst(irank + iflushed + j, lds.istage[j][7]); }
+        iflushed = ninstrs;
+    }
+    __device__ opusfe_instr instr_get(uint32_t t) const {
+        t = uni(t);
+        if (t < iflushed) return gld(instrs + t);
+        union { opusfe_instr i; uint32_t w[6]; } u;
+#pragma unroll
+        for (int k = 0; k < 6; k++) u.w[k] = uni(lds.istage[t - iflushed][k]);
+        return u.i;
+    }
+    __device__ void instr_set(uint32_t t, opusfe_instr in) {    // the block and rank of instruction t stay as they are
+        t = uni(t);
+        if (t < iflushed) { gst(instrs + t, in); return; }
+        union { opusfe_instr i; uint32_t w[6]; } u; u.i = in;
+#pragma unroll
+        for (int k = 0; k < 6; k++) lds.istage[t - iflushed][k] = u.w[k];
+    }
     __device__ uint32_t push_to(uint32_t bb, opusfe_instr in) {   // by value: a reference would go through scratch memory
         bb = uni(bb);
         LPROF(LP_PUSH);
         if (ninstrs >= icap || bb >= nbbs) { internal(); return 0; }
+        if (ninstrs - iflushed >= ISTAGE) flush_instrs();
         uint32_t t = ninstrs++;
         uint32_t rank;
         if (bb < LDS_BBS) { rank = lds.bbcnt[bb]; lds.bbcnt[bb] = rank + 1; lds.bblast[bb] = t; }
         else { rank = gld(bbcnt + bb); gst(bbcnt + bb, rank + 1); gst(bblast + bb, t); }
-        gst(instrs + t, in); gst(ibb + t, bb); gst(irank + t, uni(rank));
+        union { opusfe_instr i; uint32_t w[6]; } u; u.i = in;
+        uint32_t* e = lds.istage[t - iflushed];
+#pragma unroll
+        for (int k = 0; k < 6; k++) e[k] = u.w[k];
+        e[6] = bb; e[7] = rank;
         return t;
     }
     __device__ __forceinline__ uint32_t push(const opusfe_instr& in) { return push_to(bb_index, in); }
@@ -943,8 +987,8 @@ struct Lowerer {
                 push_to(else_end, ins(I_Jump, 0, 0, 0, merge));
                 for (uint32_t t = keep.b; t != OPUSFE_NONE;) {        // patch this loop's break placeholders (:357-359)
                     if (t >= ninstrs) { internal(); break; }
-                    uint32_t nx = gld(&instrs[t].a);
-                    gst(instrs + t, ins(I_Jump, 0, 0, 0, merge));
+                    uint32_t nx = instr_get(t).a;
+                    instr_set(t, ins(I_Jump, 0, 0, 0, merge));
                     t = nx;
                 }
                 rdiv = div; retn(); goto next;
@@ -1084,12 +1128,12 @@ struct Lowerer {
                 } else if (k == TY_GenericInteger) {
                     uint32_t t = bb_index < nbbs ? bb_last(bb_index) : OPUSFE_NONE;
                     opusfe_instr li{};
-                    if (t != OPUSFE_NONE) li = gld(instrs + t);
+                    if (t != OPUSFE_NONE) li = instr_get(t);
                     if (t != OPUSFE_NONE && li.opcode == I_Integer) {
                         uint64_t val = (uint64_t)li.c | ((uint64_t)li.extra << 32);
                         val = 0 - val;
                         li.c = (uint32_t)val; li.extra = (uint32_t)(val >> 32);
-                        gst(instrs + t, li);
+                        instr_set(t, li);
                         rv = li.dst;
                     } else { unsupported(); rv = generate_error(); }   // reference: unreachable!()
                 } else if (k == TY_Error) rv = generate_error();
@@ -1248,7 +1292,7 @@ struct Lowerer {
         if (rdiv || returns_null) {
             uint32_t t = bb_last(bb_index);
             bool term = false;
-            if (t != OPUSFE_NONE) { uint16_t op = gld(instrs + t).opcode; term = op == I_Return || op == I_Jump || op == I_Branch || op == I_Unreachable; }
+            if (t != OPUSFE_NONE) { uint16_t op = instr_get(t).opcode; term = op == I_Return || op == I_Jump || op == I_Branch || op == I_Unreachable; }
             if (!term) {
                 if (returns_null) { uint32_t v = new_var(TP_Null, true); push(ins(I_Null, v)); push(ins(I_Return, 0, v)); }
                 else push(ins(I_Unreachable));
@@ -1296,7 +1340,7 @@ __global__ MACHINE_ATTR(OPUSFE_LOWER_WAVES) __launch_bounds__(64) void k_lower_f
     L.S = S; L.fidx = fidx; L.F = S.funcs[fidx]; L.undefined_flag = undefined_flag;
     L.vars = B.vars + lower_base(CAP_VARS, dn, fidx); L.nvars = 0; L.vcap = (uint32_t)lower_cap(CAP_VARS, nn);
     uint64_t ib = lower_base(CAP_INSTRS, dn, fidx);
-    L.instrs = B.instrs + ib; L.ibb = B.ibb + ib; L.irank = B.irank + ib; L.ninstrs = 0; L.icap = (uint32_t)lower_cap(CAP_INSTRS, nn);
+    L.instrs = B.instrs + ib; L.ibb = B.ibb + ib; L.irank = B.irank + ib; L.ninstrs = 0; L.iflushed = 0; L.icap = (uint32_t)lower_cap(CAP_INSTRS, nn);
     uint64_t bbb = lower_base(CAP_BBS, dn, fidx);
     L.bbcnt = B.bbcnt + bbb; L.bblast = B.bblast + bbb; L.nbbs = 0; L.bcap = (uint32_t)lower_cap(CAP_BBS, nn);
     L.tbase = B.type_sparse_base + (uint32_t)lower_base(CAP_TYPES, dn, fidx); L.ntypes = 0; L.tcap = (uint32_t)lower_cap(CAP_TYPES, nn);
@@ -1308,6 +1352,7 @@ __global__ MACHINE_ATTR(OPUSFE_LOWER_WAVES) __launch_bounds__(64) void k_lower_f
     L.errs = B.errs + lower_base(CAP_ERRS, dn, fidx); L.nerrs = 0; L.ecap = (uint32_t)lower_cap(CAP_ERRS, nn);
     L.bb_index = 0; L.break_head = OPUSFE_NONE; L.loop_begin = OPUSFE_NONE; L.dev_status = DS_OK;
     L.rv = 0; L.rl = false; L.rdiv = false; L.sym_locals = false;
+    for (uint32_t j = lane; j < (LDS_VARS + 31) / 32; j += UNIT_LANES) L.lds.vnamed[j] = 0;
     // body = last child of the definition
     uint32_t c = S.nodes[dn].first_child;
     while (S.nodes[c].next != OPUSFE_NONE) c = S.nodes[c].next;
@@ -1318,6 +1363,8 @@ __global__ MACHINE_ATTR(OPUSFE_LOWER_WAVES) __launch_bounds__(64) void k_lower_f
 #else
     L.run(c);
 #endif
+    L.flush_instrs();
+    L.flush_vars();
     // block sizes of the LDS-resident blocks go to the global table read by k_ir_bb_offsets
     for (uint32_t b = lane; b < L.nbbs && b < LDS_BBS; b += UNIT_LANES) L.bbcnt[b] = L.lds.bbcnt[b];
     if (lane != 0) return;
