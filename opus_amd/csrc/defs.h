@@ -10,7 +10,7 @@
 // instead of 64.  The host emulation (tests/emu) runs one lane per unit.
 // occupancy hint of the two sequential-machine kernels (waves per SIMD the register allocator must leave room for)
 #ifndef OPUSFE_PARSE_WAVES
-#define OPUSFE_PARSE_WAVES 5
+#define OPUSFE_PARSE_WAVES 7
 #endif
 #ifndef OPUSFE_LOWER_WAVES
 #define OPUSFE_LOWER_WAVES 6

@@ -27,7 +27,7 @@ enum { SI_NODE_BASE = 0, SI_NODE_COUNT, SI_DEF_COUNT, SI_FIRST_DEF, SI_ERR_KIND,
 #endif
 enum { PARSE_LDS_FRAMES = OPUSFE_PARSE_LDS_FRAMES };
 #ifndef OPUSFE_PARSE_RING
-#define OPUSFE_PARSE_RING 256
+#define OPUSFE_PARSE_RING 128
 #endif
 enum { PARSE_RING = OPUSFE_PARSE_RING };
 struct PFrame { uint8_t st; uint8_t aux; uint16_t cnt; uint32_t a, b, c; };
