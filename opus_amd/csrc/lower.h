@@ -63,7 +63,13 @@ struct LowerBuffers {
 #endif
 enum { ISTAGE = OPUSFE_ISTAGE };
 static_assert(sizeof(opusfe_instr) == 24, "instruction staging copies records as 6 words");
-enum { LDS_FRAMES = 32, LDS_VARS = OPUSFE_LDS_VARS, LDS_BBS = OPUSFE_LDS_BBS, LDS_LOCALS = 64, LDS_TYPES = OPUSFE_LDS_TYPES };
+#ifndef OPUSFE_LDS_FRAMES
+#define OPUSFE_LDS_FRAMES 32
+#endif
+#ifndef OPUSFE_LDS_LOCALS
+#define OPUSFE_LDS_LOCALS 64
+#endif
+enum { LDS_FRAMES = OPUSFE_LDS_FRAMES, LDS_VARS = OPUSFE_LDS_VARS, LDS_BBS = OPUSFE_LDS_BBS, LDS_LOCALS = OPUSFE_LDS_LOCALS, LDS_TYPES = OPUSFE_LDS_TYPES };
 struct LowerLds {
     LFrame frames[LDS_FRAMES];
     uint32_t vtype[LDS_VARS];

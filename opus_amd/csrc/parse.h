@@ -553,7 +553,27 @@ struct SegParser {
             case PS_AT_CAST: append(ret); finish(cur.a); goto l_at_post_loop;
 
             // ---- parse_expression  parse.rs:815-835 ----
-            case PS_EX_0: l_ex_0: if (!call(PS_AT_0, PS_EX_1)) return false; goto l_at_0;
+            case PS_EX_0: l_ex_0: {
+                // An atom that is one literal / name token with no postfix operator behind it (the usual case) is built here:
+                // it is exactly what PS_AT_0 -> PS_AT_POST -> PS_AT_POST_LOOP would do in a frame of their own.
+                k = kind_at(i);
+                if (k == T_Integer || k == T_Float || k == T_String || k == T_Identifier || k == T_Null || k == T_False || k == T_True) {
+                    const uint8_t k2 = kind_at(i + 1);
+                    if (k2 != T_At && k2 != T_Dot && k2 != T_LeftParenthesis && k2 != T_Colon && k2 != T_Error) {
+                        consume();
+                        const uint32_t low = low_at(i - 1);
+                        const uint8_t nk = k == T_Integer ? E_Integer : k == T_Float ? E_Float : k == T_String ? E_String : k == T_Identifier ? E_Variable : k == T_Null ? E_Null : E_Bool;
+                        const uint32_t a = new_node(nk, k == T_True ? 1 : 0, (k == T_Null || k == T_False || k == T_True) ? 0u : i - 1, low);
+                        N(a).high = position;       // finish(): no children
+                        peeked = true;              // the postfix loop has looked at the next token
+                        ret = a;
+                        cur.st = PS_EX_1;
+                        goto next;
+                    }
+                }
+                if (!call(PS_AT_0, PS_EX_1)) return false;
+                goto l_at_0;
+            }
             case PS_EX_1: {
                 TRY(peek(&k));
                 uint8_t op = binop_of(k);
