@@ -247,6 +247,10 @@ struct Lowerer {
     }
     __device__ __forceinline__ uint32_t vtype(uint32_t v) const { return v < nvars ? uni(v < LDS_VARS ? lds.vtype[v] : gld(&vars[v].type_id)) : (uint32_t)TP_Error; }
     __device__ __forceinline__ void set_vtype(uint32_t v, uint32_t t) { if (v < nvars) { if (v < LDS_VARS) lds.vtype[v] = t; else gst(&vars[v].type_id, t); } }
+    __device__ void flush_types() {    // all lanes
+        const uint32_t n = ntypes < LDS_TYPES ? ntypes : (uint32_t)LDS_TYPES;
+        for (uint32_t j = lane_of(); j < n; j += UNIT_LANES) gst(S.types + tbase + j, (TypeRec)lds.types[j]);
+    }
     __device__ void flush_vars() {     // all lanes
         const uint32_t n = nvars < LDS_VARS ? nvars : (uint32_t)LDS_VARS;
         for (uint32_t j = lane_of(); j < n; j += UNIT_LANES) gst(vars + j, opusfe_variable{lds.vtype[j], ((lds.vnamed[j >> 5] >> (j & 31)) & 1u) ^ 1u});
@@ -303,9 +307,10 @@ struct Lowerer {
     __device__ uint32_t generate_error() { uint32_t v = new_var(TP_Error, true); push(ins(I_Error, v)); return v; }
     __device__ uint32_t new_type(const TypeRec& r) {
         if (ntypes >= tcap) { internal(); return TP_Error; }
-        if (ntypes < LDS_TYPES) lds.types[ntypes] = r;
-        uint32_t id = tbase + ntypes++;
-        gst(S.types + id, r);
+        // the first LDS_TYPES records exist only in LDS until flush_types(); TypeOps::rec reads them there
+        const uint32_t id = tbase + ntypes;
+        if (ntypes < LDS_TYPES) lds.types[ntypes] = r; else gst(S.types + id, r);
+        ntypes++;
         return id;
     }
     __device__ uint32_t type_pointer(uint8_t pt, uint32_t sub) { pt = uni(pt); sub = uni(sub); TypeRec r{}; r.kind = TY_Pointer; r.ptr = pt; r.sub = sub; r.alias = OPUSFE_NONE; return new_type(r); }
@@ -1371,6 +1376,7 @@ __global__ MACHINE_ATTR(OPUSFE_LOWER_WAVES) __launch_bounds__(64) void k_lower_f
 #endif
     L.flush_instrs();
     L.flush_vars();
+    L.flush_types();
     // block sizes of the LDS-resident blocks go to the global table read by k_ir_bb_offsets
     for (uint32_t b = lane; b < L.nbbs && b < LDS_BBS; b += UNIT_LANES) L.bbcnt[b] = L.lds.bbcnt[b];
     if (lane != 0) return;
