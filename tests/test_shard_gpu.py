@@ -77,3 +77,27 @@ def test_syntax_error_is_reported_by_the_owning_rank(fe):
     kind, low = want.split()[0], int(want.split()[1])
     assert u.dump_error().split()[0] == kind
     assert e.low + offset == low
+
+
+def test_large_source_properties_whole_vs_sharded(fe):
+    """Size-independent properties at a size the text oracle no longer handles in seconds (64 MB, deep regions injected):
+    lowering the whole source, lowering it again, and lowering it as 4 byte-range shards must agree on every count that
+    does not depend on the sharding (tokens and nodes of the owned bytes, instructions, variables, basic blocks)."""
+    src = O.generate(21, 64 << 20, flags=1, threads=8)
+    u = fe.get_definitions(src)
+    assert u.status == 0 and u.compile_source() == 0
+    whole = u.counts()
+    u.close()
+    u2 = fe.get_definitions(src)
+    assert u2.status == 0 and u2.compile_source() == 0
+    assert u2.counts() == whole, "the pipeline must be deterministic"
+    u2.close()
+    states, res = run_sharded(fe, src, 4)
+    assert all(r["status"] == 0 for r in res)
+    # the EndOfFile token belongs to the last rank only; every other rank's own unit ends with one of its own
+    assert sum(r["own_counts"]["tokens"] for r in res) == whole["tokens"] + (len(res) - 1)
+    assert sum(r["own_counts"]["nodes"] for r in res) == whole["nodes"]
+    for key in ("instrs", "vars", "bbs"):
+        assert sum(r["unit"].counts()[key] for r in res) == whole[key], key
+    for r in res:
+        r["unit"].close()
