@@ -194,6 +194,77 @@ __device__ __forceinline__ uint32_t lx_string_end(const uint8_t* __restrict__ s,
 
 // Lexes the token starting at `pos` (s[pos] is not whitespace, not ';', pos < n, context N).
 // parse.rs:503-720.  `strdst` (may be null) receives [u32 n][bytes] of a String token.
+// ---- correctly rounded decimal -> f64 for literals outside the fast path ---------------------------
+// parse.rs:562 uses str::parse::<f64> (correctly rounded, ties to even).  A literal here is DIGITS '.' DIGITS, i.e. the
+// rational W / 10^frac.  Up to BIGDEC_DIGITS significant digits are converted exactly with fixed-size big integers:
+// Q = floor(W * 2^E / 10^frac) with E chosen so that Q has 55..56 bits, then 53 bits are kept and the rest plus the
+// division remainder decide the rounding.  (Rare path: the arrays live in scratch memory.)
+enum { BIGDEC_LIMBS = 24, BIGDEC_DIGITS = 76 };      // 768-bit integers; 10^76 < 2^253
+struct BigDec { uint32_t w[BIGDEC_LIMBS]; };
+__device__ __forceinline__ void bd_zero(BigDec& a) { for (int i = 0; i < BIGDEC_LIMBS; i++) a.w[i] = 0; }
+__device__ __forceinline__ void bd_mul10_add(BigDec& a, uint32_t d) {
+    uint64_t c = d;
+    for (int i = 0; i < BIGDEC_LIMBS; i++) { c += (uint64_t)a.w[i] * 10u; a.w[i] = (uint32_t)c; c >>= 32; }
+}
+__device__ __forceinline__ int bd_bits(const BigDec& a) {
+    for (int i = BIGDEC_LIMBS - 1; i >= 0; i--) if (a.w[i]) return i * 32 + 32 - __builtin_clz(a.w[i]);
+    return 0;
+}
+__device__ __forceinline__ void bd_shl(BigDec& a, int k) {
+    const int ws = k >> 5, bs = k & 31;
+    for (int i = BIGDEC_LIMBS - 1; i >= 0; i--) {
+        uint32_t v = 0;
+        if (i - ws >= 0) v = a.w[i - ws] << bs;
+        if (bs && i - ws - 1 >= 0) v |= a.w[i - ws - 1] >> (32 - bs);
+        a.w[i] = v;
+    }
+}
+__device__ __forceinline__ void bd_shr1(BigDec& a) {
+    for (int i = 0; i < BIGDEC_LIMBS; i++) a.w[i] = (a.w[i] >> 1) | (i + 1 < BIGDEC_LIMBS ? a.w[i + 1] << 31 : 0u);
+}
+__device__ __forceinline__ bool bd_ge(const BigDec& a, const BigDec& b) {
+    for (int i = BIGDEC_LIMBS - 1; i >= 0; i--) if (a.w[i] != b.w[i]) return a.w[i] > b.w[i];
+    return true;
+}
+__device__ __forceinline__ void bd_sub(BigDec& a, const BigDec& b) {
+    uint64_t br = 0;
+    for (int i = 0; i < BIGDEC_LIMBS; i++) { uint64_t d = (uint64_t)a.w[i] - b.w[i] - br; a.w[i] = (uint32_t)d; br = (d >> 63) & 1; }
+}
+__device__ __forceinline__ bool bd_is_zero(const BigDec& a) { for (int i = 0; i < BIGDEC_LIMBS; i++) if (a.w[i]) return false; return true; }
+// digits = the literal's digits without the '.', frac of them behind the point; false when there are too many
+__device__ bool lx_decimal_to_f64(const uint8_t* __restrict__ s, uint32_t int_lo, uint32_t int_hi, uint32_t frac_lo, uint32_t frac_hi, double* out) {
+    while (frac_hi > frac_lo && s[frac_hi - 1] == '0') frac_hi--;          // trailing zeros of the fraction
+    while (int_lo < int_hi && s[int_lo] == '0') int_lo++;                  // leading zeros
+    uint32_t lead = frac_lo;                                                // 0.000ddd: zeros that are not significant
+    if (int_lo == int_hi) while (lead < frac_hi && s[lead] == '0') lead++;
+    const uint32_t sig = (int_hi - int_lo) + (frac_hi - lead), frac = frac_hi - frac_lo;
+    if (sig == 0) { *out = 0.0; return true; }
+    if (sig > BIGDEC_DIGITS || frac > BIGDEC_DIGITS) return false;
+    BigDec W, D; bd_zero(W); bd_zero(D);
+    for (uint32_t q = int_lo; q < int_hi; q++) bd_mul10_add(W, (uint32_t)(s[q] - '0'));
+    for (uint32_t q = frac_lo; q < frac_hi; q++) bd_mul10_add(W, (uint32_t)(s[q] - '0'));
+    D.w[0] = 1;
+    for (uint32_t k = 0; k < frac; k++) bd_mul10_add(D, 0);
+    // scale so that the quotient has 55 or 56 bits
+    const int E = 55 - (bd_bits(W) - bd_bits(D));
+    if (E >= 0) bd_shl(W, E); else bd_shl(D, -E);
+    uint64_t Q = 0;
+    bd_shl(D, 56);
+    for (int bit = 56; bit >= 0; bit--) {
+        if (bd_ge(W, D)) { bd_sub(W, D); Q |= 1ull << bit; }
+        bd_shr1(D);
+    }
+    const bool rem = !bd_is_zero(W);
+    const int qb = 64 - __builtin_clzll(Q), sh = qb - 53;                   // qb is 55 or 56
+    uint64_t m = Q >> sh;
+    const bool round = (Q >> (sh - 1)) & 1, sticky = (Q & ((1ull << (sh - 1)) - 1)) != 0 || rem;
+    int e2 = sh - E;                                                          // value = m * 2^e2
+    if (round && (sticky || (m & 1))) { m++; if (m == (1ull << 53)) { m >>= 1; e2++; } }
+    const uint64_t bits = ((uint64_t)(e2 + 52 + 1023) << 52) | (m & ((1ull << 52) - 1));   // normal range by the digit limits
+    *out = __longlong_as_double((long long)bits);
+    return true;
+}
+
 __device__ void lex_one(const uint8_t* __restrict__ s, uint32_t n, uint32_t pos, LexTok& o, uint8_t* strdst, uint32_t* status) {
     o.kind = T_EndOfFile; o.flags = 0; o.aux = 0; o.low = pos; o.end = pos + 1; o.nval = 0; o.v0 = o.v1 = 0; o.payload = 0; o.strbytes = 0;
     int c = s[pos];
@@ -241,10 +312,8 @@ __device__ void lex_one(const uint8_t* __restrict__ s, uint32_t n, uint32_t pos,
             if (exact) {
                 const double P10[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
                 f = (double)w / P10[frac];
-            } else {
-                // trailing zeros in the fraction do not change the value: retry without them
-                // (keeps "1.50000000000000000000000" exact); otherwise unsupported for now.
-                lx_unsupported(status, DS_UNSUPPORTED_FLOAT, pos);
+            } else if (!lx_decimal_to_f64(s, pos, p - 1 - frac, p - frac, p, &f)) {
+                lx_unsupported(status, DS_UNSUPPORTED_FLOAT, pos);      // more than 76 significant digits
             }
             o.kind = T_Float; o.nval = 1; o.v0 = (uint64_t)__double_as_longlong(f);
             if (lx_at(s, n, p) == 'f') {

@@ -6,7 +6,13 @@ LEX_CASES = ["5s", "5i8", "5n", "5i80", "5in", "7i12", "1.5f32", "2.", "1..2", "
              "a#b", "#", "foo(\n\tbar,\n\tbaz)\n", "a;b\nc", '"a;b" ; "c"\nd', "a\r\n\tb\r\n", "\x0b\x0cfoo",
              "18446744073709551616 4294967296 4294967295", "1.25 0.1 123456.789 3.0f32",
              "x" * 200, "ab " * 100, '"' + "s" * 300 + '" tail', "; " + "c" * 300 + "\nafter", "1" * 70,
-             '"' + "u" * 500, 'x = "abc\\', '"\\x', '"\\xZZ" y', "a" * 63 + '"' + "b" * 200, "\t" * 70 + "x\n" + "\t" * 3 + "y"]
+             '"' + "u" * 500, 'x = "abc\\', '"\\x', '"\\xZZ" y', "a" * 63 + '"' + "b" * 200, "\t" * 70 + "x\n" + "\t" * 3 + "y",
+             # float literals outside the Clinger fast path: correctly rounded like str::parse::<f64> (ties to even)
+             "0.30000000000000004 9007199254740993.0 9007199254740992.5 4503599627370497.5 123456789012345678901234567890.5",
+             "0.000000000000000000000000000001 1.0000000000000000000000000000000000000001 3.14159265358979323846264338327950288",
+             "1.50000000000000000000000000 000.000 179769313486231570000000000000000000000.0 0.1000000000000000055511151231257827"]
+# more than 76 significant digits: OPUSFE_UNSUPPORTED, never a wrong value
+TOO_LONG_FLOAT = "var x = 1." + "1" * 80 + "\n"
 
 # parser inputs: valid programs first, then one construct per syntax error
 PARSE_CASES = [

@@ -37,6 +37,7 @@ inline unsigned __shfl_down(unsigned, int, int) { emu_collective(); }
 inline int __shfl(int, int, int) { emu_collective(); }
 inline void __syncthreads() {}
 inline long long __double_as_longlong(double d) { long long v; memcpy(&v, &d, 8); return v; }
+inline double __longlong_as_double(long long v) { double d; memcpy(&d, &v, 8); return d; }
 
 template <class K, class... A>
 inline void emu_launch(K kernel, unsigned grid, unsigned block, A... args) {

@@ -89,3 +89,12 @@ def test_emu_ir_generated_and_deep():
 def test_emu_ir_big_function_spill_paths():
     """every LDS-resident table of the two machines overflows into its sparse global region (AddressSanitizer watches)"""
     compare_ir([big_function().encode(), big_function(70, 40, 300, 20).encode()])
+
+
+def test_emu_float_literals_outside_the_fast_path():
+    lits = ["0.30000000000000004", "9007199254740993.0", "9007199254740992.5", "4503599627370497.5", "123456789012345678901234567890.5",
+            "0.000000000000000000000000000001", "1.0000000000000000000000000000000000000001", "3.14159265358979323846264338327950288",
+            "1.50000000000000000000000000", "000.000", "179769313486231570000000000000000000000.0", "0.1000000000000000055511151231257827"]
+    src = "".join(f"const c{i} float64 = {t}\n" for i, t in enumerate(lits)).encode()
+    (st, got), = E.dump_many([src], 0)
+    assert st == 0 and got == O.dump(src, O.TOKENS)

@@ -48,3 +48,36 @@ def test_generated_token_stream_matches_parser_driven_log(fe, seed, size):
 def test_deep_regions_token_stream(fe):
     src = O.generate(3, 2 << 20, flags=1)
     assert fe.lex(src).dump_tokens() == O.dump(src, O.TOKENS)
+
+
+def test_float_literals_are_correctly_rounded(fe):
+    """random long literals and exact halfway points between adjacent doubles: the token text (shortest round-trip form of
+    the f64) must equal the oracle's (strtod, correctly rounded like str::parse::<f64>, parse.rs:562)"""
+    import random
+    from fractions import Fraction
+    rnd = random.Random(7)
+    lits = []
+    for _ in range(1500):
+        ni = rnd.randint(1, 40)
+        nf = min(rnd.randint(1, 40), 76 - ni)
+        lits.append("".join(rnd.choice("0123456789") for _ in range(ni)) + "." + "".join(rnd.choice("0123456789") for _ in range(nf)))
+    for _ in range(300):
+        m, e = rnd.getrandbits(52) | (1 << 52), rnd.randint(-60, 60)
+        v = Fraction(2 * m + 1) * Fraction(2) ** (e - 1)          # halfway between m * 2^e and (m + 1) * 2^e
+        ip, r, fr = v.numerator // v.denominator, v.numerator % v.denominator, ""
+        while r and len(fr) < 75:
+            r *= 10
+            fr += str(r // v.denominator)
+            r %= v.denominator
+        t = str(ip) + "." + (fr or "0")
+        if r == 0 and len(t.replace(".", "").lstrip("0")) <= 76:
+            lits.append(t)
+    src = "".join(f"const c{i} float64 = {t}\n" for i, t in enumerate(lits)).encode()
+    u = fe.lex(src)
+    assert u.status == 0
+    assert u.dump_tokens() == O.dump(src, O.TOKENS)
+
+
+def test_float_literal_with_too_many_digits_is_unsupported(fe):
+    from cases import TOO_LONG_FLOAT
+    assert fe.lex(TOO_LONG_FLOAT.encode()).status == 2
