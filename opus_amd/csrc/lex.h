@@ -201,18 +201,20 @@ __device__ __forceinline__ uint32_t lx_string_end(const uint8_t* __restrict__ s,
 // division remainder decide the rounding.  (Rare path: the arrays live in scratch memory.)
 enum { BIGDEC_LIMBS = 24, BIGDEC_DIGITS = 76 };      // 768-bit integers; 10^76 < 2^253
 struct BigDec { uint32_t w[BIGDEC_LIMBS]; };
-__device__ __forceinline__ void bd_zero(BigDec& a) { for (int i = 0; i < BIGDEC_LIMBS; i++) a.w[i] = 0; }
+__device__ __forceinline__ void bd_zero(BigDec& a) {
+    _Pragma("unroll 1") for (int i = 0; i < BIGDEC_LIMBS; i++) a.w[i] = 0;
+}
 __device__ __forceinline__ void bd_mul10_add(BigDec& a, uint32_t d) {
     uint64_t c = d;
-    for (int i = 0; i < BIGDEC_LIMBS; i++) { c += (uint64_t)a.w[i] * 10u; a.w[i] = (uint32_t)c; c >>= 32; }
+    _Pragma("unroll 1") for (int i = 0; i < BIGDEC_LIMBS; i++) { c += (uint64_t)a.w[i] * 10u; a.w[i] = (uint32_t)c; c >>= 32; }
 }
 __device__ __forceinline__ int bd_bits(const BigDec& a) {
-    for (int i = BIGDEC_LIMBS - 1; i >= 0; i--) if (a.w[i]) return i * 32 + 32 - __builtin_clz(a.w[i]);
+    _Pragma("unroll 1") for (int i = BIGDEC_LIMBS - 1; i >= 0; i--) if (a.w[i]) return i * 32 + 32 - __builtin_clz(a.w[i]);
     return 0;
 }
 __device__ __forceinline__ void bd_shl(BigDec& a, int k) {
     const int ws = k >> 5, bs = k & 31;
-    for (int i = BIGDEC_LIMBS - 1; i >= 0; i--) {
+    _Pragma("unroll 1") for (int i = BIGDEC_LIMBS - 1; i >= 0; i--) {
         uint32_t v = 0;
         if (i - ws >= 0) v = a.w[i - ws] << bs;
         if (bs && i - ws - 1 >= 0) v |= a.w[i - ws - 1] >> (32 - bs);
@@ -220,19 +222,22 @@ __device__ __forceinline__ void bd_shl(BigDec& a, int k) {
     }
 }
 __device__ __forceinline__ void bd_shr1(BigDec& a) {
-    for (int i = 0; i < BIGDEC_LIMBS; i++) a.w[i] = (a.w[i] >> 1) | (i + 1 < BIGDEC_LIMBS ? a.w[i + 1] << 31 : 0u);
+    _Pragma("unroll 1") for (int i = 0; i < BIGDEC_LIMBS; i++) a.w[i] = (a.w[i] >> 1) | (i + 1 < BIGDEC_LIMBS ? a.w[i + 1] << 31 : 0u);
 }
 __device__ __forceinline__ bool bd_ge(const BigDec& a, const BigDec& b) {
-    for (int i = BIGDEC_LIMBS - 1; i >= 0; i--) if (a.w[i] != b.w[i]) return a.w[i] > b.w[i];
+    _Pragma("unroll 1") for (int i = BIGDEC_LIMBS - 1; i >= 0; i--) if (a.w[i] != b.w[i]) return a.w[i] > b.w[i];
     return true;
 }
 __device__ __forceinline__ void bd_sub(BigDec& a, const BigDec& b) {
     uint64_t br = 0;
-    for (int i = 0; i < BIGDEC_LIMBS; i++) { uint64_t d = (uint64_t)a.w[i] - b.w[i] - br; a.w[i] = (uint32_t)d; br = (d >> 63) & 1; }
+    _Pragma("unroll 1") for (int i = 0; i < BIGDEC_LIMBS; i++) { uint64_t d = (uint64_t)a.w[i] - b.w[i] - br; a.w[i] = (uint32_t)d; br = (d >> 63) & 1; }
 }
-__device__ __forceinline__ bool bd_is_zero(const BigDec& a) { for (int i = 0; i < BIGDEC_LIMBS; i++) if (a.w[i]) return false; return true; }
+__device__ __forceinline__ bool bd_is_zero(const BigDec& a) {
+    _Pragma("unroll 1") for (int i = 0; i < BIGDEC_LIMBS; i++) if (a.w[i]) return false;
+    return true;
+}
 // digits = the literal's digits without the '.', frac of them behind the point; false when there are too many
-__device__ bool lx_decimal_to_f64(const uint8_t* __restrict__ s, uint32_t int_lo, uint32_t int_hi, uint32_t frac_lo, uint32_t frac_hi, double* out) {
+__device__ __noinline__ bool lx_decimal_to_f64(const uint8_t* __restrict__ s, uint32_t int_lo, uint32_t int_hi, uint32_t frac_lo, uint32_t frac_hi, double* out) {
     while (frac_hi > frac_lo && s[frac_hi - 1] == '0') frac_hi--;          // trailing zeros of the fraction
     while (int_lo < int_hi && s[int_lo] == '0') int_lo++;                  // leading zeros
     uint32_t lead = frac_lo;                                                // 0.000ddd: zeros that are not significant
