@@ -460,7 +460,15 @@ __device__ __forceinline__ void lex_chunk(const uint8_t* __restrict__ s, uint32_
 }
 
 // per-chunk packed counts: tok (8 bits) | val (8 bits); string-pool bytes separately
-__global__ __launch_bounds__(LEX_THREADS) void k_lex_count(const uint8_t* __restrict__ src, uint32_t n, const uint32_t* __restrict__ chunk_fn,
+#ifndef OPUSFE_LEX_WAVES
+#define OPUSFE_LEX_WAVES 8
+#endif
+#if OPUSFE_LEX_WAVES
+#define LEX_ATTR __attribute__((amdgpu_waves_per_eu(OPUSFE_LEX_WAVES, OPUSFE_LEX_WAVES)))
+#else
+#define LEX_ATTR
+#endif
+__global__ LEX_ATTR __launch_bounds__(LEX_THREADS) void k_lex_count(const uint8_t* __restrict__ src, uint32_t n, const uint32_t* __restrict__ chunk_fn,
                                                          const uint8_t* __restrict__ tile_state, uint8_t* __restrict__ chunk_state,
                                                          uint32_t* __restrict__ chunk_cnt, uint32_t* __restrict__ chunk_str,
                                                          Cnt3* __restrict__ tile_cnt, uint32_t* status) {
@@ -496,7 +504,7 @@ __global__ __launch_bounds__(LEX_THREADS) void k_lex_count(const uint8_t* __rest
     if (threadIdx.x == 0) tile_cnt[blockIdx.x] = total;
 }
 
-__global__ __launch_bounds__(LEX_THREADS) void k_lex_emit(const uint8_t* __restrict__ src, uint32_t n, const uint8_t* __restrict__ chunk_state,
+__global__ LEX_ATTR __launch_bounds__(LEX_THREADS) void k_lex_emit(const uint8_t* __restrict__ src, uint32_t n, const uint8_t* __restrict__ chunk_state,
                                                         const uint32_t* __restrict__ chunk_cnt, const uint32_t* __restrict__ chunk_str,
                                                         const Cnt3* __restrict__ tile_off, opusfe_token* __restrict__ raw, uint64_t* __restrict__ val64,
                                                         uint8_t* __restrict__ strpool, uint32_t* status) {
