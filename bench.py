@@ -81,10 +81,12 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
+        import datetime
+        tmo = datetime.timedelta(seconds=300)      # a rank that fails must not leave the others waiting for ever
         if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=tmo)
         else:
-            dist.init_process_group(backend="gloo")
+            dist.init_process_group(backend="gloo", timeout=tmo)
     workload = args.workload or ("c3" if world == 1 else "c4")
 
     nbytes = int(args.bytes)
