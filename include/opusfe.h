@@ -127,6 +127,11 @@ int opusfe_shard_lex(opusfe_ctx* ctx, const uint8_t* d_src, uint64_t len, uint32
 int opusfe_shard_net_depth(opusfe_shard* shard, uint64_t prev_kinds, int64_t* net);
 int opusfe_shard_boundary(opusfe_shard* shard, int64_t depth_in, uint64_t* pos);
 void opusfe_shard_free(opusfe_shard* shard);
+/* own (+) hdr: a new parsed unit whose definition order is hdr's definitions that start before byte `split_pos` of hdr's
+   source, then own's, then the rest of hdr's; arrays concatenated and re-based on the GPU (no second parse of `own`).
+   `hdr` is the parsed text of the other shards' headers (those of the ranks before this one first).  No counterpart in
+   the reference (one file, one thread); for lowering a shard against the whole program's declarations. */
+int opusfe_unit_join(opusfe_ctx* ctx, opusfe_unit* own, opusfe_unit* hdr, uint64_t split_pos, opusfe_unit** out);
 /* device text (owned by the unit) that other shards prepend / append to see this unit's definitions: functions as
    `extern <signature>`, externs / types / globals verbatim, one per line, in file order */
 int opusfe_unit_headers(opusfe_unit* unit, const uint8_t** d_out, uint64_t* len);

@@ -9,6 +9,7 @@
 #include "lex.h"
 #include "parse.h"
 #include "lower.h"
+#include "join.h"
 #include "dump.h"
 #include "dump_ast.h"
 #include "dump_ir.h"
@@ -460,6 +461,59 @@ int opusfe_parse_batch(opusfe_ctx* ctx, uint32_t n, const uint8_t* const* srcs, 
     for (uint32_t i = 0; i < n; i++) if (statuses[i] >= OPUSFE_ERR_HIP && statuses[i] != OPUSFE_SEMANTIC) worst = statuses[i];
     if (worst != OPUSFE_OK) ctx->msg = "opusfe_parse_batch: a file failed with a device / argument error (see statuses)";
     return worst;
+}
+
+// own ⊕ hdr (join.h): one parsed unit whose definitions are hdr's definitions that start before byte `split_pos` of hdr's
+// source, then own's, then the rest of hdr's.  Neither input is modified; the result owns all of its arrays.
+int opusfe_unit_join(opusfe_ctx* ctx, opusfe_unit* own, opusfe_unit* hdr, uint64_t split_pos, opusfe_unit** out) {
+    if (!ctx || !own || !hdr || !out) return OPUSFE_ERR_ARG;
+    *out = nullptr;
+    if (own->ctx != ctx || hdr->ctx != ctx) return OPUSFE_ERR_ARG;
+    if (!own->parsed || own->status != OPUSFE_OK || !hdr->parsed || hdr->status != OPUSFE_OK) return fail(ctx, OPUSFE_ERR_ARG, "opusfe_unit_join needs two successfully parsed units");
+    return guarded(ctx, [&] {
+        const uint64_t a_len = (own->len + 63) & ~(uint64_t)63;          // H's source starts on a fresh 64-byte line
+        const uint64_t len = a_len + hdr->len, n_tok = own->n_tokens + hdr->n_tokens, n_nodes = own->n_nodes + hdr->n_nodes;
+        const uint64_t n_defs = own->n_defs + hdr->n_defs, n_val = own->n_val64 + hdr->n_val64, n_str = own->n_strpool + hdr->n_strpool;
+        if (len >= 0xFFFF0000ull || n_tok >= 0xFFFFFFF0ull || n_nodes >= 0xFFFFFFF0ull) return fail(ctx, OPUSFE_ERR_ARG, "joined unit too large for 32-bit positions");
+        hipStream_t st = ctx->stream;
+        opusfe_unit* u = new opusfe_unit();
+        u->ctx = ctx; u->status = OPUSFE_OK; u->len = len; u->own_src = true;
+        u->n_tokens = n_tok; u->n_nodes = n_nodes; u->n_defs = n_defs; u->n_val64 = n_val; u->n_strpool = n_str;
+        uint8_t* src = dev_alloc_t<uint8_t>(ctx, len + 64);
+        u->d_src = src;
+        u->d_tokens = dev_alloc_t<opusfe_token>(ctx, n_tok + 1);
+        u->d_val64 = dev_alloc_t<uint64_t>(ctx, n_val + 1);
+        u->d_strpool = dev_alloc_t<uint8_t>(ctx, n_str + 16);
+        u->d_nodes = dev_alloc_t<opusfe_node>(ctx, n_nodes + 1);
+        u->d_def_nodes = dev_alloc_t<uint32_t>(ctx, n_defs + 1);
+        try {
+            HIP_TRY(hipMemsetAsync(src, '\n', len + 64, st));
+            HIP_TRY(hipMemcpyAsync(src, own->d_src, own->len, hipMemcpyDeviceToDevice, st));
+            if (hdr->len) HIP_TRY(hipMemcpyAsync(src + a_len, hdr->d_src, hdr->len, hipMemcpyDeviceToDevice, st));
+            if (own->n_tokens) HIP_TRY(hipMemcpyAsync(u->d_tokens, own->d_tokens, own->n_tokens * sizeof(opusfe_token), hipMemcpyDeviceToDevice, st));
+            if (own->n_val64) HIP_TRY(hipMemcpyAsync(u->d_val64, own->d_val64, own->n_val64 * 8, hipMemcpyDeviceToDevice, st));
+            if (hdr->n_val64) HIP_TRY(hipMemcpyAsync(u->d_val64 + own->n_val64, hdr->d_val64, hdr->n_val64 * 8, hipMemcpyDeviceToDevice, st));
+            if (own->n_strpool) HIP_TRY(hipMemcpyAsync(u->d_strpool, own->d_strpool, own->n_strpool, hipMemcpyDeviceToDevice, st));
+            if (hdr->n_strpool) HIP_TRY(hipMemcpyAsync(u->d_strpool + own->n_strpool, hdr->d_strpool, hdr->n_strpool, hipMemcpyDeviceToDevice, st));
+            TempList tmp(ctx);
+            JoinSplit* split = tmp.get<JoinSplit>(1);
+            LAUNCH(ctx, "join_split", k_join_split, 1, 64, hdr->d_nodes, hdr->d_def_nodes, (uint32_t)hdr->n_defs, (uint32_t)hdr->n_nodes,
+                   (uint32_t)(split_pos > hdr->len ? hdr->len : split_pos), split);
+            if (hdr->n_tokens)
+                LAUNCH(ctx, "join_tokens", k_join_tokens, grid_for(hdr->n_tokens, 256), 256, hdr->d_tokens, (uint32_t)hdr->n_tokens, u->d_tokens + own->n_tokens,
+                       (uint32_t)a_len, (uint32_t)own->n_val64, (uint32_t)own->n_strpool);
+            if (n_nodes)
+                LAUNCH(ctx, "join_nodes", k_join_nodes, grid_for(n_nodes, 256), 256, own->d_nodes, (uint32_t)own->n_nodes, hdr->d_nodes, (uint32_t)hdr->n_nodes,
+                       split, (uint32_t)own->n_tokens, (uint32_t)a_len, u->d_nodes);
+            if (n_defs)
+                LAUNCH(ctx, "join_defs", k_join_defs, grid_for(n_defs, 256), 256, own->d_def_nodes, (uint32_t)own->n_defs, (uint32_t)own->n_nodes,
+                       hdr->d_def_nodes, (uint32_t)hdr->n_defs, split, u->d_def_nodes);
+            sync_stream(ctx);
+        } catch (...) { opusfe_free_unit(u); throw; }
+        u->parsed = true;
+        *out = u;
+        return (int)OPUSFE_OK;
+    });
 }
 
 // Text another shard needs to know about this unit's definitions (multi-GPU IR generation): device buffer owned by

@@ -69,6 +69,7 @@ def lib():
         L.opusfe_shard_boundary.argtypes = [vp, C.c_int64, C.POINTER(u64)]
         L.opusfe_shard_free.argtypes = [vp]
         L.opusfe_unit_headers.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
+        L.opusfe_unit_join.argtypes = [vp, vp, vp, u64, C.POINTER(vp)]
         L.opusfe_lower.argtypes = [vp, vp]
         L.opusfe_unit_status.argtypes = [vp]
         L.opusfe_get_counts.argtypes = [vp, C.POINTER(Counts)]
@@ -142,6 +143,15 @@ class Unit:
             raise OpusfeError(rc, self.ctx.message())
         self.status = rc
         return rc
+
+    def join(self, hdr, split_pos):
+        """self (+) hdr (opusfe_unit_join): a new parsed Unit with hdr's definitions that start before byte `split_pos` of
+        hdr's source, then self's, then the rest of hdr's."""
+        out = C.c_void_p()
+        rc = lib().opusfe_unit_join(self.ctx.handle, self.handle, hdr.handle, int(split_pos), C.byref(out))
+        if rc != OK:
+            raise OpusfeError(rc, self.ctx.message())
+        return Unit(self.ctx, out, OK)
 
     def headers_device(self):
         """(device pointer, length) of the definition-header text other shards need (opusfe_unit_headers)."""

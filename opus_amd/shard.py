@@ -167,8 +167,9 @@ def plan(states, gather):
 
 
 def compile_sharded(states, gather, lower=True):
-    """Steps 6-8: parse the owned bytes, exchange definition headers, compile own bytes between the others' headers.
-    Returns per state a dict(status, unit, ir) — `unit` is the unit of the combined source."""
+    """Steps 6-8: parse the owned bytes, exchange definition headers, lower the own definitions between the others' headers.
+    Returns per state a dict(status, unit, own_counts) — `unit` is the joined unit (headers of the ranks before, own
+    definitions, headers of the ranks after)."""
     world = states[0].world
     results = []
     parsed = []
@@ -194,15 +195,22 @@ def compile_sharded(states, gather, lower=True):
         own_counts = u.counts()
         before = [all_hdrs[q] for q in range(s.rank)]
         after = [all_hdrs[q] for q in range(s.rank + 1, world)]
-        nl = torch.full((1,), 10, dtype=torch.uint8, device=s.own.device)
-        combined = torch.cat(before + [s.own, nl] + after + [torch.zeros(64, dtype=torch.uint8, device=s.own.device)])
-        n = combined.numel() - 64
+        # The other ranks' headers are parsed as a unit of their own and JOINED with the unit of the owned bytes on the GPU
+        # (opusfe_unit_join: arrays concatenated and re-based in definition order): the owned gigabyte is parsed once.
+        split_pos = sum(int(t.numel()) for t in before)
+        htext = torch.cat(before + after + [torch.zeros(64, dtype=torch.uint8, device=s.own.device)])
+        n = htext.numel() - 64
         torch.cuda.synchronize()
-        u2 = s.ctx.get_definitions_device(combined.data_ptr(), n)
-        s._combined = combined
-        rc = u2.status
-        if rc == F.OK and lower:
-            rc = u2.compile_source()
+        uh = s.ctx.get_definitions_device(htext.data_ptr(), n)
+        s._hdr_text = htext
+        rc = uh.status
+        u2 = u
+        if rc == F.OK:
+            u2 = u.join(uh, split_pos)
+            if lower:
+                rc = u2.compile_source()
         results.append(dict(status=rc, unit=u2, own_counts=own_counts, first_bad_rank=None))
-        u.close()
+        uh.close()
+        if u2 is not u:
+            u.close()
     return results
