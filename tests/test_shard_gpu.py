@@ -101,3 +101,30 @@ def test_large_source_properties_whole_vs_sharded(fe):
         assert sum(r["unit"].counts()[key] for r in res) == whole[key], key
     for r in res:
         r["unit"].close()
+
+
+def test_unit_join_equals_parsing_the_concatenated_text(fe):
+    """opusfe_unit_join(own, hdr, split) must lower exactly like one parse of before + own + after: literal pools of the
+    header unit (big integers, strings), type definitions, globals, overloads on both sides of the owned text."""
+    before = ('type Pair = record { a int32 b float64 }\nconst BIG nat64 = 18446744073709551615\nvar PI float64\n'
+              'library "before lib"\ntype Arr = {12} nat16\nextern ext1(x int32) int32\nextern over(x int32) int32\nvar counter int32 = 7\n')
+    own = ('over(x int64) int64\n\treturn x + 1i64\n'
+           'f(p Pair, q @mut Pair) float64\n\tq@.a = ext1(p.a) + over(counter) + tail(2)\n\tvar big = BIG\n\tvar w Wide\n\treturn p.b * PI + SCALE\n'
+           'g() int64\n\treturn over(5i64)\n')
+    after = ('type Wide = record { p Pair n nat64 }\nvar SCALE float64\nlibrary "after lib"\nextern tail(x int32) int32\nconst LAST nat64 = 4294967296\n')
+    whole = (before + own + after).encode()
+    assert O.dump(whole, O.ERROR) == "Ok\n"
+    a = fe.get_definitions(own.encode())
+    h = fe.get_definitions((before + after).encode())
+    assert a.status == 0 and h.status == 0
+    j = a.join(h, len(before))
+    assert j.compile_source() == 0, fe.message()
+    assert j.dump_ir() == O.dump(whole, O.IR)
+    assert j._dump(4) == O.dump(whole, O.SEM)
+    # degenerate splits: everything before / everything after / no headers at all
+    for text, split in ((before + after, len(before + after)), (before + after, 0), ("", 0)):
+        h2 = fe.get_definitions(text.encode())
+        j2 = a.join(h2, split)
+        c = j2.counts()
+        assert c["definitions"] == a.counts()["definitions"] + h2.counts()["definitions"]
+        j2.close(); h2.close()
