@@ -1335,10 +1335,11 @@ __global__ void k_sem_user_syms(SemView S, uint64_t* __restrict__ out) {
 // one lane per function definition
 __global__ MACHINE_ATTR(OPUSFE_LOWER_WAVES) __launch_bounds__(64) void k_lower_functions(SemView S, LowerBuffers B, const uint8_t* __restrict__ undefined_flag, const uint32_t* __restrict__ def_nodes,
                                                          uint32_t n_defs, uint32_t n_nodes, uint32_t n_tokens, const DefCnt* __restrict__ def_excl, FuncIr* __restrict__ out,
-                                                         uint32_t* __restrict__ status, uint64_t* __restrict__ prof_out, const uint64_t* __restrict__ user_syms) {
-    const uint32_t d = blockIdx.x * (blockDim.x / UNIT_LANES) + threadIdx.x / UNIT_LANES;
+                                                         uint32_t* __restrict__ status, uint64_t* __restrict__ prof_out, const uint64_t* __restrict__ user_syms, const uint32_t* __restrict__ order) {
+    const uint32_t slot = blockIdx.x * (blockDim.x / UNIT_LANES) + threadIdx.x / UNIT_LANES;
     const uint32_t lane = threadIdx.x % UNIT_LANES;
-    if (d >= n_defs) return;
+    if (slot >= n_defs) return;
+    const uint32_t d = order ? order[slot] : slot;
     const uint32_t dn = def_nodes[d];
     if (S.nodes[dn].kind != D_Function) return;
     const uint32_t fidx = def_excl[d].funcs;
@@ -1566,8 +1567,14 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
     LAUNCH(ctx, "sem_user_syms", k_sem_user_syms, 1, 64, S, user_syms);
     uint64_t* prof_buf = tmp.get<uint64_t>(LP_COUNT);
     HIP_TRY(hipMemsetAsync(prof_buf, 0, LP_COUNT * 8, st));
+    uint32_t* order = tmp.get<uint32_t>(n_defs);
+    uint32_t* order_hist = tmp.get<uint32_t>(33);
+    HIP_TRY(hipMemsetAsync(order_hist, 0, 33 * sizeof(uint32_t), st));
+    LAUNCH(ctx, "order_hist", k_order_hist, grid_for(n_defs, 256), 256, u->d_def_nodes, n_defs, n_nodes, order_hist);
+    LAUNCH(ctx, "order_scan", k_order_scan, 1, 64, order_hist);
+    LAUNCH(ctx, "order_scatter", k_order_scatter, grid_for(n_defs, 256), 256, u->d_def_nodes, n_defs, n_nodes, order_hist, order);
     LAUNCH(ctx, "lower_functions", k_lower_functions, grid_for((uint64_t)n_defs * UNIT_LANES, 64), 64, S, B, undefined_flag, u->d_def_nodes, n_defs, n_nodes, (uint32_t)u->n_tokens, def_excl, R->d_funcs,
-           ctx->d_status + WL_STATUS, prof_buf, user_syms);
+           ctx->d_status + WL_STATUS, prof_buf, user_syms, (const uint32_t*)order);
 #ifdef OPUSFE_LOWER_PROF
     {
         uint64_t h[LP_COUNT];

@@ -684,10 +684,11 @@ struct SegParser {
 
 __global__ MACHINE_ATTR(OPUSFE_PARSE_WAVES) __launch_bounds__(64) void k_parse_segments(const opusfe_token* __restrict__ tok, uint32_t n_tokens, const uint32_t* __restrict__ seg_start,
                                                         uint32_t n_segs, opusfe_node* __restrict__ nodes, PFrame* __restrict__ frames,
-                                                        uint32_t* __restrict__ seg_info, uint32_t* __restrict__ status, uint32_t* __restrict__ first_err_seg) {
-    const uint32_t s = blockIdx.x * (blockDim.x / UNIT_LANES) + threadIdx.x / UNIT_LANES;
+                                                        uint32_t* __restrict__ seg_info, uint32_t* __restrict__ status, uint32_t* __restrict__ first_err_seg, const uint32_t* __restrict__ order) {
+    const uint32_t slot = blockIdx.x * (blockDim.x / UNIT_LANES) + threadIdx.x / UNIT_LANES;
     const uint32_t lane = threadIdx.x % UNIT_LANES;
-    if (s >= n_segs) return;
+    if (slot >= n_segs) return;
+    const uint32_t s = order ? order[slot] : slot;     // largest segments first (scan.h)
     uint32_t tb = seg_start[s], te = (s + 1 < n_segs) ? seg_start[s + 1] : n_tokens;
     SegParser P;    // no fields of its own: the state is static LDS (see lower.h)
     P.tok.p = tok; P.nodes = nodes; P.n_tokens = n_tokens;
@@ -815,8 +816,14 @@ inline void run_parser(opusfe_ctx* ctx, opusfe_unit* u) {
     Cnt2* scan_tmp = tmp.get<Cnt2>((n_segs + SCAN_TILE - 1) / SCAN_TILE + 1);
     uint32_t init[4] = {0xFFFFFFFFu, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(ctx->d_status + WP_FIRST_ERR, init, sizeof init, hipMemcpyHostToDevice, st));
+    uint32_t* order = tmp.get<uint32_t>(n_segs);
+    uint32_t* order_hist = tmp.get<uint32_t>(33);
+    HIP_TRY(hipMemsetAsync(order_hist, 0, 33 * sizeof(uint32_t), st));
+    LAUNCH(ctx, "order_hist", k_order_hist, grid_for(n_segs, 256), 256, u->d_seg_start, n_segs, n_tok, order_hist);
+    LAUNCH(ctx, "order_scan", k_order_scan, 1, 64, order_hist);
+    LAUNCH(ctx, "order_scatter", k_order_scatter, grid_for(n_segs, 256), 256, u->d_seg_start, n_segs, n_tok, order_hist, order);
     LAUNCH(ctx, "parse_segments", k_parse_segments, grid_for((uint64_t)n_segs * UNIT_LANES, 64), 64, u->d_tokens, n_tok, u->d_seg_start, n_segs, sparse, frames,
-           u->d_seg_info, ctx->d_status, ctx->d_status + WP_FIRST_ERR);
+           u->d_seg_info, ctx->d_status, ctx->d_status + WP_FIRST_ERR, (const uint32_t*)order);
 #ifdef OPUSFE_PARSE_PROF
     {
         unsigned long long h[128];

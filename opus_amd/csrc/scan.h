@@ -154,4 +154,43 @@ struct OpAddCnt3 { __host__ __device__ Cnt3 operator()(Cnt3 a, Cnt3 b) const { r
 // "last defined value": element = value | (1 << 31) when defined
 struct OpLast { __host__ __device__ uint32_t operator()(uint32_t a, uint32_t b) const { return (b >> 31) ? b : a; } };
 
+#ifndef OPUSFE_EMU
+// ---- largest units first ---------------------------------------------------------------------------
+// One wave works through one unit (parser: segment, lowering: function) from start to end, so a long unit that is
+// dispatched late finishes long after everything else.  Units are therefore dispatched by size class (bit length of
+// their token / node count, largest class first): a counting sort over 33 classes.  The order only decides WHEN a function runs, never what it produces.
+// (class counters are kept in LDS per workgroup: one global atomic per class and workgroup instead of one per unit)
+__device__ __forceinline__ uint32_t order_class(const uint32_t* __restrict__ start, uint32_t n, uint32_t end_all, uint32_t i) {
+    const uint32_t size = (i + 1 < n ? start[i + 1] : end_all) - start[i];
+    return 32u - (size ? (uint32_t)__builtin_clz(size) : 32u);
+}
+__global__ __launch_bounds__(256) void k_order_hist(const uint32_t* __restrict__ start, uint32_t n, uint32_t end_all, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t h[33];
+    if (threadIdx.x < 33) h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicAdd(&h[order_class(start, n, end_all, i)], 1u);
+    __syncthreads();
+    if (threadIdx.x < 33 && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+__global__ void k_order_scan(uint32_t* __restrict__ hist) {          // in place: count -> first output slot, largest class first
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    uint32_t acc = 0;
+    for (int c = 32; c >= 0; c--) { uint32_t v = hist[c]; hist[c] = acc; acc += v; }
+}
+__global__ __launch_bounds__(256) void k_order_scatter(const uint32_t* __restrict__ start, uint32_t n, uint32_t end_all, uint32_t* __restrict__ hist, uint32_t* __restrict__ order) {
+    __shared__ uint32_t h[33], base[33];
+    if (threadIdx.x < 33) h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t c = 0, mine = 0;
+    if (i < n) { c = order_class(start, n, end_all, i); mine = atomicAdd(&h[c], 1u); }
+    __syncthreads();
+    if (threadIdx.x < 33 && h[threadIdx.x]) base[threadIdx.x] = atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+    __syncthreads();
+    if (i < n) order[base[c] + mine] = i;
+}
+
+#endif
+
 }  // namespace opusfe

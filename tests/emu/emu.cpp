@@ -122,7 +122,7 @@ void emu_parse(EmuUnit& E) {
     E.seg_info.assign((size_t)n_segs * SI_WORDS, 0);
     uint32_t first_err = 0xFFFFFFFFu;
     emu_launch(k_parse_segments, grid_for(n_segs, 64), 64, u.h_tokens.data(), n_tok, E.seg_start.data(), n_segs, sparse.data(), frames.data(),
-               E.seg_info.data(), E.status, &first_err);
+               E.seg_info.data(), E.status, &first_err, (const uint32_t*)nullptr);
     if (getenv("EMU_VERBOSE")) for (uint32_t s = 0; s < n_segs; s++) { uint32_t k = E.seg_info[(size_t)s * SI_WORDS + SI_ERR_KIND]; if (k != OPUSFE_NONE && (k & 0x200u)) fprintf(stderr, "segment %u of %u: internal condition %u (first error segment %u)\n", s, n_segs, k & 0xFF, first_err); }
     std::vector<Cnt2> cnt(n_segs);
     emu_launch(k_ast_counts, grid_for(n_segs, 256), 256, E.seg_info.data(), n_segs, cnt.data());
@@ -219,7 +219,7 @@ void emu_lower(EmuUnit& E) {
     uint64_t user_syms = 0;
     emu_launch(k_sem_user_syms, 1, 1, S, &user_syms);
     emu_launch(k_lower_functions, grid_for(n_defs, 64), 64, S, B, (const uint8_t*)undefined_flag.data(), def_nodes, n_defs, n_nodes, (uint32_t)u.n_tokens, (const DefCnt*)def_excl.data(),
-               R->funcs.data(), lstatus, (uint64_t*)nullptr, (const uint64_t*)&user_syms);
+               R->funcs.data(), lstatus, (uint64_t*)nullptr, (const uint64_t*)&user_syms, (const uint32_t*)nullptr);
     std::vector<IrCnt> cnt(n_funcs);
     emu_launch(k_ir_counts, grid_for(n_funcs, 256), 256, (const FuncIr*)R->funcs.data(), n_funcs, cnt.data());
     IrCnt tot{0, 0, 0, 0, 0, 0};
