@@ -1,5 +1,7 @@
 // IR generation on the GPU.  Restates generate_ir.rs (IrGenerator, :75-1199) as an explicit-stack machine:
-// one lane lowers one function (functions only depend on the global tables of sem.h, SURVEY §7 hard part 3).
+// one WAVE lowers one function (functions only depend on the global tables of sem.h, SURVEY §7 hard part 3); all 64
+// lanes run the same steps (wave-uniform control flow), the machine's registers are static LDS variables, read-only
+// tables come in by scalar loads, outputs are staged in LDS and leave as whole lines.
 //
 // Emission order is the reference's: variables are numbered in creation order, basic blocks in creation order,
 // and every instruction is tagged (bb, rank-in-bb) at push time — deferred terminators (`bbs[branch].push(..)`,

@@ -1,9 +1,10 @@
 // GPU parser for gfx950.  Restates parse.rs:723-1355 (recursive descent, LL(1) on the peeked token)
 // as an explicit-stack pushdown machine so that nesting depth (1000-deep blocks / parentheses /
-// pointer types) costs global-memory frames instead of call-stack recursion.
+// pointer types) costs frames (the top of the stack in LDS, the rest in global memory) instead of call-stack recursion.
 //
 // Unit of parallelism: one top-level SEGMENT (lex.h k_final: the run of tokens between two returns
-// of the indentation to column 0) per lane.  Segments contain whole definitions, so lanes never
+// of the indentation to column 0) per WAVE (wave-uniform control flow, machine state in LDS, tokens by scalar loads,
+// the newest nodes in an LDS ring).  Segments contain whole definitions, so waves never
 // communicate; the first syntax error of the file is the error of the lowest-numbered failing
 // segment (frontend.rs:130-133 stops at the first Err).
 //
