@@ -48,3 +48,32 @@ def test_empty_corpus_and_empty_file(fe):
     u = fe.compile_corpus([b"", b"; nothing\n"])
     assert [x.status for x in u] == [0, 0]
     assert all(x.dump_ir() == "" for x in u)
+
+
+def test_differential_fuzz_small_sources(fe):
+    """tools/fuzz_parity.py in small: generated sources of random size, every fifth with an injected syntax error, some
+    truncated at a random byte; whole path through opusfe_parse_batch against the oracle"""
+    import random
+    rnd = random.Random(4)
+    srcs = []
+    for k in range(160):
+        s = O.generate(7000 + k, rnd.randint(2000, 30000))
+        if k % 5 == 3:
+            s = O.inject(s, 7000 + k, k % 3)
+        if k % 11 == 7:
+            s = s[:rnd.randint(1, len(s))]
+        srcs.append(s)
+    units = fe.compile_corpus(srcs, lower=True)
+    for s, u in zip(srcs, units):
+        want_err = O.dump(s, O.ERROR)
+        if want_err == "Unsupported\n":
+            assert u.status == 2
+        elif want_err != "Ok\n":
+            assert u.status == 1 and u.dump_error() == want_err
+        else:
+            want_ir, want_sem = O.dump(s, O.IR), O.dump(s, O.SEM)
+            if want_ir == "" and want_sem != "":
+                assert u.status == 7
+            else:
+                assert u.status == 0 and u.dump_ir() == want_ir and u._dump(4) == want_sem
+        u.close()

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Differential fuzzing on the GPU box: many small generated sources (some with injected syntax errors) through
+opusfe_parse_batch, every result compared with the CPU oracle (IR text, semantic diagnostics, first-error line).
+usage: python tools/fuzz_parity.py [--seeds 300] [--first 1000]        exit status 1 on the first mismatch"""
+import argparse
+import os
+import random
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seeds", type=int, default=300)
+    ap.add_argument("--first", type=int, default=1000)
+    args = ap.parse_args()
+    import opus_amd
+    import oracle_lib as O
+    rnd = random.Random(99)
+    srcs = []
+    for k in range(args.seeds):
+        s = O.generate(args.first + k, rnd.randint(2000, 40000), flags=0)
+        if k % 5 == 3:
+            s = O.inject(s, args.first + k, k % 3)
+        if k % 11 == 7:
+            s = s[:rnd.randint(1, len(s))]
+        srcs.append(s)
+    ctx = opus_amd.Context(0)
+    units = ctx.compile_corpus(srcs, lower=True)
+    bad = 0
+    for k, (s, u) in enumerate(zip(srcs, units)):
+        want_err = O.dump(s, O.ERROR)
+        if want_err == "Unsupported\n":
+            ok = u.status == 2
+        elif want_err != "Ok\n":
+            ok = u.status == 1 and u.dump_error() == want_err
+        else:
+            want_ir, want_sem = O.dump(s, O.IR), O.dump(s, O.SEM)
+            if want_ir == "" and want_sem != "":
+                ok = u.status == 7
+            else:
+                ok = u.status == 0 and u.dump_ir() == want_ir and u._dump(4) == want_sem
+        if not ok:
+            bad += 1
+            path = os.path.join(ROOT, "gpurun_out", f"fuzz_bad_{args.first + k}.opus")
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            open(path, "wb").write(s)
+            print(f"MISMATCH seed {args.first + k}: status {u.status}, oracle error line {want_err.strip()!r} -> {path}", flush=True)
+        u.close()
+    print(f"fuzz: {len(srcs)} sources, {bad} mismatches", flush=True)
+    ctx.close()
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
