@@ -149,6 +149,56 @@ int opusfe_get_counts(const opusfe_unit* unit, opusfe_counts* out);
 int opusfe_get_error(const opusfe_unit* unit, opusfe_error* out);
 /* copies device result arrays to caller-provided host buffers (cap in elements); returns element count via *n */
 int opusfe_copy_tokens(opusfe_unit* unit, opusfe_token* dst, uint64_t cap, uint64_t* n);
+/* ---- flat result arrays: what a host backend reads instead of IrGenerator's fields
+   (generate_ir.rs:58-98 `variables`, `bbs`, `function`; llvm.rs:355-420 walks exactly these) ----
+   Ids: variables and basic blocks are numbered per function from 0 (dst/a/b and Jump/Branch/Phi targets are those local
+   numbers; add var_base / bb_base of the function for the global arrays); type ids index OPUSFE_A_TYPES directly. */
+typedef struct opusfe_function_ir {      /* one per Definition::Function / extern, in definition order; n_bbs == 0: extern */
+    uint32_t def_node;                   /* root node of the definition */
+    uint32_t func;                       /* index into OPUSFE_A_SIGNATURES */
+    uint32_t n_vars, n_instrs, n_bbs, n_types, n_call_args, n_errors;
+    uint32_t var_base, instr_base, bb_base, type_base, call_arg_base, error_base;
+    uint32_t status, _pad;
+} opusfe_function_ir;
+typedef struct opusfe_type {             /* compile.rs:45-75 Type, structural */
+    uint8_t kind;                        /* variant index in compile.rs:45-75 order (Integer8 .. Error) */
+    uint8_t ptr;                         /* Pointer: 0 @, 1 @mut, 2 {}, 3 mut {} (compile.rs:38-43 PointerType) */
+    uint8_t src;                         /* Function: 1 = `ref` is a proc-type node, 2 = `ref` is a signature index */
+    uint8_t _pad;
+    uint32_t sub;                        /* Pointer / Array: element type id; Function: return type id */
+    uint32_t ref;                        /* Record: record-type node (children = fields); Function: see src; Array: length token */
+    uint32_t alias;                      /* name token of the `type` definition this id stands for, else 0xFFFFFFFF */
+} opusfe_type;
+typedef struct opusfe_signature {        /* compile.rs:300-352 Function / FunctionSignature */
+    uint32_t def_node, name_tok, nargs, ret_type, first_arg /* node; siblings follow */, flags /* bit0 extern */;
+} opusfe_signature;
+typedef struct opusfe_global { uint32_t def_node, type_id, is_const, name_tok; } opusfe_global;
+typedef struct opusfe_semantic_error { uint32_t kind /* compile.rs:124-152 variant index */, low, len; } opusfe_semantic_error;
+
+enum {
+    OPUSFE_A_SOURCE = 0,      /* uint8_t   source bytes */
+    OPUSFE_A_TOKENS = 1,      /* opusfe_token */
+    OPUSFE_A_VAL64 = 2,       /* uint64_t  integer / float-bit / error payload pool */
+    OPUSFE_A_STRINGS = 3,     /* uint8_t   string pool: [u32 n][n bytes] padded to 4 */
+    OPUSFE_A_NODES = 4,       /* opusfe_node, dense, definitions in file order, pre-order inside a definition */
+    OPUSFE_A_DEFINITIONS = 5, /* uint32_t  root node of each definition */
+    OPUSFE_A_SIGNATURES = 6,  /* opusfe_signature, one per function / extern (after opusfe_lower) */
+    OPUSFE_A_GLOBALS = 7,     /* opusfe_global */
+    OPUSFE_A_TYPES = 8,       /* opusfe_type */
+    OPUSFE_A_NODE_TYPES = 9,  /* uint32_t  per node: resolved type id of a type node (compile.rs:919 resolve_type), else 0xFFFFFFFF */
+    OPUSFE_A_FUNCTIONS = 10,  /* opusfe_function_ir */
+    OPUSFE_A_VARIABLES = 11,  /* opusfe_variable  (generate_ir.rs:69 variables) */
+    OPUSFE_A_BB_OFFSETS = 12, /* uint32_t  bbs + 1 entries: instructions of global bb g are [off[g], off[g+1]) */
+    OPUSFE_A_INSTRS = 13,     /* opusfe_instr */
+    OPUSFE_A_CALL_ARGS = 14,  /* uint32_t  variable ids of Call arguments (instr.c = offset, instr.sub = count) */
+    OPUSFE_A_SEM_ERRORS = 15, /* opusfe_semantic_error, in report order */
+    OPUSFE_A_COUNT = 16
+};
+/* device pointer (owned by the unit, valid until opusfe_free_unit / the next opusfe_lower), element count and size */
+int opusfe_array(opusfe_unit* unit, int which, const void** d_ptr, uint64_t* count, uint32_t* elem_size);
+/* device -> host copy of one array; dst == NULL only queries *n; cap in elements */
+int opusfe_copy_array(opusfe_unit* unit, int which, void* dst, uint64_t cap, uint64_t* n);
+
 /* canonical text dumps (formats: SURVEY.md §8c).  what: 0 tokens, 1 AST, 2 IR, 3 first-error line, 4 semantic errors of IR generation.
    *out is malloc'ed by the library; release with opusfe_free_text. */
 int opusfe_dump(opusfe_unit* unit, int what, char** out, uint64_t* out_len);

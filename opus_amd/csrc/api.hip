@@ -579,6 +579,53 @@ int opusfe_copy_tokens(opusfe_unit* u, opusfe_token* dst, uint64_t cap, uint64_t
     });
 }
 
+static_assert(sizeof(opusfe_function_ir) == sizeof(FuncIr) && sizeof(opusfe_type) == sizeof(TypeRec) && sizeof(opusfe_signature) == sizeof(FuncRec)
+              && sizeof(opusfe_global) == sizeof(GlobalRec) && sizeof(opusfe_semantic_error) == sizeof(SemErr), "public records mirror the device records");
+
+int opusfe_array(opusfe_unit* u, int which, const void** d_ptr, uint64_t* count, uint32_t* elem_size) {
+    if (!u || which < 0 || which >= OPUSFE_A_COUNT) return OPUSFE_ERR_ARG;
+    // the IR-side arrays exist only after a successful opusfe_lower (finalize errors leave no IR, frontend.rs:145)
+    const IrResult* R = u->lowered && u->status == OPUSFE_OK ? (const IrResult*)u->ir : nullptr;
+    const void* p = nullptr; uint64_t n = 0; uint32_t es = 0;
+    switch (which) {
+        case OPUSFE_A_SOURCE: p = u->d_src; n = u->len; es = 1; break;
+        case OPUSFE_A_TOKENS: p = u->d_tokens; n = u->n_tokens; es = sizeof(opusfe_token); break;
+        case OPUSFE_A_VAL64: p = u->d_val64; n = u->n_val64; es = 8; break;
+        case OPUSFE_A_STRINGS: p = u->d_strpool; n = u->n_strpool; es = 1; break;
+        case OPUSFE_A_NODES: p = u->d_nodes; n = u->n_nodes; es = sizeof(opusfe_node); break;
+        case OPUSFE_A_DEFINITIONS: p = u->d_def_nodes; n = u->n_defs; es = 4; break;
+        case OPUSFE_A_SIGNATURES: es = sizeof(FuncRec); if (R) { p = R->d_funcrecs; n = R->n_funcs; } break;
+        case OPUSFE_A_GLOBALS: es = sizeof(GlobalRec); if (R) { p = R->d_globals; n = R->n_globals; } break;
+        case OPUSFE_A_TYPES: es = sizeof(TypeRec); if (R) { p = R->d_types; n = R->n_types; } break;
+        case OPUSFE_A_NODE_TYPES: es = 4; if (R) { p = R->d_tid_of_node; n = u->n_nodes; } break;
+        case OPUSFE_A_FUNCTIONS: es = sizeof(FuncIr); if (R) { p = R->d_funcs; n = R->n_funcs; } break;
+        case OPUSFE_A_VARIABLES: es = sizeof(opusfe_variable); if (R) { p = R->d_vars; n = R->n_vars; } break;
+        case OPUSFE_A_BB_OFFSETS: es = 4; if (R) { p = R->d_bb_offsets; n = R->n_bbs + 1; } break;
+        case OPUSFE_A_INSTRS: es = sizeof(opusfe_instr); if (R) { p = R->d_instrs; n = R->n_instrs; } break;
+        case OPUSFE_A_CALL_ARGS: es = 4; if (R) { p = R->d_cargs; n = R->n_cargs; } break;
+        case OPUSFE_A_SEM_ERRORS: es = sizeof(SemErr); if (R) { p = R->d_errs; n = R->n_errs; } break;
+    }
+    if (!p) n = 0;   // a stage that did not run (or stopped early) has no array
+    if (d_ptr) *d_ptr = n ? p : nullptr;
+    if (count) *count = n;
+    if (elem_size) *elem_size = es;
+    return OPUSFE_OK;
+}
+
+int opusfe_copy_array(opusfe_unit* u, int which, void* dst, uint64_t cap, uint64_t* n) {
+    const void* p = nullptr; uint64_t cnt = 0; uint32_t es = 0;
+    int rc = opusfe_array(u, which, &p, &cnt, &es);
+    if (rc != OPUSFE_OK || !n) return OPUSFE_ERR_ARG;
+    *n = cnt;
+    if (!dst) return OPUSFE_OK;
+    if (cap < cnt) return OPUSFE_ERR_ARG;
+    return guarded(u->ctx, [&] {
+        HIP_TRY(hipStreamSynchronize(u->ctx->stream));
+        if (cnt) HIP_TRY(hipMemcpy(dst, p, cnt * es, hipMemcpyDeviceToHost));
+        return (int)OPUSFE_OK;
+    });
+}
+
 int opusfe_dump(opusfe_unit* u, int what, char** out, uint64_t* out_len) {
     if (!u || !out) return OPUSFE_ERR_ARG;
     *out = nullptr;

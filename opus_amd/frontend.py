@@ -75,6 +75,8 @@ def lib():
         L.opusfe_get_counts.argtypes = [vp, C.POINTER(Counts)]
         L.opusfe_get_error.argtypes = [vp, C.POINTER(Error)]
         L.opusfe_copy_tokens.argtypes = [vp, vp, u64, C.POINTER(u64)]
+        L.opusfe_array.argtypes = [vp, i, C.POINTER(vp), C.POINTER(u64), C.POINTER(u32)]
+        L.opusfe_copy_array.argtypes = [vp, i, vp, u64, C.POINTER(u64)]
         L.opusfe_dump.argtypes = [vp, i, C.POINTER(vp), C.POINTER(u64)]
         L.opusfe_free_text.argtypes = [vp]
         L.opusfe_free_unit.argtypes = [vp]
@@ -160,6 +162,31 @@ class Unit:
         if rc != OK:
             raise OpusfeError(rc, self.ctx.message())
         return p.value or 0, n.value
+
+    def array(self, which):
+        """numpy copy of one flat result array (opusfe_copy_array; ids and record layouts in opus_amd/ir_view.py)"""
+        import numpy as np
+        from .ir_view import DTYPES
+        n = C.c_uint64()
+        if lib().opusfe_copy_array(self.handle, which, None, 0, C.byref(n)) != OK:
+            raise OpusfeError(ERR_ARG, f"no array {which}")
+        arr = np.empty(n.value, dtype=DTYPES[which])
+        rc = lib().opusfe_copy_array(self.handle, which, arr.ctypes.data, n.value, C.byref(n))
+        if rc != OK:
+            raise OpusfeError(rc, self.ctx.message())
+        return arr
+
+    def array_device(self, which):
+        """(device pointer, element count, element size) of one flat result array (opusfe_array)"""
+        p, n, es = C.c_void_p(), C.c_uint64(), C.c_uint32()
+        if lib().opusfe_array(self.handle, which, C.byref(p), C.byref(n), C.byref(es)) != OK:
+            raise OpusfeError(ERR_ARG, f"no array {which}")
+        return p.value or 0, n.value, es.value
+
+    def ir_view(self):
+        """backend hand-off view over the arrays (opus_amd/ir_view.py)"""
+        from .ir_view import IrView
+        return IrView(self)
 
     def tokens(self):
         n = C.c_uint64()

@@ -27,6 +27,21 @@ def test_record_sizes_match_the_header():
     assert C.sizeof(F.Token) == 16
     assert C.sizeof(F.Error) == 48
     assert C.sizeof(F.Counts) == 9 * 8
+    # flat result arrays (opusfe_array): numpy record layouts of opus_amd/ir_view.py against the sizes in the header
+    from opus_amd import ir_view as V
+    import numpy as np
+    sizes = {V.A_TOKENS: 16, V.A_NODES: 24, V.A_INSTRS: 24, V.A_VARIABLES: 8, V.A_TYPES: 16, V.A_SIGNATURES: 24, V.A_GLOBALS: 16,
+             V.A_FUNCTIONS: 64, V.A_SEM_ERRORS: 12, V.A_VAL64: 8, V.A_DEFINITIONS: 4}
+    for which, size in sizes.items():
+        assert np.dtype(V.DTYPES[which]).itemsize == size, which
+    assert len(V.DTYPES) == 16
+
+
+def test_hand_off_text_helpers_follow_rust_formatting():
+    from opus_amd import ir_view as V
+    assert V.rust_f64(1.0) == "1" and V.rust_f64(0.1) == "0.1" and V.rust_f64(1e21) == "1000000000000000000000"
+    assert V.rust_f64(1.5e-7) == "0.00000015" and V.rust_f64(float("inf")) == "inf"
+    assert V.rust_debug_str(b'a"\n\x01\\') == '"a\\"\\n\\u{1}\\\\"'
 
 
 def test_no_gpu_means_loud_failure_not_a_cpu_path():

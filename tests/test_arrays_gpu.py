@@ -1,0 +1,104 @@
+"""GPU: the flat result arrays of the boundary (opusfe_array / opusfe_copy_array) and the backend hand-off view
+built on them (opus_amd/ir_view.py; backend/mod.rs:6-10, llvm.rs:355-420 read exactly these fields)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from opus_amd import ir_view as V
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+with open(os.path.join(HERE, "golden", "kats.json")) as f:
+    KATS = json.load(f)
+
+
+def test_arrays_of_a_kat_render_the_hand_derived_ir(fe):
+    for k in ("kat1", "kat2", "kat3"):
+        u = fe.get_definitions(KATS[k]["src"].encode())
+        assert u.compile_source() == 0
+        assert u.ir_view().text() == KATS[k]["ir"]
+
+
+def test_array_counts_agree_with_counts_and_structure(fe):
+    src = O.generate(31, 300_000)
+    u = fe.get_definitions(src)
+    assert u.compile_source() == 0
+    c, v = u.counts(), u.ir_view()
+    assert len(v.source) == len(src) and v.source == src
+    assert len(v.tokens) == c["tokens"] and len(v.nodes) == c["nodes"] and len(v.definitions) == c["definitions"]
+    assert len(v.functions) == c["functions"] == len(v.signatures)
+    assert len(v.variables) == c["vars"] and len(v.instrs) == c["instrs"] and len(v.bb_offsets) == c["bbs"] + 1
+    assert len(v.types) == c["types"] and len(v.node_types) == c["nodes"]
+    # bb_offsets is a monotone partition of the instruction array; the per-function bases tile the global arrays
+    off = v.bb_offsets.astype(np.int64)
+    assert off[0] == 0 and off[-1] == len(v.instrs) and (np.diff(off) >= 0).all()
+    f = v.functions
+    for name, base in (("n_vars", "var_base"), ("n_instrs", "instr_base"), ("n_bbs", "bb_base")):
+        want = np.concatenate([[0], np.cumsum(f[name].astype(np.int64))[:-1]])
+        assert (f[base].astype(np.int64) == want).all(), name
+    # every operand of every instruction is a variable of its own function; every jump target one of its blocks
+    for i in range(0, len(v), max(1, len(v) // 50)):
+        fv = v.function(i)
+        nv, nb = len(fv.variables), len(fv.bbs)
+        for bb in fv.bbs:
+            assert len(bb) > 0
+            for ins in bb:
+                op = int(ins["opcode"])
+                if op in (V.I_LOAD, V.I_NOT, V.I_NEGATE, V.I_CAST):
+                    assert int(ins["dst"]) < nv and int(ins["a"]) < nv
+                if op == V.I_JUMP:
+                    assert int(ins["c"]) < nb
+                if op == V.I_BRANCH:
+                    assert int(ins["a"]) < nv and int(ins["b"]) < nb and int(ins["c"]) < nb
+                if op == V.I_CALL:
+                    assert all(int(x) < nv for x in fv.call_args(ins))
+    # definitions are in file order and each root node's span starts where its definition does
+    lows = v.nodes["low"][v.definitions]
+    assert (np.diff(lows.astype(np.int64)) > 0).all()
+    assert v.text() == O.dump(src, O.IR)
+
+
+def test_get_lvalue_type_is_the_pointee(fe):
+    src = b"f(x int32) int32\n\tvar y int32 = x\n\ty = y + 1\n\treturn y\n"
+    u = fe.get_definitions(src)
+    assert u.compile_source() == 0
+    fv = u.ir_view().function(0)
+    allocs = [int(i["dst"]) for bb in fv.bbs for i in bb if int(i["opcode"]) == V.I_ALLOCATE]
+    assert allocs, "locals are allocated lvalues (generate_ir.rs:100-116)"
+    for a in allocs:
+        assert u.ir_view().type_text(fv.get_lvalue_type(a)) == "int32"
+    with pytest.raises(ValueError):
+        loads = [int(i["dst"]) for bb in fv.bbs for i in bb if int(i["opcode"]) == V.I_LOAD]
+        fv.get_lvalue_type(loads[0])
+
+
+def test_device_pointers_and_states(fe):
+    u = fe.get_definitions(b"f() int32\n\treturn 1\n")
+    # before lowering: front-half arrays only
+    assert u.array_device(V.A_TOKENS)[1] == u.counts()["tokens"] and u.array_device(V.A_TOKENS)[2] == 16
+    assert u.array_device(V.A_NODES)[2] == 24 and u.array_device(V.A_INSTRS)[1] == 0 and u.array_device(V.A_INSTRS)[0] == 0
+    assert u.compile_source() == 0
+    p, n, es = u.array_device(V.A_INSTRS)
+    assert p != 0 and n == u.counts()["instrs"] and es == 24
+    assert u.array_device(V.A_VARIABLES)[2] == 8
+    # a unit whose finalize reported errors has no IR arrays (frontend.rs:145)
+    bad = fe.get_definitions(b"var g nosuchtype\nf() int32\n\treturn 1\n")
+    assert bad.compile_source() == 7
+    assert bad.array_device(V.A_INSTRS)[1] == 0 and len(bad.array(V.A_FUNCTIONS)) == 0
+    assert len(bad.array(V.A_NODES)) == bad.counts()["nodes"]
+
+
+def test_semantic_error_array_matches_the_dump(fe):
+    src = b"f() int32\n\treturn nosuch\n\ng() int32\n\tbreak\n\treturn 2\n"
+    u = fe.get_definitions(src)
+    assert u.compile_source() == 0
+    errs = u.array(V.A_SEM_ERRORS)
+    want = O.dump(src, O.SEM).splitlines()
+    assert len(errs) == len(want) > 0
+    for e, line in zip(errs, want):
+        _, low, ln = line.split(" ")
+        assert int(e["low"]) == int(low) and int(e["len"]) == int(ln)

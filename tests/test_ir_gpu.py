@@ -37,6 +37,9 @@ def check_ir(fe, src: bytes):
     got = u.dump_ir()
     assert got == want_ir, first_diff(got, want_ir)
     assert u._dump(4) == want_sem
+    # backend hand-off: the flat arrays alone reproduce the same text
+    view_text = u.ir_view().text()
+    assert view_text == want_ir, first_diff(view_text, want_ir)
     return u
 
 
