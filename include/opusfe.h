@@ -140,7 +140,9 @@ int opusfe_unit_headers(opusfe_unit* unit, const uint8_t** d_out, uint64_t* len)
 int opusfe_lower(opusfe_ctx* ctx, opusfe_unit* unit);
 
 /* number of semantic errors (compile.rs:124-152) reported by finalize / IR generation of the unit; IR generated while
-   errors were reported contains Error instructions exactly like the reference's (compile.rs:777-780) */
+   errors were reported contains Error instructions exactly like the reference's (compile.rs:777-780).  The diagnostics
+   themselves, in the reference's report order, are the array OPUSFE_A_SEM_ERRORS (also after OPUSFE_SEMANTIC, where they
+   are the finalize-time errors of compile.rs:1002-1065 and no IR exists) and opusfe_dump(unit, 4). */
 int opusfe_semantic_error_count(const opusfe_unit* unit, uint64_t* n);
 
 /* ---- results ---- */

@@ -603,7 +603,10 @@ int opusfe_array(opusfe_unit* u, int which, const void** d_ptr, uint64_t* count,
         case OPUSFE_A_BB_OFFSETS: es = 4; if (R) { p = R->d_bb_offsets; n = R->n_bbs + 1; } break;
         case OPUSFE_A_INSTRS: es = sizeof(opusfe_instr); if (R) { p = R->d_instrs; n = R->n_instrs; } break;
         case OPUSFE_A_CALL_ARGS: es = 4; if (R) { p = R->d_cargs; n = R->n_cargs; } break;
-        case OPUSFE_A_SEM_ERRORS: es = sizeof(SemErr); if (R) { p = R->d_errs; n = R->n_errs; } break;
+        case OPUSFE_A_SEM_ERRORS:   // also after OPUSFE_SEMANTIC: the finalize-time diagnostics
+            es = sizeof(SemErr);
+            if (u->lowered && u->ir && (u->status == OPUSFE_OK || u->status == OPUSFE_SEMANTIC)) { p = ((const IrResult*)u->ir)->d_errs; n = ((const IrResult*)u->ir)->n_errs; }
+            break;
     }
     if (!p) n = 0;   // a stage that did not run (or stopped early) has no array
     if (d_ptr) *d_ptr = n ? p : nullptr;

@@ -29,14 +29,6 @@ enum { CAP_VARS = 5, CAP_INSTRS = 6, CAP_BBS = 3, CAP_TYPES = 3, CAP_CARGS = 1, 
 __host__ __device__ __forceinline__ uint64_t lower_base(uint32_t mult, uint32_t def_node, uint32_t fidx) { return (uint64_t)mult * def_node + (uint64_t)CAP_CONST * fidx; }
 __host__ __device__ __forceinline__ uint64_t lower_cap(uint32_t mult, uint32_t n_nodes) { return (uint64_t)mult * n_nodes + CAP_CONST; }
 
-struct SemErr { uint32_t kind, low, len; };
-// compile.rs:124-152 order
-enum SErrKind : uint32_t { SE_ParseError, SE_UndefinedVariable, SE_ShadowedName, SE_UndefinedFunction, SE_NoOverloadForFunction, SE_AmbiguousOverload,
-    SE_AmbiguousFunctionReference, SE_UnexpectedType, SE_InvalidType, SE_InvalidOperandType, SE_InvalidOperandTypes, SE_FunctionMightNotReturn,
-    SE_BreakOutsideLoop, SE_ContinueOutsideLoop, SE_InvalidLvalue, SE_ImmutableLvalue, SE_ArrayPointerToNonArray, SE_InvalidCast, SE_UndefinedType,
-    SE_FieldAccessOnNonRecord, SE_FieldDoesNotExist, SE_CallOfNonFunction, SE_ReferenceToBuiltinFunction, SE_AttemptToCallOrIndexConstant,
-    SE_InvalidNumberOfArgs, SE_InvalidConstantExpression };
-
 // per-function result header (sparse counts; dense bases are filled after the scans)
 struct FuncIr { uint32_t def_node, func, n_vars, n_instrs, n_bbs, n_types, n_cargs, n_errs, var_base, instr_base, bb_base, type_base, carg_base, err_base, status, pad; };
 struct IrCnt { uint32_t vars, instrs, bbs, types, cargs, errs; };
@@ -1560,6 +1552,17 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
     R->n_funcs = n_funcs; R->n_globals = n_globals; R->n_gtypes = n_gtypes;
     if (ctx->h_status[WL_FINERR] != 0) {   // frontend.rs:145: semantic errors while finalizing -> no IR
         R->n_sem_errors = ctx->h_status[WL_FINERR];
+        // the diagnostics themselves, in the reference's report order (definitions in file order)
+        uint32_t* fin_cnt = tmp.get<uint32_t>(n_defs);
+        LAUNCH(ctx, "sem_fin_count", k_sem_fin_count, grid_for(n_defs, 256), 256, u->d_nodes, u->d_def_nodes, n_defs, R->d_tid_of_node, undefined_flag, ph_def, n_nodes, types, fin_cnt);
+        prof_begin(ctx, "sem_fin_scan");
+        device_scan<true>(fin_cnt, fin_cnt, n_defs, OpAddU32(), (uint32_t)0, scan_tmp, (uint32_t*)nullptr, st);
+        prof_end(ctx);
+        R->n_errs = R->n_sem_errors;
+        R->d_errs = dev_alloc_t<SemErr>(ctx, R->n_errs);
+        LAUNCH(ctx, "sem_fin_emit", k_sem_fin_emit, grid_for(n_defs, 256), 256, u->d_nodes, u->d_def_nodes, n_defs, R->d_tid_of_node, undefined_flag, ph_def, n_nodes, types, fin_cnt, R->d_errs);
+        HIP_TRY(hipStreamSynchronize(st));
+        prof_collect(ctx);
         u->status = OPUSFE_SEMANTIC;
         ctx->msg = "finalize_definition reported semantic errors; IR generation skipped (frontend.rs:145)";
         return;

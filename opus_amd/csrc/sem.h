@@ -514,6 +514,14 @@ __global__ void k_sem_resolve_types(const uint8_t* __restrict__ src, const opusf
     types[id] = r;
 }
 
+struct SemErr { uint32_t kind, low, len; };
+// compile.rs:124-152 order
+enum SErrKind : uint32_t { SE_ParseError, SE_UndefinedVariable, SE_ShadowedName, SE_UndefinedFunction, SE_NoOverloadForFunction, SE_AmbiguousOverload,
+    SE_AmbiguousFunctionReference, SE_UnexpectedType, SE_InvalidType, SE_InvalidOperandType, SE_InvalidOperandTypes, SE_FunctionMightNotReturn,
+    SE_BreakOutsideLoop, SE_ContinueOutsideLoop, SE_InvalidLvalue, SE_ImmutableLvalue, SE_ArrayPointerToNonArray, SE_InvalidCast, SE_UndefinedType,
+    SE_FieldAccessOnNonRecord, SE_FieldDoesNotExist, SE_CallOfNonFunction, SE_ReferenceToBuiltinFunction, SE_AttemptToCallOrIndexConstant,
+    SE_InvalidNumberOfArgs, SE_InvalidConstantExpression };
+
 // Contents of a type id as finalize_definition of the definition at node `at_def` sees them (compile.rs:1055-1062,
 // Q14): a `type` placeholder holds Type::Error until its own definition has been finalized, and an alias of an
 // alias captures whatever the target held at that moment.  Decided from the AST alone (placeholders are written
@@ -532,6 +540,50 @@ __device__ __forceinline__ TypeRec sem_contents_at(const opusfe_node* nodes, con
     return content;
 }
 
+// The semantic errors finalize_definition (compile.rs:1002-1065) reports for definition d, in report order: UndefinedType
+// for every unknown name among the type nodes it resolves (resolve_type, compile.rs:919-966, left to right = node order:
+// arguments then return type; fields; proc arguments then result), then at most one error for a global's value
+// (make_value compile.rs:983-1000 -> InvalidConstantExpression, else type_is_valid compile.rs:154-170 -> InvalidType).
+// out == nullptr: count only.  Decided from the AST and the immutable structured type records, so the result is the same
+// before and after k_sem_finalize wrote the placeholders.
+__device__ __forceinline__ uint32_t sem_finalize_errors(const opusfe_node* __restrict__ nodes, const uint32_t* __restrict__ def_nodes, uint32_t n_defs, uint32_t d,
+                                                        const uint32_t* __restrict__ tid_of_node, const uint8_t* __restrict__ undefined_flag,
+                                                        const uint32_t* __restrict__ ph_def, uint32_t n_nodes, const TypeRec* __restrict__ types, SemErr* out) {
+    const uint32_t dn = def_nodes[d];
+    const uint32_t dn_end = d + 1 < n_defs ? def_nodes[d + 1] : n_nodes;
+    const opusfe_node n = nodes[dn];
+    uint32_t nerr = 0;
+    auto undefined_in = [&](uint32_t lo, uint32_t hi) {
+        for (uint32_t y = lo; y < hi; y++)
+            if (undefined_flag[y]) { if (out) out[nerr] = SemErr{SE_UndefinedType, nodes[y].low, nodes[y].high - nodes[y].low}; nerr++; }
+    };
+    switch (n.kind) {
+        case D_Function: case D_Extern: {
+            uint32_t c = n.first_child;
+            while (nodes[c].kind == X_NamedType) c = nodes[c].next;
+            // the signature's nodes are the contiguous range up to the body
+            undefined_in(dn + 1, nodes[c].next != OPUSFE_NONE ? nodes[c].next : dn_end);
+            break;
+        }
+        case D_Variable: case D_Constant: {
+            const uint32_t ty = n.first_child, val = nodes[ty].next;
+            undefined_in(ty, val != OPUSFE_NONE ? val : dn_end);
+            if (val != OPUSFE_NONE) {
+                const opusfe_node v = nodes[val];
+                const bool is_int = v.kind == E_Integer || (v.kind == E_Negate && nodes[v.first_child].kind == E_Integer);
+                uint32_t kind = OPUSFE_NONE;
+                if (!is_int) kind = SE_InvalidConstantExpression;
+                else if (!kind_is_integral(sem_contents_at(nodes, tid_of_node, types, ph_def, tid_of_node[ty], dn, n_defs).kind)) kind = SE_InvalidType;
+                if (kind != OPUSFE_NONE) { if (out) out[nerr] = SemErr{kind, v.low, v.high - v.low}; nerr++; }
+            }
+            break;
+        }
+        case D_Type: undefined_in(n.first_child, dn_end); break;
+        default: break;
+    }
+    return nerr;
+}
+
 // finalize_definition (compile.rs:1002-1065), one lane per definition.  err[0] counts semantic errors
 // (has_errors): with any, frontend.rs:145 skips IR generation.
 __global__ void k_sem_finalize(const opusfe_node* __restrict__ nodes, const uint32_t* __restrict__ def_nodes, uint32_t n_defs,
@@ -541,9 +593,8 @@ __global__ void k_sem_finalize(const opusfe_node* __restrict__ nodes, const uint
     uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= n_defs) return;
     const uint32_t dn = def_nodes[d];
-    const uint32_t dn_end = d + 1 < n_defs ? def_nodes[d + 1] : n_nodes;
     const opusfe_node n = nodes[dn];
-    uint32_t nerr = 0;
+    const uint32_t nerr = sem_finalize_errors(nodes, def_nodes, n_defs, d, tid_of_node, undefined_flag, ph_def, n_nodes, types, nullptr);
     switch (n.kind) {
         case D_Function: case D_Extern: {
             FuncRec f{}; f.def_node = dn; f.name_tok = n.payload; f.flags = n.kind == D_Extern ? 1u : 0u;
@@ -551,31 +602,15 @@ __global__ void k_sem_finalize(const opusfe_node* __restrict__ nodes, const uint
             f.first_arg = OPUSFE_NONE;
             while (nodes[c].kind == X_NamedType) { if (f.nargs == 0) f.first_arg = c; f.nargs++; c = nodes[c].next; }
             f.ret = tid_of_node[c];
-            // UndefinedType errors of the signature: its nodes are the contiguous range up to the body
-            uint32_t sig_end = nodes[c].next != OPUSFE_NONE ? nodes[c].next : dn_end;
-            for (uint32_t y = dn + 1; y < sig_end; y++) nerr += undefined_flag[y];
             funcs[def_excl[d].funcs] = f;
             break;
         }
         case D_Variable: case D_Constant: {
-            uint32_t ty = n.first_child;
-            uint32_t tid = tid_of_node[ty];
-            uint32_t val = nodes[ty].next;
-            uint32_t ty_end = val != OPUSFE_NONE ? val : dn_end;
-            for (uint32_t y = ty; y < ty_end; y++) nerr += undefined_flag[y];
-            if (val != OPUSFE_NONE) {
-                // make_value (compile.rs:983-1000): Integer or Negate(Integer) only; type_is_valid (compile.rs:154-170)
-                const opusfe_node v = nodes[val];
-                bool is_int = v.kind == E_Integer || (v.kind == E_Negate && nodes[v.first_child].kind == E_Integer);
-                if (!is_int) nerr++;
-                else if (!kind_is_integral(sem_contents_at(nodes, tid_of_node, types, ph_def, tid, dn, n_defs).kind)) nerr++;
-            }
-            GlobalRec g{dn, tid, n.kind == D_Constant ? 1u : 0u, n.payload};
+            GlobalRec g{dn, tid_of_node[n.first_child], n.kind == D_Constant ? 1u : 0u, n.payload};
             globals[def_excl[d].globals] = g;
             break;
         }
         case D_Type: {
-            for (uint32_t y = n.first_child; y < dn_end; y++) nerr += undefined_flag[y];
             TypeRec content = sem_contents_at(nodes, tid_of_node, types, ph_def, tid_of_node[n.first_child], dn, n_defs);
             content.alias = n.payload;
             types[tid_of_node[dn]] = content;
@@ -584,6 +619,20 @@ __global__ void k_sem_finalize(const opusfe_node* __restrict__ nodes, const uint
         default: break;
     }
     if (nerr) atomicAdd(err, nerr);
+}
+
+// The ordered diagnostics of a unit whose finalize reported errors (the rare path: two more launches and a scan).
+__global__ void k_sem_fin_count(const opusfe_node* __restrict__ nodes, const uint32_t* __restrict__ def_nodes, uint32_t n_defs, const uint32_t* __restrict__ tid_of_node,
+                                const uint8_t* __restrict__ undefined_flag, const uint32_t* __restrict__ ph_def, uint32_t n_nodes, const TypeRec* __restrict__ types,
+                                uint32_t* __restrict__ cnt) {
+    uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d < n_defs) cnt[d] = sem_finalize_errors(nodes, def_nodes, n_defs, d, tid_of_node, undefined_flag, ph_def, n_nodes, types, nullptr);
+}
+__global__ void k_sem_fin_emit(const opusfe_node* __restrict__ nodes, const uint32_t* __restrict__ def_nodes, uint32_t n_defs, const uint32_t* __restrict__ tid_of_node,
+                               const uint8_t* __restrict__ undefined_flag, const uint32_t* __restrict__ ph_def, uint32_t n_nodes, const TypeRec* __restrict__ types,
+                               const uint32_t* __restrict__ excl, SemErr* __restrict__ out) {
+    uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d < n_defs) sem_finalize_errors(nodes, def_nodes, n_defs, d, tid_of_node, undefined_flag, ph_def, n_nodes, types, out + excl[d]);
 }
 
 }  // namespace opusfe

@@ -124,3 +124,20 @@ def big_function(n_locals=150, n_ifs=140, chain=90, depth=70):
     L.append("\t\ts = s + 1")
     L.append("\treturn s + d")
     return "\n".join(L) + "\n"
+
+
+# finalize_definition errors (compile.rs:1002-1065): reported in definition order, no IR is generated (frontend.rs:145)
+FINALIZE_ERROR_CASES = [
+    "f(a nosuch, b int32, c other) missing\n\treturn 1\n",
+    "var g nosuch\nf() int32\n\treturn 1\n",
+    "var g int32 = 1 + 2\n",
+    "var g float64 = 1\nconst c bool = 2\nconst d int8 = -3\n",
+    "var g nosuch = 1.5\n",
+    "var g nosuch = 3\n",
+    "type T = record { a nosuch b @other c int32 }\nf(t T) int32 return 1\n",
+    "extern e(p (nosuch, int32) other, q {4} third) fourth\n",
+    "type A = B\ntype B = int32\nvar x A = 1\nvar y B = 2\n",
+    "var a int32 = x\nf(p nosuch) int32\n\treturn q\nvar b other = -1\ntype U = @@missing\nconst k int64 = \"s\"\n",
+    "f() int32\n\tvar x nosuch\n\treturn 1\nvar g nosuch2\n",
+    "type P = record { x int32 }\nvar p P = 1\nvar q @int32 = 0\nvar r string = 1\n",
+]

@@ -199,7 +199,18 @@ void emu_lower(EmuUnit& E) {
     emu_launch(k_sem_finalize, grid_for(n_defs, 256), 256, nodes, def_nodes, n_defs, def_excl.data(), R->tid_of_node.data(), undefined_flag.data(), ph_def.data(), n_nodes,
                types, R->funcrecs.data(), R->globals.data(), &finerr);
     R->n_funcs = n_funcs; R->n_globals = n_globals; R->n_gtypes = n_gtypes;
-    if (finerr) { R->n_sem_errors = finerr; u.status = OPUSFE_SEMANTIC; free(slots); free(entries); free(types); return; }
+    if (finerr) {
+        std::vector<uint32_t> fin_cnt(n_defs);
+        emu_launch(k_sem_fin_count, grid_for(n_defs, 256), 256, nodes, def_nodes, n_defs, (const uint32_t*)R->tid_of_node.data(), (const uint8_t*)undefined_flag.data(),
+                   (const uint32_t*)ph_def.data(), n_nodes, (const TypeRec*)types, fin_cnt.data());
+        { uint32_t run = 0; for (uint32_t d = 0; d < n_defs; d++) { uint32_t c = fin_cnt[d]; fin_cnt[d] = run; run += c; } }
+        SemErr* errs = exact<SemErr>(finerr);   // exact-size block: an emit beyond the counted total is an ASan error
+        emu_launch(k_sem_fin_emit, grid_for(n_defs, 256), 256, nodes, def_nodes, n_defs, (const uint32_t*)R->tid_of_node.data(), (const uint8_t*)undefined_flag.data(),
+                   (const uint32_t*)ph_def.data(), n_nodes, (const TypeRec*)types, (const uint32_t*)fin_cnt.data(), errs);
+        R->errs.assign(errs, errs + finerr); R->n_errs = finerr;
+        free(errs);
+        R->n_sem_errors = finerr; u.status = OPUSFE_SEMANTIC; free(slots); free(entries); free(types); return;
+    }
     if (n_funcs == 0) { free(slots); free(entries); free(types); return; }
     LowerBuffers B{};
     B.vars = exact<opusfe_variable>(lower_base(CAP_VARS, n_nodes, n_funcs) + CAP_CONST);

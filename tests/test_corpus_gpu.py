@@ -73,7 +73,7 @@ def test_differential_fuzz_small_sources(fe):
         else:
             want_ir, want_sem = O.dump(s, O.IR), O.dump(s, O.SEM)
             if want_ir == "" and want_sem != "":
-                assert u.status == 7
+                assert u.status == 7 and u._dump(4) == want_sem
             else:
                 assert u.status == 0 and u.dump_ir() == want_ir and u._dump(4) == want_sem
         u.close()

@@ -6,7 +6,7 @@ import pytest
 
 import emu_lib as E
 import oracle_lib as O
-from cases import IR_CASES, LEX_CASES, PARSE_CASES, big_function
+from cases import FINALIZE_ERROR_CASES, IR_CASES, LEX_CASES, PARSE_CASES, big_function
 
 
 def compare_parse(cases):
@@ -72,6 +72,7 @@ def compare_ir(cases):
         want_ir, want_sem = O.dump(c, O.IR), O.dump(c, O.SEM)
         if want_ir == "" and want_sem != "":
             assert st == 7, c[:80]
+            assert sem == want_sem, c[:80]      # the finalize-time diagnostics, in report order
             continue
         assert st == 0, (st, c[:80])
         assert ir == want_ir, c[:80]
@@ -79,7 +80,7 @@ def compare_ir(cases):
 
 
 def test_emu_ir_hand_cases():
-    compare_ir([s.encode() for s in IR_CASES] + [s.encode() for s in PARSE_CASES])
+    compare_ir([s.encode() for s in IR_CASES] + [s.encode() for s in PARSE_CASES] + [s.encode() for s in FINALIZE_ERROR_CASES])
 
 
 def test_emu_ir_generated_and_deep():

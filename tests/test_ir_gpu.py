@@ -6,7 +6,7 @@ import os
 import pytest
 
 import oracle_lib as O
-from cases import IR_CASES, PARSE_CASES, big_function as _big_function
+from cases import FINALIZE_ERROR_CASES, IR_CASES, PARSE_CASES, big_function as _big_function
 
 pytestmark = pytest.mark.gpu
 
@@ -32,6 +32,7 @@ def check_ir(fe, src: bytes):
     rc = u.compile_source()
     if want_ir == "" and want_sem != "":
         assert rc == 7, "finalize errors: the reference generates no IR (frontend.rs:145)"
+        assert u._dump(4) == want_sem, "finalize-time diagnostics in report order"
         return u
     assert rc == 0, (rc, fe.message())
     got = u.dump_ir()
@@ -56,6 +57,22 @@ def test_kat_ir_matches_hand_derived_fixtures(fe):
 @pytest.mark.parametrize("src", IR_CASES, ids=[f"ir{i}" for i in range(len(IR_CASES))])
 def test_ir_hand_cases(fe, src):
     check_ir(fe, src.encode())
+
+
+def test_finalize_time_diagnostics_are_ordered(fe):
+    """with finalize errors the reference prints them in definition order and generates no IR"""
+    from opus_amd import ir_view as V
+    for s in FINALIZE_ERROR_CASES:
+        src = s.encode()
+        want = O.dump(src, O.SEM)
+        assert want != "" and O.dump(src, O.IR) == "", s
+        u = check_ir(fe, src)
+        errs = u.array(V.A_SEM_ERRORS)           # the same list as an array (the boundary's "ordered array")
+        assert [f"{int(e['low'])} {int(e['len'])}" for e in errs] == [ln.split(" ", 1)[1] for ln in want.splitlines()]
+        n = __import__("ctypes").c_uint64()
+        import opus_amd.frontend as F
+        F.lib().opusfe_semantic_error_count(u.handle, n)
+        assert n.value == len(errs)
 
 
 def test_ir_of_parser_cases(fe):

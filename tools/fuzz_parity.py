@@ -40,7 +40,7 @@ def main():
         else:
             want_ir, want_sem = O.dump(s, O.IR), O.dump(s, O.SEM)
             if want_ir == "" and want_sem != "":
-                ok = u.status == 7
+                ok = u.status == 7 and u._dump(4) == want_sem
             else:
                 ok = u.status == 0 and u.dump_ir() == want_ir and u._dump(4) == want_sem
         if not ok:
