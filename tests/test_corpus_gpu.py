@@ -77,3 +77,28 @@ def test_differential_fuzz_small_sources(fe):
             else:
                 assert u.status == 0 and u.dump_ir() == want_ir and u._dump(4) == want_sem
         u.close()
+
+
+def test_semantic_mutants(fe):
+    """ill-typed programs (tests/mutate.py): the 25 semantic error kinds, Error instructions and the panic paths of the
+    reference's IR generation — IR text and ordered diagnostics against the oracle"""
+    import mutate as M
+    srcs = M.mutants(400, seed0=50_000)
+    units = fe.compile_corpus(srcs, lower=True)
+    seen = {}
+    for s, u in zip(srcs, units):
+        w = M.expectation(s)
+        seen[w[0]] = seen.get(w[0], 0) + 1
+        if w[0] == "unsupported":
+            assert u.status == 2, s
+        elif w[0] == "syntax":
+            assert u.status == 1 and u.dump_error() == w[1], s
+        elif w[0] == "semantic":
+            assert u.status == 7 and u._dump(4) == w[1], s
+        else:
+            assert u.status == 0, (u.status, s)
+            assert u.dump_ir() == w[1], s
+            assert u._dump(4) == w[2], s
+            assert u.ir_view().text() == w[1]
+        u.close()
+    assert seen.get("ir", 0) > 100 and seen.get("syntax", 0) > 50 and seen.get("semantic", 0) > 0

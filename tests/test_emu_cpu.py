@@ -99,3 +99,25 @@ def test_emu_float_literals_outside_the_fast_path():
     src = "".join(f"const c{i} float64 = {t}\n" for i, t in enumerate(lits)).encode()
     (st, got), = E.dump_many([src], 0)
     assert st == 0 and got == O.dump(src, O.TOKENS)
+
+
+def test_emu_semantic_mutants():
+    """ill-typed programs (tests/mutate.py): the error paths of IR generation, emulated under ASan before any GPU sees them"""
+    import mutate as M
+    cases = M.mutants(260)
+    want = [M.expectation(c) for c in cases]
+    errs, irs, sems = E.dump_many(cases, 3), E.dump_many(cases, 2), E.dump_many(cases, 4)
+    seen = set()
+    for c, w, (_, err), (st, ir), (_, sem) in zip(cases, want, errs, irs, sems):
+        seen.add(w[0])
+        if w[0] == "unsupported":
+            assert st == 2, c
+        elif w[0] == "syntax":
+            assert st == 1 and err == w[1], c
+        elif w[0] == "semantic":
+            assert st == 7 and sem == w[1], c
+        else:
+            assert st == 0, (st, c)
+            assert ir == w[1], c
+            assert sem == w[2], c
+    assert {"syntax", "semantic", "ir"} <= seen

@@ -16,6 +16,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", type=int, default=300)
     ap.add_argument("--first", type=int, default=1000)
+    ap.add_argument("--mutants", type=int, default=0, help="also this many ill-typed mutants (tests/mutate.py)")
     args = ap.parse_args()
     import opus_amd
     import oracle_lib as O
@@ -28,12 +29,15 @@ def main():
         if k % 11 == 7:
             s = s[:rnd.randint(1, len(s))]
         srcs.append(s)
+    if args.mutants:
+        import mutate as M
+        srcs += M.mutants(args.mutants, seed0=args.first)
     ctx = opus_amd.Context(0)
     units = ctx.compile_corpus(srcs, lower=True)
     bad = 0
     for k, (s, u) in enumerate(zip(srcs, units)):
         want_err = O.dump(s, O.ERROR)
-        if want_err == "Unsupported\n":
+        if want_err == "Unsupported\n" or (want_err == "Ok\n" and O.time_run(s)[1].status == 2):
             ok = u.status == 2
         elif want_err != "Ok\n":
             ok = u.status == 1 and u.dump_error() == want_err
