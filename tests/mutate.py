@@ -98,14 +98,51 @@ def mutants(n, seed0=0, lo=600, hi=5000):
     return out
 
 
+BYTES = b"\t\t\t\n\n\n  ()[]{}:=<>+-*/%@~.,?\"\"\\\\;;#$!&|^`'0123456789abcdefxyz_ABZ\r\x00\x7f"
+
+
+def byte_mutants(n, seed0=0, lo=700, hi=3000):
+    """n sources with a few random byte edits (replace / insert / delete / swap of lines' indentation): lexer contexts,
+    brackets, dents, continuation lines, escapes"""
+    out = []
+    rnd = random.Random(777 + seed0)
+    for k in range(n):
+        s = bytearray(O.generate(60_000 + seed0 + k, rnd.randint(lo, hi)))
+        for _ in range(rnd.randint(1, 5)):
+            if not s:
+                break
+            i = rnd.randrange(len(s))
+            op = rnd.randrange(4)
+            if op == 0:
+                s[i] = rnd.choice(BYTES)
+            elif op == 1:
+                s.insert(i, rnd.choice(BYTES))
+            elif op == 2:
+                del s[i]
+            else:
+                j = s.find(b"\n", i)
+                if j >= 0:
+                    s[j + 1:j + 1] = b"\t" * rnd.randint(1, 3) if rnd.random() < 0.7 else b"  "
+        out.append(bytes(s))
+    return out
+
+
+def swallowed_lexical_error(src: bytes) -> bool:
+    """the reference lexed an Err token and went on (Q6/Q7: after a bad escape it resumes inside the string body as code):
+    the product's documented OPUSFE_UNSUPPORTED, the only accepted difference"""
+    lines = O.dump(src, O.TOKENS).splitlines()
+    return any(" Err(" in ln for ln in lines[:-1])
+
+
 def expectation(src: bytes):
-    """what the reference does with `src`, per the oracle: ("syntax", error line) | ("unsupported",) |
+    """what the reference does with `src`, per the oracle: ("syntax", error line, unsupported_allowed) | ("unsupported",) |
     ("semantic", diagnostics) — finalize errors, no IR | ("ir", IR text, diagnostics)"""
     err = O.dump(src, O.ERROR)
     if err == "Unsupported\n":
         return ("unsupported",)
     if err != "Ok\n":
-        return ("syntax", err)
+        # a swallowed bad escape may be answered by OPUSFE_UNSUPPORTED; any other answer must be the reference's error
+        return ("syntax", err, swallowed_lexical_error(src))
     if O.time_run(src)[1].status == 2:
         return ("unsupported",)
     ir, sem = O.dump(src, O.IR), O.dump(src, O.SEM)

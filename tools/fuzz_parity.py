@@ -31,22 +31,22 @@ def main():
         srcs.append(s)
     if args.mutants:
         import mutate as M
-        srcs += M.mutants(args.mutants, seed0=args.first)
+        srcs += M.mutants(args.mutants, seed0=args.first) + M.byte_mutants(args.mutants, seed0=args.first)
     ctx = opus_amd.Context(0)
     units = ctx.compile_corpus(srcs, lower=True)
     bad = 0
     for k, (s, u) in enumerate(zip(srcs, units)):
+        import mutate as M
+        w = M.expectation(s)
         want_err = O.dump(s, O.ERROR)
-        if want_err == "Unsupported\n" or (want_err == "Ok\n" and O.time_run(s)[1].status == 2):
+        if w[0] == "unsupported":
             ok = u.status == 2
-        elif want_err != "Ok\n":
-            ok = u.status == 1 and u.dump_error() == want_err
+        elif w[0] == "syntax":
+            ok = (u.status == 1 and u.dump_error() == w[1]) or (w[2] and u.status == 2)
+        elif w[0] == "semantic":
+            ok = u.status == 7 and u._dump(4) == w[1]
         else:
-            want_ir, want_sem = O.dump(s, O.IR), O.dump(s, O.SEM)
-            if want_ir == "" and want_sem != "":
-                ok = u.status == 7 and u._dump(4) == want_sem
-            else:
-                ok = u.status == 0 and u.dump_ir() == want_ir and u._dump(4) == want_sem
+            ok = u.status == 0 and u.dump_ir() == w[1] and u._dump(4) == w[2]
         if not ok:
             bad += 1
             path = os.path.join(ROOT, "gpurun_out", f"fuzz_bad_{args.first + k}.opus")
