@@ -202,7 +202,7 @@ def main():
             roofline = {"bound": "hbm", "kernel": name, "achieved": round(a, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(a / HBM_PEAK_GBS, 5), "traffic": traffic, "avg_ms": round(avg_ms, 4),
                         "launches_per_step": per_step, "algorithmic_bytes_per_launch": int(alg[stage_of(name)] / max(1.0, per_step))}
-        cpu = None
+        cpu = parity = None
         if world == 1 and not args.no_cpu:
             sample = src[:int(min(args.cpu_sample_bytes, nbytes))]
             # cut the sample at a top-level definition boundary (a line that starts in column 0 after a newline)
@@ -211,6 +211,19 @@ def main():
                 cut -= 1
             sample = sample[:cut] if cut > 0 else sample
             tcpu, c2 = O.time_run(sample, lower=(args.stage == "ir"))
+            # the oracle as checker: the GPU path on the same sample must produce the same element counts
+            us = ctx.get_definitions(sample)
+            if us.status == opus_amd.OK and args.stage == "ir":
+                us.compile_source()
+            cs = us.counts()
+            # (node counts are not comparable: the flat AST has list / pair carrier nodes the reference's boxed tree does not)
+            pairs = [("tokens", c2.tokens), ("definitions", c2.definitions)] if args.stage != "lex" else []
+            if args.stage == "ir":
+                pairs += [("instrs", c2.instrs), ("vars", c2.vars)]
+            parity = {"sample_bytes": len(sample), "oracle_status": c2.status, "gpu_status": us.status,
+                      "counts_match": all(cs[k] == v for k, v in pairs) and (us.status == 0) == (c2.status == 0),
+                      "compared": [k for k, _ in pairs]}
+            us.close()
             cpu = {"value": round(len(sample) / 1e6 / tcpu, 3), "unit": "MB/s", "cores": 1, "kind": "port",
                    "sample": f"first {len(sample)} bytes of the same source (whole definitions), oracle {'lex+parse+IR' if args.stage == 'ir' else 'lex+parse'}, single thread like the reference; status {c2.status}"}
         stage_name = {"lex": "lex only (PARTIAL path)", "parse": "lex+parse (PARTIAL path)", "ir": "lex+parse+IR"}[args.stage]
@@ -224,7 +237,7 @@ def main():
                                        "byte-range shards; all-gather of ctx/tail/depth/cut carries, prefix halo, definition headers")},
                "hbm_gbs_whole_path": round(world * total_alg / (dt / args.steps) / 1e9, 2),
                "hbm_frac_whole_path": round(total_alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 5),
-               "roofline": roofline, "cpu_baseline": cpu,
+               "roofline": roofline, "cpu_baseline": cpu, "parity_check": parity if cpu is not None else None,
                "kernels": [{"name": n, "ms_per_step": round(ms / args.steps, 4), "launches_per_step": l / args.steps} for n, ms, l in kstats[:24]],
                "gen_seconds": round(gen_s, 1)}
     ctx.close()
