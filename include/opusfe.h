@@ -55,7 +55,9 @@ typedef struct opusfe_token {
                            Identifier: FNV-1a hash of the name; Error: val64 index of {span, payload} */
 } opusfe_token;
 #define OPUSFE_TF_INLINE 1u   /* Integer value stored inline */
-#define OPUSFE_TF_RESYNC 2u   /* Error token after which the reference resumes inside a string body (Q7 note) */
+#define OPUSFE_TF_RESYNC 2u   /* Error token behind which the reference resumes lexing inside what the context automaton sees as a
+                                 string body; opusfe_parse re-lexes with that position when the parser drops the token
+                                 (DESIGN.md §5 resync passes); opusfe_lex alone leaves the flag for the caller */
 #define OPUSFE_TOK_ERROR 60
 
 typedef struct opusfe_node {

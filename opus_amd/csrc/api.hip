@@ -62,6 +62,12 @@ void run_lexer(opusfe_ctx* ctx, opusfe_unit* u, int force_dents) {
     const uint64_t ntiles = (nchunks + LEX_THREADS - 1) / LEX_THREADS;
     uint32_t T = 0, nval = 0, nstr = 0;
     opusfe_token* raw = nullptr;
+    Resync rs{nullptr, 0};
+    if (!u->resync.empty()) {   // a later pass of parse_with_resync
+        uint32_t* d = tmp.get<uint32_t>(u->resync.size());
+        HIP_TRY(hipMemcpyAsync(d, u->resync.data(), u->resync.size() * 4, hipMemcpyHostToDevice, st));
+        rs = Resync{d, (uint32_t)u->resync.size()};
+    }
     if (ntiles > 0) {
         uint32_t* chunk_fn = tmp.get<uint32_t>(nchunks);
         uint32_t* tile_fn = tmp.get<uint32_t>(ntiles);
@@ -71,9 +77,9 @@ void run_lexer(opusfe_ctx* ctx, opusfe_unit* u, int force_dents) {
         uint32_t* chunk_str = tmp.get<uint32_t>(nchunks);
         Cnt3* tile_cnt = tmp.get<Cnt3>(ntiles);
         Cnt3* scan_tmp = tmp.get<Cnt3>((ntiles + SCAN_TILE - 1) / SCAN_TILE + 1);
-        LAUNCH(ctx, "lex_ctx_chunk", k_ctx_chunk, ntiles, LEX_THREADS, src, n, chunk_fn, tile_fn);
+        LAUNCH(ctx, "lex_ctx_chunk", k_ctx_chunk, ntiles, LEX_THREADS, src, n, chunk_fn, tile_fn, rs);
         LAUNCH(ctx, "lex_ctx_tiles", k_ctx_tiles, 1, SCAN_THREADS, tile_fn, tile_state, (uint32_t)ntiles, (uint32_t)CS_N, (uint32_t*)nullptr);
-        LAUNCH(ctx, "lex_count", k_lex_count, ntiles, LEX_THREADS, src, n, chunk_fn, tile_state, chunk_state, chunk_cnt, chunk_str, tile_cnt, status);
+        LAUNCH(ctx, "lex_count", k_lex_count, ntiles, LEX_THREADS, src, n, chunk_fn, tile_state, chunk_state, chunk_cnt, chunk_str, tile_cnt, status, rs);
         prof_begin(ctx, "scan_cnt3");
         device_scan<true>(tile_cnt, tile_cnt, ntiles, OpAddCnt3(), Cnt3{0, 0, 0, 0}, scan_tmp, (Cnt3*)(ctx->d_status + W_LEXTOT), st);
         prof_end(ctx);
@@ -83,7 +89,7 @@ void run_lexer(opusfe_ctx* ctx, opusfe_unit* u, int force_dents) {
         u->d_val64 = dev_alloc_t<uint64_t>(ctx, nval);
         u->d_strpool = dev_alloc_t<uint8_t>(ctx, nstr);
         u->n_val64 = nval; u->n_strpool = nstr;
-        LAUNCH(ctx, "lex_emit", k_lex_emit, ntiles, LEX_THREADS, src, n, chunk_state, chunk_cnt, chunk_str, tile_cnt, raw, u->d_val64, u->d_strpool, status);
+        LAUNCH(ctx, "lex_emit", k_lex_emit, ntiles, LEX_THREADS, src, n, chunk_state, chunk_cnt, chunk_str, tile_cnt, raw, u->d_val64, u->d_strpool, status, rs);
     }
     // token-level passes over T raw tokens and T + 1 gaps
     const uint64_t G = (uint64_t)T + 1;
@@ -205,7 +211,7 @@ int opusfe_shard_ctx(opusfe_ctx* ctx, const uint8_t* d_src, uint64_t len, uint32
         uint32_t* chunk_fn = tmp.get<uint32_t>(nchunks);
         uint32_t* tile_fn = tmp.get<uint32_t>(ntiles);
         uint8_t* tile_state = tmp.get<uint8_t>(ntiles);
-        LAUNCH(ctx, "lex_ctx_chunk", k_ctx_chunk, ntiles, LEX_THREADS, d_src, n, chunk_fn, tile_fn);
+        LAUNCH(ctx, "lex_ctx_chunk", k_ctx_chunk, ntiles, LEX_THREADS, d_src, n, chunk_fn, tile_fn, Resync{nullptr, 0});
         LAUNCH(ctx, "lex_ctx_tiles", k_ctx_tiles, 1, SCAN_THREADS, tile_fn, tile_state, (uint32_t)ntiles, (uint32_t)CS_N, ctx->d_status + 60);
         HIP_TRY(hipMemcpyAsync(ctx->h_status + 60, ctx->d_status + 60, 4, hipMemcpyDeviceToHost, ctx->stream));
         sync_stream(ctx);
@@ -241,9 +247,9 @@ int opusfe_shard_lex(opusfe_ctx* ctx, const uint8_t* d_src, uint64_t len, uint32
         Cnt3* tile_cnt = tmp.get<Cnt3>(ntiles);
         Cnt3* scan_tmp = tmp.get<Cnt3>((ntiles + SCAN_TILE - 1) / SCAN_TILE + 1);
         uint32_t* status = ctx->d_status + W_STATUS;
-        LAUNCH(ctx, "lex_ctx_chunk", k_ctx_chunk, ntiles, LEX_THREADS, d_src, n, chunk_fn, tile_fn);
+        LAUNCH(ctx, "lex_ctx_chunk", k_ctx_chunk, ntiles, LEX_THREADS, d_src, n, chunk_fn, tile_fn, Resync{nullptr, 0});
         LAUNCH(ctx, "lex_ctx_tiles", k_ctx_tiles, 1, SCAN_THREADS, tile_fn, tile_state, (uint32_t)ntiles, start_state, (uint32_t*)nullptr);
-        LAUNCH(ctx, "lex_count", k_lex_count, ntiles, LEX_THREADS, d_src, n, chunk_fn, tile_state, chunk_state, chunk_cnt, chunk_str, tile_cnt, status);
+        LAUNCH(ctx, "lex_count", k_lex_count, ntiles, LEX_THREADS, d_src, n, chunk_fn, tile_state, chunk_state, chunk_cnt, chunk_str, tile_cnt, status, Resync{nullptr, 0});
         device_scan<true>(tile_cnt, tile_cnt, ntiles, OpAddCnt3(), Cnt3{0, 0, 0, 0}, scan_tmp, (Cnt3*)(ctx->d_status + W_LEXTOT), st);
         fetch_status(ctx);
         const uint32_t T = ctx->h_status[W_LEXTOT], nval = ctx->h_status[W_LEXTOT + 1], nstr = ctx->h_status[W_LEXTOT + 2];
@@ -251,7 +257,7 @@ int opusfe_shard_lex(opusfe_ctx* ctx, const uint8_t* d_src, uint64_t len, uint32
         s->raw = dev_alloc_t<opusfe_token>(ctx, T);
         s->val64 = dev_alloc_t<uint64_t>(ctx, nval);
         s->strpool = dev_alloc_t<uint8_t>(ctx, nstr);
-        LAUNCH(ctx, "lex_emit", k_lex_emit, ntiles, LEX_THREADS, d_src, n, chunk_state, chunk_cnt, chunk_str, tile_cnt, s->raw, s->val64, s->strpool, status);
+        LAUNCH(ctx, "lex_emit", k_lex_emit, ntiles, LEX_THREADS, d_src, n, chunk_state, chunk_cnt, chunk_str, tile_cnt, s->raw, s->val64, s->strpool, status, Resync{nullptr, 0});
         const uint64_t G = (uint64_t)T + 1;
         s->depth = dev_alloc_t<int32_t>(ctx, G); s->gapval = dev_alloc_t<uint32_t>(ctx, G); s->prev = dev_alloc_t<uint32_t>(ctx, G);
         s->scan_tmp = dev_alloc_t<uint32_t>(ctx, (G + SCAN_TILE - 1) / SCAN_TILE + 2);
@@ -383,12 +389,55 @@ static int with_host_source(opusfe_ctx* ctx, const uint8_t* src, uint64_t len, o
 }
 
 static int body_lex(opusfe_ctx* ctx, opusfe_unit* u, int force_dents) { run_lexer(ctx, u, force_dents); return u->status; }
+// index of the Err token flagged OPUSFE_TF_RESYNC that starts at byte `pos` (one match at most)
+__global__ void k_find_resync_token(const opusfe_token* __restrict__ tok, uint32_t n, uint32_t pos, uint32_t* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && tok[i].low == pos && tok[i].kind == T_Error && (tok[i].flags & OPUSFE_TF_RESYNC)) atomicMin(out, i);
+}
+
+// After a pass that ended OPUSFE_UNSUPPORTED because the parser dropped an Err token behind which the reference resumes
+// lexing inside a string body (Q6/Q7): the byte position where the reference resumes, else NONE.
+static uint32_t swallowed_resync_point(opusfe_ctx* ctx, opusfe_unit* u) {
+    if (u->status != OPUSFE_UNSUPPORTED || u->dev_status != DS_UNSUPPORTED_RESYNC || u->n_tokens == 0) return OPUSFE_NONE;
+    const uint32_t pos = ctx->h_status[W_UNSUP_POS];
+    uint32_t* d_idx = ctx->d_status + 63;
+    HIP_TRY(hipMemsetAsync(d_idx, 0xFF, 4, ctx->stream));
+    hipLaunchKernelGGL(k_find_resync_token, dim3(grid_for(u->n_tokens, 256)), dim3(256), 0, ctx->stream, u->d_tokens, (uint32_t)u->n_tokens, pos, d_idx);
+    uint32_t idx = OPUSFE_NONE;
+    HIP_TRY(hipMemcpyAsync(&idx, d_idx, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (idx == OPUSFE_NONE) return OPUSFE_NONE;     // the unsupported byte is something else (non-ASCII, ...)
+    opusfe_token t{}; uint64_t span = 0;
+    HIP_TRY(hipMemcpy(&t, u->d_tokens + idx, sizeof t, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&span, u->d_val64 + t.payload, 8, hipMemcpyDeviceToHost));
+    return (uint32_t)span + (uint32_t)(span >> 32);   // the error span ends where the reference resumes (lex.h lx_error callers)
+}
+
+static void drop_lex_and_parse(opusfe_ctx* ctx, opusfe_unit* u) {
+    dev_free(ctx, u->d_tokens); dev_free(ctx, u->d_val64); dev_free(ctx, u->d_strpool); dev_free(ctx, u->d_seg_start);
+    dev_free(ctx, u->d_nodes); dev_free(ctx, u->d_seg_info); dev_free(ctx, u->d_def_nodes);
+    u->d_tokens = nullptr; u->d_val64 = nullptr; u->d_strpool = nullptr; u->d_seg_start = nullptr; u->d_nodes = nullptr; u->d_seg_info = nullptr; u->d_def_nodes = nullptr;
+    u->n_tokens = u->n_val64 = u->n_strpool = u->n_segs = u->n_nodes = u->n_defs = 0;
+    u->parsed = false; u->has_error = false; u->have_h_lex = u->have_h_ast = false;
+}
+
 static int body_parse(opusfe_ctx* ctx, opusfe_unit* u, int) {
-    run_lexer(ctx, u, 0);
-    if (u->status != OPUSFE_OK && u->status != OPUSFE_UNSUPPORTED) return u->status;
-    // an input the lexer cannot follow the reference on is still parsed: a syntax error that the
-    // reference reports BEFORE reaching that byte wins (run_parser decides with u->unsup_pos)
-    run_parser(ctx, u);
+    // Normally one pass.  A pass that meets a swallowed Err token behind which the reference lexes a string body as code
+    // (malformed input only) yields that resync point; the unit is lexed and parsed again with it (lex.h Resync), up to
+    // MAX_RESYNC such points per unit, after which OPUSFE_UNSUPPORTED stands.
+    enum { MAX_RESYNC = 16 };
+    for (;;) {
+        run_lexer(ctx, u, 0);
+        if (u->status != OPUSFE_OK && u->status != OPUSFE_UNSUPPORTED) return u->status;
+        // an input the lexer cannot follow the reference on is still parsed: a syntax error that the
+        // reference reports BEFORE reaching that byte wins (run_parser decides with u->unsup_pos)
+        run_parser(ctx, u);
+        if (u->resync.size() >= MAX_RESYNC) break;
+        const uint32_t r = swallowed_resync_point(ctx, u);
+        if (r == OPUSFE_NONE || r > u->len || (!u->resync.empty() && r <= u->resync.back())) break;
+        u->resync.push_back(r);
+        drop_lex_and_parse(ctx, u);
+    }
     if (u->status != OPUSFE_OK) ctx->msg = u->status == OPUSFE_UNSUPPORTED ? status_text(u->dev_status) : u->status == OPUSFE_SYNTAX ? "syntax error" : ctx->msg;
     return u->status;
 }

@@ -122,7 +122,9 @@ inline std::string dump_tokens(const opusfe_unit* u, uint64_t limit) {
     uint64_t n = u->h_tokens.size() < limit ? u->h_tokens.size() : limit;
     for (uint64_t i = 0; i < n; i++) {
         const opusfe_token& t = u->h_tokens[i];
-        out += std::to_string(t.low); out += ' '; out += std::to_string((uint64_t)t.low + t.len); out += ' ';
+        uint64_t end = (uint64_t)t.low + t.len;
+        if (t.kind == T_Error && (t.flags & OPUSFE_TF_RESYNC)) { uint64_t sp = u->h_val64[t.payload]; end = (uint32_t)sp + (sp >> 32); }   // the reference resumes right behind the error span; `len` runs to where the context automaton returns to code
+        out += std::to_string(t.low); out += ' '; out += std::to_string(end); out += ' ';
         fmt_token_debug(out, v, t);
         out += '\n';
     }

@@ -55,14 +55,35 @@ __host__ __device__ __forceinline__ bool ctx_has_transient(uint32_t f) {
 }
 struct OpCtx { __host__ __device__ uint32_t operator()(uint32_t a, uint32_t b) const { return ctx_compose(a, b); } };
 
-__global__ __launch_bounds__(LEX_THREADS) void k_ctx_chunk(const uint8_t* __restrict__ src, uint32_t n, uint32_t* __restrict__ chunk_fn, uint32_t* __restrict__ tile_fn) {
+// Resync points (sorted byte positions, normally none): after some lexical errors the reference resumes lexing in the
+// middle of what the context automaton sees as a string (parse.rs:683-717: a bad escape returns Err with the position just
+// behind it; parse.rs:563-581: an invalid float suffix swallows two characters, whatever they are).  If the parser then
+// drops that Err token (Q6/Q7) the bytes behind it are code.  The host finds such a position R from a first pass
+// (api.hip parse_with_resync) and lexes again with R in this list: at R the context is N and a token starts.
+struct Resync { const uint32_t* pos; uint32_t n; };
+constexpr uint32_t CTX_RESET = 0;   // every state -> N
+// smallest listed position >= p, else 0xFFFFFFFF
+__host__ __device__ __forceinline__ uint32_t rs_next(const Resync& rs, uint32_t p) {
+    uint32_t lo = 0, hi = rs.n;
+    while (lo < hi) { uint32_t mid = (lo + hi) / 2; if (rs.pos[mid] < p) lo = mid + 1; else hi = mid; }
+    return lo < rs.n ? rs.pos[lo] : 0xFFFFFFFFu;
+}
+__host__ __device__ __forceinline__ bool rs_has(const Resync& rs, uint32_t p) { return rs.n != 0 && rs_next(rs, p) == p; }
+
+__global__ __launch_bounds__(LEX_THREADS) void k_ctx_chunk(const uint8_t* __restrict__ src, uint32_t n, uint32_t* __restrict__ chunk_fn, uint32_t* __restrict__ tile_fn, Resync rs) {
     __shared__ uint32_t lds[4];
     uint32_t chunk = blockIdx.x * LEX_THREADS + threadIdx.x;
     uint64_t base = (uint64_t)chunk * LEX_CHUNK;
     uint32_t f = CTX_IDENTITY;
     if (base < n) {
         uint32_t end = (uint32_t)((base + LEX_CHUNK < n) ? base + LEX_CHUNK : n);
-        if (end - (uint32_t)base == LEX_CHUNK) {
+        uint32_t nr = rs.n ? rs_next(rs, (uint32_t)base) : 0xFFFFFFFFu;
+        if (nr < end) {   // a resync point in this chunk: everything before it is forgotten
+            for (uint32_t i = (uint32_t)base; i < end; i++) {
+                if (i == nr) { f = CTX_RESET; nr = rs_next(rs, i + 1); }
+                f = ctx_compose(f, ctx_of_byte(src[i]));
+            }
+        } else if (end - (uint32_t)base == LEX_CHUNK) {
             const uint4* p = reinterpret_cast<const uint4*>(src + base);
 #pragma unroll
             for (int q = 0; q < LEX_CHUNK / 16; q++) {
@@ -270,7 +291,7 @@ __device__ __noinline__ bool lx_decimal_to_f64(const uint8_t* __restrict__ s, ui
     return true;
 }
 
-__device__ void lex_one(const uint8_t* __restrict__ s, uint32_t n, uint32_t pos, LexTok& o, uint8_t* strdst, uint32_t* status) {
+__device__ void lex_one(const uint8_t* __restrict__ s, uint32_t n, uint32_t pos, LexTok& o, uint8_t* strdst, uint32_t* status, const Resync& rs) {
     o.kind = T_EndOfFile; o.flags = 0; o.aux = 0; o.low = pos; o.end = pos + 1; o.nval = 0; o.v0 = o.v1 = 0; o.payload = 0; o.strbytes = 0;
     int c = s[pos];
     switch (c) {
@@ -327,8 +348,8 @@ __device__ void lex_one(const uint8_t* __restrict__ s, uint32_t n, uint32_t pos,
                 if (a >= 0x80 || b >= 0x80) lx_unsupported(status, DS_UNSUPPORTED_NONASCII, pos);
                 if (a == '3' && b == '2') { o.aux = 32; p += 3; }
                 else if (a == '6' && b == '4') { o.aux = 64; p += 3; }
-                else if (a >= 0 && b < 0) { lx_error(o, PE_InvalidNumericSize, pos, p + 2 - pos, (uint32_t)a - (uint32_t)'0', p + 2); if (!lx_is_run(a)) o.flags |= OPUSFE_TF_RESYNC; return; }
-                else if (a >= 0 && b >= 0) { lx_error(o, PE_InvalidNumericSize, pos, p + 3 - pos, ((uint32_t)a - (uint32_t)'0') * 10u + ((uint32_t)b - (uint32_t)'0'), p + 3); if (!lx_is_run(a) || !lx_is_run(b)) o.flags |= OPUSFE_TF_RESYNC; return; }
+                else if (a >= 0 && b < 0) { lx_error(o, PE_InvalidNumericSize, pos, p + 2 - pos, (uint32_t)a - (uint32_t)'0', p + 2); if (!lx_is_run(a) && !rs_has(rs, p + 2)) o.flags |= OPUSFE_TF_RESYNC; return; }
+                else if (a >= 0 && b >= 0) { lx_error(o, PE_InvalidNumericSize, pos, p + 3 - pos, ((uint32_t)a - (uint32_t)'0') * 10u + ((uint32_t)b - (uint32_t)'0'), p + 3); if ((!lx_is_run(a) || !lx_is_run(b)) && !rs_has(rs, p + 3)) o.flags |= OPUSFE_TF_RESYNC; return; }
                 else { lx_unsupported(status, DS_UNSUPPORTED_HANG, pos); p += 1; }   // `<float>f<EOF>`: the reference loops forever (Q4)
             }
             o.end = p;
@@ -400,16 +421,16 @@ __device__ void lex_one(const uint8_t* __restrict__ s, uint32_t n, uint32_t pos,
                     int hv = hc < 0 ? -1 : lx_hex(hc), lv = lc < 0 ? -1 : lx_hex(lc);
                     if (hv >= 0 && lv >= 0) { if (dst) dst[nout] = (uint8_t)(hv * 16 + lv); nout++; p = q2; continue; }
                     if (q2 > n) q2 = n;
-                    lx_error(o, PE_InvalidEscapeSequence, escape_position, q2 - escape_position, 0, lx_string_end(s, n, p));
-                    o.flags |= OPUSFE_TF_RESYNC;
+                    if (rs_has(rs, q2)) lx_error(o, PE_InvalidEscapeSequence, escape_position, q2 - escape_position, 0, q2);   // second pass: lexing resumes at q2
+                    else { lx_error(o, PE_InvalidEscapeSequence, escape_position, q2 - escape_position, 0, lx_string_end(s, n, p)); o.flags |= OPUSFE_TF_RESYNC; }
                     o.strbytes = 4 + ((nout + 3) & ~3u);
                     return;
                 }
                 if (e < 0) { lx_error(o, PE_UnexpectedEndOfFile, n, 0, 0, n); o.strbytes = 4 + ((nout + 3) & ~3u); return; }
                 uint32_t el = lx_utf8_len(e);
                 if (escape_position + el > n) el = n - escape_position;
-                lx_error(o, PE_InvalidEscapeSequence, escape_position, el, 0, lx_string_end(s, n, p));
-                o.flags |= OPUSFE_TF_RESYNC;
+                if (rs_has(rs, escape_position + el)) lx_error(o, PE_InvalidEscapeSequence, escape_position, el, 0, escape_position + el);
+                else { lx_error(o, PE_InvalidEscapeSequence, escape_position, el, 0, lx_string_end(s, n, p)); o.flags |= OPUSFE_TF_RESYNC; }
                 o.strbytes = 4 + ((nout + 3) & ~3u);
                 return;
             }
@@ -428,21 +449,35 @@ __device__ void lex_one(const uint8_t* __restrict__ s, uint32_t n, uint32_t pos,
 // Walks one chunk [cbeg, cend) given the context state at cbeg; calls f(tok) for every token that
 // starts inside the chunk.  Returns nothing; `f` accumulates.
 template <class F>
-__device__ __forceinline__ void lex_chunk(const uint8_t* __restrict__ s, uint32_t n, uint32_t cbeg, uint32_t cend, uint32_t state, uint32_t* status, F&& f) {
+__device__ __forceinline__ void lex_chunk(const uint8_t* __restrict__ s, uint32_t n, uint32_t cbeg, uint32_t cend, uint32_t state, uint32_t* status, const Resync& rs, F&& f) {
     uint32_t pos = cbeg;
-    // (a) finish a string / comment that began in an earlier chunk
-    while (state != CS_N && pos < cend) { state = ctx_apply(ctx_of_byte(s[pos]), state); pos++; }
+    bool forced = false;      // a resync point: context N and a token boundary, whatever precedes it
+    if (rs.n) {
+        uint32_t nr = rs_next(rs, cbeg);
+        if (nr == cbeg) { state = CS_N; forced = true; }
+        // the invalid-float-suffix error swallows two characters (parse.rs:563-581): a chunk that starts on the second one,
+        // in code context behind a non-run first one, starts inside that Err token, which ends at the resync point cbeg + 1
+        else if (state == CS_N && cbeg > 0 && !lx_is_run(s[cbeg - 1]) && rs_has(rs, cbeg + 1)) { pos = cbeg + 1; forced = true; }
+        // (a) as below, but a resync point ends the string: context N and a token boundary at pos (> cbeg: no look-back)
+        while (state != CS_N && pos < cend) {
+            if (pos == nr) { state = CS_N; break; }
+            state = ctx_apply(ctx_of_byte(s[pos]), state); pos++;
+        }
+    } else {
+        // (a) finish a string / comment that began in an earlier chunk
+        while (state != CS_N && pos < cend) { state = ctx_apply(ctx_of_byte(s[pos]), state); pos++; }
+    }
     if (state != CS_N) return;
     // (b) we are in context N at pos (== cbeg unless (a) moved us, in which case pos is a boundary).
-    if (pos == cbeg && cbeg > 0 && lx_is_run(s[cbeg - 1])) {
+    if (pos == cbeg && cbeg > 0 && !forced && lx_is_run(s[cbeg - 1])) {
         // The chunk may begin inside a token: find the closest certain boundary to the left
-        // (a byte that is not a run character in context N always ends a token) and re-lex from it.
+        // (a byte that is not a run character in context N always ends a token; so does a resync point) and re-lex from it.
         uint32_t p = cbeg;
-        while (p > 0 && lx_is_run(s[p - 1])) p--;
+        while (p > 0 && lx_is_run(s[p - 1]) && !rs_has(rs, p)) p--;
         while (p < cbeg) {
             LexTok t;
             // only run characters here: never whitespace, ';' or '"'
-            lex_one(s, n, p, t, nullptr, status);
+            lex_one(s, n, p, t, nullptr, status, rs);
             p = t.end;
         }
         pos = p;   // >= cbeg: first boundary at or after the chunk start
@@ -471,7 +506,7 @@ __device__ __forceinline__ void lex_chunk(const uint8_t* __restrict__ s, uint32_
 __global__ LEX_ATTR __launch_bounds__(LEX_THREADS) void k_lex_count(const uint8_t* __restrict__ src, uint32_t n, const uint32_t* __restrict__ chunk_fn,
                                                          const uint8_t* __restrict__ tile_state, uint8_t* __restrict__ chunk_state,
                                                          uint32_t* __restrict__ chunk_cnt, uint32_t* __restrict__ chunk_str,
-                                                         Cnt3* __restrict__ tile_cnt, uint32_t* status) {
+                                                         Cnt3* __restrict__ tile_cnt, uint32_t* status, Resync rs) {
     __shared__ uint32_t lds[4];
     __shared__ Cnt3 lds3[4];
     uint32_t chunk = blockIdx.x * LEX_THREADS + threadIdx.x;
@@ -489,9 +524,9 @@ __global__ LEX_ATTR __launch_bounds__(LEX_THREADS) void k_lex_count(const uint8_
     Cnt3 c{0, 0, 0, 0};
     if (live) {
         uint32_t cbeg = (uint32_t)base, cend = (uint32_t)((base + LEX_CHUNK < n) ? base + LEX_CHUNK : n);
-        lex_chunk(src, n, cbeg, cend, state, status, [&](uint32_t pos) {
+        lex_chunk(src, n, cbeg, cend, state, status, rs, [&](uint32_t pos) {
             LexTok t;
-            lex_one(src, n, pos, t, nullptr, status);
+            lex_one(src, n, pos, t, nullptr, status, rs);
             c.tok++; c.val += t.nval; c.str += t.strbytes;
             return t.end;
         });
@@ -507,7 +542,7 @@ __global__ LEX_ATTR __launch_bounds__(LEX_THREADS) void k_lex_count(const uint8_
 __global__ LEX_ATTR __launch_bounds__(LEX_THREADS) void k_lex_emit(const uint8_t* __restrict__ src, uint32_t n, const uint8_t* __restrict__ chunk_state,
                                                         const uint32_t* __restrict__ chunk_cnt, const uint32_t* __restrict__ chunk_str,
                                                         const Cnt3* __restrict__ tile_off, opusfe_token* __restrict__ raw, uint64_t* __restrict__ val64,
-                                                        uint8_t* __restrict__ strpool, uint32_t* status) {
+                                                        uint8_t* __restrict__ strpool, uint32_t* status, Resync rs) {
     __shared__ Cnt3 lds3[4];
     __shared__ Cnt3 wave_last[4];
     uint32_t chunk = blockIdx.x * LEX_THREADS + threadIdx.x;
@@ -523,9 +558,9 @@ __global__ LEX_ATTR __launch_bounds__(LEX_THREADS) void k_lex_emit(const uint8_t
     uint32_t cbeg = (uint32_t)base, cend = (uint32_t)((base + LEX_CHUNK < n) ? base + LEX_CHUNK : n);
     uint32_t state = chunk_state[chunk];
     uint32_t ti = off.tok, vi = off.val, si = off.str;
-    lex_chunk(src, n, cbeg, cend, state, status, [&](uint32_t pos) {
+    lex_chunk(src, n, cbeg, cend, state, status, rs, [&](uint32_t pos) {
         LexTok t;
-        lex_one(src, n, pos, t, strpool + si, status);
+        lex_one(src, n, pos, t, strpool + si, status, rs);
         opusfe_token o;
         o.kind = t.kind; o.flags = t.flags; o.aux = t.aux; o.low = t.low; o.len = t.end - t.low;
         if (t.kind == T_Error) { o.low = pos; o.payload = vi; }

@@ -23,6 +23,7 @@ struct opusfe_unit {
     bool parsed = false;
     bool has_error = false; opusfe_error error{}; uint32_t err_seg = 0;
     uint32_t unsup_pos = 0xFFFFFFFFu;                          // first byte the reference cannot be followed on (lexer)
+    std::vector<uint32_t> resync;                              // sorted resync points found by earlier passes (lex.h Resync)
     // IR
     bool lowered = false;
     void* ir = nullptr;                                        // opusfe::IrResult (lower.h)

@@ -30,6 +30,7 @@ struct EmuUnit {
     std::vector<uint8_t> src;
     std::vector<uint32_t> seg_start;
     std::vector<uint32_t> seg_info;
+    std::vector<uint32_t> resync;     // api.hip body_parse: resync points found by earlier passes
     uint32_t status[64] = {0};
 };
 
@@ -43,18 +44,19 @@ void emu_lex(EmuUnit& E, int force_dents) {
     // AddressSanitizer sees any write outside a token's reserved pool slice
     std::vector<uint8_t> chunk_state;
     Cnt3 tot{0, 0, 0, 0};
+    const Resync rs{E.resync.data(), (uint32_t)E.resync.size()};
     {
         uint32_t state = CS_N;
         for (uint64_t cb = 0; cb < n; cb += LEX_CHUNK) {
             uint32_t cbeg = (uint32_t)cb, cend = (uint32_t)((cb + LEX_CHUNK < n) ? cb + LEX_CHUNK : n);
             chunk_state.push_back((uint8_t)state);
-            lex_chunk(src, n, cbeg, cend, state, status, [&](uint32_t pos) {
+            lex_chunk(src, n, cbeg, cend, state, status, rs, [&](uint32_t pos) {
                 LexTok t;
-                lex_one(src, n, pos, t, nullptr, status);
+                lex_one(src, n, pos, t, nullptr, status, rs);
                 tot.tok++; tot.val += t.nval; tot.str += t.strbytes;
                 return t.end;
             });
-            for (uint32_t p = cbeg; p < cend; p++) state = ctx_apply(ctx_of_byte(src[p]), state);
+            for (uint32_t p = cbeg; p < cend; p++) { if (rs_has(rs, p)) state = CS_N; state = ctx_apply(ctx_of_byte(src[p]), state); }   // k_ctx_chunk
         }
     }
     opusfe_token* raw_p = (opusfe_token*)malloc(sizeof(opusfe_token) * (tot.tok ? tot.tok : 1));
@@ -64,9 +66,9 @@ void emu_lex(EmuUnit& E, int force_dents) {
         uint32_t ti = 0, vi = 0, si = 0, c = 0;
         for (uint64_t cb = 0; cb < n; cb += LEX_CHUNK, c++) {
             uint32_t cbeg = (uint32_t)cb, cend = (uint32_t)((cb + LEX_CHUNK < n) ? cb + LEX_CHUNK : n);
-            lex_chunk(src, n, cbeg, cend, chunk_state[c], status, [&](uint32_t pos) {
+            lex_chunk(src, n, cbeg, cend, chunk_state[c], status, rs, [&](uint32_t pos) {
                 LexTok t;
-                lex_one(src, n, pos, t, pool_p + si, status);
+                lex_one(src, n, pos, t, pool_p + si, status, rs);
                 opusfe_token o;
                 o.kind = t.kind; o.flags = t.flags; o.aux = t.aux; o.low = t.low; o.len = t.end - t.low;
                 if (t.kind == T_Error) { o.low = pos; o.payload = vi; }
@@ -279,8 +281,17 @@ char* emu_dump(const uint8_t* src, uint64_t len, int what, uint64_t* out_len, in
     E.src.resize(len + 16, 0);          // the product pads device sources the same way
     E.u.len = len;
     E.u.h_src.assign(src, src + len);
-    emu_lex(E, what == 5);
-    if (what != 5 && (E.u.status == OPUSFE_OK || E.u.status == OPUSFE_UNSUPPORTED)) emu_parse(E);
+    for (;;) {   // api.hip body_parse: lex and parse again with every resync point a pass finds
+        emu_lex(E, what == 5);
+        if (what != 5 && (E.u.status == OPUSFE_OK || E.u.status == OPUSFE_UNSUPPORTED)) emu_parse(E);
+        if (what == 5 || E.resync.size() >= 16 || E.u.status != OPUSFE_UNSUPPORTED || E.u.dev_status != DS_UNSUPPORTED_RESYNC) break;
+        uint32_t r = OPUSFE_NONE;
+        for (const opusfe_token& t : E.u.h_tokens)
+            if (t.low == E.status[1] && t.kind == T_Error && (t.flags & OPUSFE_TF_RESYNC)) { uint64_t sp = E.u.h_val64[t.payload]; r = (uint32_t)sp + (uint32_t)(sp >> 32); break; }
+        if (r == OPUSFE_NONE || r > E.u.len || (!E.resync.empty() && r <= E.resync.back())) break;
+        E.resync.push_back(r);
+        E.u.has_error = false; E.u.parsed = false; E.u.have_h_ast = false;
+    }
     if ((what == 2 || what == 4) && E.u.status == OPUSFE_OK) emu_lower(E);
     std::string s;
     switch (what) {

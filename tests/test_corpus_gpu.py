@@ -29,11 +29,7 @@ def test_corpus_matches_oracle_per_file(fe):
         want_err = O.dump(src, O.ERROR)
         if want_err != "Ok\n":
             errors += 1
-            if u.status == 2:
-                continue                     # swallowed bad escape: documented UNSUPPORTED
             assert u.status == 1 and u.dump_error() == want_err
-            continue
-        if u.status == 2:
             continue
         assert u.status == 0, (u.status, src[:60])
         got, want = u.dump_ir(), O.dump(src, O.IR)
@@ -83,7 +79,7 @@ def test_semantic_mutants(fe):
     """ill-typed programs (tests/mutate.py): the 25 semantic error kinds, Error instructions and the panic paths of the
     reference's IR generation — IR text and ordered diagnostics against the oracle"""
     import mutate as M
-    srcs = M.mutants(400, seed0=50_000) + M.byte_mutants(300, seed0=50_000)
+    srcs = M.mutants(400, seed0=50_000) + M.byte_mutants(300, seed0=50_000) + M.trap_mutants(300, seed0=50_000)
     units = fe.compile_corpus(srcs, lower=True)
     seen = {}
     for s, u in zip(srcs, units):
@@ -92,7 +88,7 @@ def test_semantic_mutants(fe):
         if w[0] == "unsupported":
             assert u.status == 2, s
         elif w[0] == "syntax":
-            assert (u.status == 1 and u.dump_error() == w[1]) or (w[2] and u.status == 2), s
+            assert u.status == 1 and u.dump_error() == w[1], s
         elif w[0] == "semantic":
             assert u.status == 7 and u._dump(4) == w[1], s
         else:

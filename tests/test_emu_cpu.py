@@ -15,9 +15,6 @@ def compare_parse(cases):
     toks = E.dump_many(cases, 0)
     for c, (st, e), (_, a), (_, t) in zip(cases, errs, asts, toks):
         want = O.dump(c, O.ERROR)
-        if st == 2 and want != "Unsupported\n":
-            assert b"\\q" in c or b"\\x" in c or b"\\" in c, (c[:80], want)   # documented: swallowed bad escape
-            continue
         assert e == want, (c[:80], e, want)
         if want == "Ok\n":
             assert a == O.dump(c, O.AST), c[:80]
@@ -104,7 +101,7 @@ def test_emu_float_literals_outside_the_fast_path():
 def test_emu_semantic_mutants():
     """ill-typed programs (tests/mutate.py): the error paths of IR generation, emulated under ASan before any GPU sees them"""
     import mutate as M
-    cases = M.mutants(260) + M.byte_mutants(240)
+    cases = M.mutants(260) + M.byte_mutants(240) + M.trap_mutants(300)
     want = [M.expectation(c) for c in cases]
     errs, irs, sems = E.dump_many(cases, 3), E.dump_many(cases, 2), E.dump_many(cases, 4)
     seen = set()
@@ -113,7 +110,7 @@ def test_emu_semantic_mutants():
         if w[0] == "unsupported":
             assert st == 2, c
         elif w[0] == "syntax":
-            assert (st == 1 and err == w[1]) or (w[2] and st == 2), c
+            assert st == 1 and err == w[1], c
         elif w[0] == "semantic":
             assert st == 7 and sem == w[1], c
         else:

@@ -31,7 +31,7 @@ def main():
         srcs.append(s)
     if args.mutants:
         import mutate as M
-        srcs += M.mutants(args.mutants, seed0=args.first) + M.byte_mutants(args.mutants, seed0=args.first)
+        srcs += M.mutants(args.mutants, seed0=args.first) + M.byte_mutants(args.mutants, seed0=args.first) + M.trap_mutants(args.mutants, seed0=args.first)
     ctx = opus_amd.Context(0)
     units = ctx.compile_corpus(srcs, lower=True)
     bad = 0
