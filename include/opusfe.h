@@ -148,6 +148,10 @@ int opusfe_lower(opusfe_ctx* ctx, opusfe_unit* unit);
 int opusfe_semantic_error_count(const opusfe_unit* unit, uint64_t* n);
 
 /* ---- results ---- */
+/* number of resync passes opusfe_parse took for this unit (0 for well-formed input).  A byte-range shard of a
+   larger source that needed one cannot be combined with its neighbours: behind the resync point the reference's lexer
+   contexts differ from the ones the shard carries were computed with (opus_amd/shard.py reports OPUSFE_UNSUPPORTED). */
+int opusfe_unit_resync_passes(const opusfe_unit* unit, uint32_t* n);
 int opusfe_unit_status(const opusfe_unit* unit);           /* OPUSFE_OK / _SYNTAX / _UNSUPPORTED ... of the unit */
 int opusfe_get_counts(const opusfe_unit* unit, opusfe_counts* out);
 int opusfe_get_error(const opusfe_unit* unit, opusfe_error* out);

@@ -601,6 +601,12 @@ int opusfe_semantic_error_count(const opusfe_unit* u, uint64_t* n) {
     return OPUSFE_OK;
 }
 
+int opusfe_unit_resync_passes(const opusfe_unit* u, uint32_t* n) {
+    if (!u || !n) return OPUSFE_ERR_ARG;
+    *n = (uint32_t)u->resync.size();
+    return OPUSFE_OK;
+}
+
 int opusfe_unit_status(const opusfe_unit* unit) { return unit ? unit->status : OPUSFE_ERR_ARG; }
 
 int opusfe_get_counts(const opusfe_unit* u, opusfe_counts* out) {

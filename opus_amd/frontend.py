@@ -72,6 +72,7 @@ def lib():
         L.opusfe_unit_join.argtypes = [vp, vp, vp, u64, C.POINTER(vp)]
         L.opusfe_lower.argtypes = [vp, vp]
         L.opusfe_unit_status.argtypes = [vp]
+        L.opusfe_unit_resync_passes.argtypes = [vp, C.POINTER(u32)]
         L.opusfe_get_counts.argtypes = [vp, C.POINTER(Counts)]
         L.opusfe_get_error.argtypes = [vp, C.POINTER(Error)]
         L.opusfe_copy_tokens.argtypes = [vp, vp, u64, C.POINTER(u64)]
@@ -137,6 +138,12 @@ class Unit:
 
     def dump_error(self):
         return self._dump(3)
+
+    def resync_passes(self):
+        """how many extra lex + parse passes the unit needed for swallowed lexical errors (0 for well-formed input)"""
+        n = C.c_uint32()
+        lib().opusfe_unit_resync_passes(self.handle, C.byref(n))
+        return n.value
 
     def compile_source(self):
         """frontend.rs:140-187, IR part.  Returns the status (OK / SEMANTIC / UNSUPPORTED)."""

@@ -179,7 +179,9 @@ def compile_sharded(states, gather, lower=True):
         u = s.ctx.get_definitions_device(buf.data_ptr(), s.own.numel())
         s._own_buf = buf
         parsed.append(u)
-    statuses = gather("status", [u.status for u in parsed])
+    # a shard that needed a resync pass (swallowed lexical error) changes the lexer context of everything behind
+    # it, which the carries exchanged in plan() did not know: the sharded path reports such a source as UNSUPPORTED
+    statuses = gather("status", [F.UNSUPPORTED if (u.status == F.OK and u.resync_passes() > 0) else u.status for u in parsed])
     if any(st != F.OK for st in statuses):
         first = next(r for r, st in enumerate(statuses) if st != F.OK)
         return [dict(status=statuses[first], unit=u, ir=None, first_bad_rank=first) for u in parsed]

@@ -90,3 +90,23 @@ def test_truncations_of_a_program(fe):
         assert u.dump_error() == want, (n, data[-40:])
         if want == "Ok\n":
             assert u.dump_ast() == O.dump(data, O.AST), n
+
+
+def test_resync_passes_only_on_swallowed_lexical_errors(fe):
+    ok = b"f() int32\n\treturn 1\n"
+    assert fe.get_definitions(ok).resync_passes() == 0
+    reported = b'f() null\n\tvar s = "ab\\q"\n'                       # the Err token is the first syntax error: one pass
+    u = fe.get_definitions(reported)
+    assert u.status == 1 and u.resync_passes() == 0 and u.dump_error() == O.dump(reported, O.ERROR)
+    for src in (b'f() int32\n\treturn 1\n"ab\\q\ng() int32\n\treturn 2\n',                      # Q7: dropped at top level
+                b'f() int32\n\treturn 1\n"a\\xZ1 g() int32\n\treturn 2\n',
+                b'f() null\n\tx = 1.5f";"\n\ty = 2\n"zz\\q\n"yy\\w\nh() null\n\treturn\n',          # several in one file
+                b'f(a bool) null\n\tif a\n\t\treturn\n\t"bad \\q esc" g()\n'):                        # Q6: the else probe
+        u = fe.get_definitions(src)
+        assert u.dump_error() == O.dump(src, O.ERROR), src
+        assert u.dump_tokens() == O.dump(src, O.TOKENS), src
+        if u.status == 0:
+            assert u.dump_ast() == O.dump(src, O.AST)
+            assert u.compile_source() in (0, 7)
+            assert u.dump_ir() == O.dump(src, O.IR)
+    assert fe.get_definitions(b'f() int32\n\treturn 1\n"ab\\q\ng() int32\n\treturn 2\n').resync_passes() == 1

@@ -128,3 +128,19 @@ def test_unit_join_equals_parsing_the_concatenated_text(fe):
         c = j2.counts()
         assert c["definitions"] == a.counts()["definitions"] + h2.counts()["definitions"]
         j2.close(); h2.close()
+
+
+def test_shard_with_a_swallowed_lexical_error_is_refused(fe):
+    """A swallowed bad escape at a top-level position turns the rest of the file's lexer contexts around; the
+    single-GPU path follows the reference with a resync pass, the sharded path must refuse (not answer wrongly)."""
+    a, b = O.generate(5, 150_000), O.generate(6, 150_000)
+    src = a + b'"ab\\q\n' + b
+    whole = fe.get_definitions(src)
+    assert whole.resync_passes() >= 1
+    assert whole.dump_error() == O.dump(src, O.ERROR)          # the single-GPU answer is the reference's
+    states, res = run_sharded(fe, src, 4)
+    assert all(r["status"] != 0 for r in res) and res[0]["first_bad_rank"] is not None
+    st = res[0]["status"]
+    assert st in (1, 2)
+    if st == 1:      # a syntax error reported before the trap wins, exactly as on one GPU
+        assert O.dump(src, O.ERROR) != "Ok\n"
