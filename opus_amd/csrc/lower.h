@@ -1523,12 +1523,13 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
     R->d_tid_of_node = dev_alloc_t<uint32_t>(ctx, n_nodes);
     uint8_t* undefined_flag = tmp.get<uint8_t>(n_nodes);
     uint32_t* ph_def = tmp.get<uint32_t>(n_gtypes);
+    uint32_t* ph_prev = tmp.get<uint32_t>(n_gtypes);     // `type` definition -> the previous one of the same name (duplicates)
     R->d_funcrecs = dev_alloc_t<FuncRec>(ctx, n_funcs);
     R->d_globals = dev_alloc_t<GlobalRec>(ctx, n_globals);
     LAUNCH(ctx, "sem_resolve_types", k_sem_resolve_types, grid_for(std::max<uint32_t>(n_nodes, TP_COUNT), 256), 256, u->d_src, u->d_tokens, u->d_nodes, n_nodes,
-           slot_of_node, slots, n_slots - 1, entries, R->d_tid_of_node, types, undefined_flag, ph_def);
+           slot_of_node, slots, n_slots - 1, entries, R->d_tid_of_node, types, undefined_flag, ph_def, ph_prev);
     LAUNCH(ctx, "sem_finalize", k_sem_finalize, grid_for(n_defs, 256), 256, u->d_nodes, u->d_def_nodes, n_defs, def_excl, R->d_tid_of_node, undefined_flag,
-           ph_def, n_nodes, types, R->d_funcrecs, R->d_globals, ctx->d_status + WL_FINERR);
+           ph_def, ph_prev, n_nodes, types, R->d_funcrecs, R->d_globals, ctx->d_status + WL_FINERR);
 
     // E. lowering into sparse per-function regions
     LowerBuffers B{};
@@ -1554,13 +1555,13 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
         R->n_sem_errors = ctx->h_status[WL_FINERR];
         // the diagnostics themselves, in the reference's report order (definitions in file order)
         uint32_t* fin_cnt = tmp.get<uint32_t>(n_defs);
-        LAUNCH(ctx, "sem_fin_count", k_sem_fin_count, grid_for(n_defs, 256), 256, u->d_nodes, u->d_def_nodes, n_defs, R->d_tid_of_node, undefined_flag, ph_def, n_nodes, types, fin_cnt);
+        LAUNCH(ctx, "sem_fin_count", k_sem_fin_count, grid_for(n_defs, 256), 256, u->d_nodes, u->d_def_nodes, n_defs, R->d_tid_of_node, undefined_flag, ph_def, ph_prev, n_nodes, types, fin_cnt);
         prof_begin(ctx, "sem_fin_scan");
         device_scan<true>(fin_cnt, fin_cnt, n_defs, OpAddU32(), (uint32_t)0, scan_tmp, (uint32_t*)nullptr, st);
         prof_end(ctx);
         R->n_errs = R->n_sem_errors;
         R->d_errs = dev_alloc_t<SemErr>(ctx, R->n_errs);
-        LAUNCH(ctx, "sem_fin_emit", k_sem_fin_emit, grid_for(n_defs, 256), 256, u->d_nodes, u->d_def_nodes, n_defs, R->d_tid_of_node, undefined_flag, ph_def, n_nodes, types, fin_cnt, R->d_errs);
+        LAUNCH(ctx, "sem_fin_emit", k_sem_fin_emit, grid_for(n_defs, 256), 256, u->d_nodes, u->d_def_nodes, n_defs, R->d_tid_of_node, undefined_flag, ph_def, ph_prev, n_nodes, types, fin_cnt, R->d_errs);
         HIP_TRY(hipStreamSynchronize(st));
         prof_collect(ctx);
         u->status = OPUSFE_SEMANTIC;

@@ -469,10 +469,33 @@ __device__ __forceinline__ uint32_t sem_type_id_of(const uint8_t* src, const opu
     return TP_Error;
 }
 
+// The `type` definition of the same name that precedes definition node `def` (duplicate names: every one of them writes
+// the placeholder that type_resolution_map holds for the name, compile.rs:1055-1062, in definition order), else NONE.
+__device__ __forceinline__ uint32_t sem_prev_type_def(const uint8_t* src, const opusfe_token* tok, uint32_t name_tok, uint32_t def,
+                                                      const NameSlot* slots, uint32_t slot_mask, const NameEntry* entries) {
+    NameKey key = key_tok(name_tok);
+    uint32_t h = name_hash(tok, key) & slot_mask;
+    for (uint32_t probe = 0; probe <= slot_mask; probe++) {
+        uint32_t rep = slots[h].rep;
+        if (rep == OPUSFE_NONE) break;
+        if (name_eq(src, tok, key, key_tok(rep))) {
+            const NameSlot sl = slots[h];
+            uint32_t best = OPUSFE_NONE;      // the largest type-definition node below `def` (entries are few per name)
+            for (uint32_t j = 0; j < sl.count; j++) {
+                NameEntry e = entries[sl.offset + j];
+                if ((e.kind_index >> 30) == NK_TYPE && e.def_node < def && (best == OPUSFE_NONE || e.def_node > best)) best = e.def_node;
+            }
+            return best;
+        }
+        h = (h + 1) & slot_mask;
+    }
+    return OPUSFE_NONE;
+}
+
 __global__ void k_sem_resolve_types(const uint8_t* __restrict__ src, const opusfe_token* __restrict__ tok, const opusfe_node* __restrict__ nodes, uint32_t n_nodes,
                                     const uint32_t* __restrict__ slot_of_node, const NameSlot* __restrict__ slots, uint32_t slot_mask,
                                     const NameEntry* __restrict__ entries, uint32_t* __restrict__ tid_of_node, TypeRec* __restrict__ types,
-                                    uint8_t* __restrict__ undefined_flag, uint32_t* __restrict__ ph_def) {
+                                    uint8_t* __restrict__ undefined_flag, uint32_t* __restrict__ ph_def, uint32_t* __restrict__ ph_prev) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < TP_COUNT) { TypeRec p{}; p.kind = prim_kind(i); p.alias = OPUSFE_NONE; types[i] = p; }   // launched with >= TP_COUNT lanes
     if (i >= n_nodes) return;
@@ -484,6 +507,7 @@ __global__ void k_sem_resolve_types(const uint8_t* __restrict__ src, const opusf
         types[id] = r;
         tid_of_node[i] = id;
         ph_def[slot_of_node[i]] = i;
+        ph_prev[slot_of_node[i]] = sem_prev_type_def(src, tok, n.payload, i, slots, slot_mask, entries);
         return;
     }
     if (n.kind < Y_Name || n.kind > Y_Array) { tid_of_node[i] = OPUSFE_NONE; return; }
@@ -527,13 +551,16 @@ enum SErrKind : uint32_t { SE_ParseError, SE_UndefinedVariable, SE_ShadowedName,
 // alias captures whatever the target held at that moment.  Decided from the AST alone (placeholders are written
 // concurrently by other lanes of k_sem_finalize), returns the record and whether it is final.
 __device__ __forceinline__ TypeRec sem_contents_at(const opusfe_node* nodes, const uint32_t* tid_of_node, const TypeRec* types,
-                                                   const uint32_t* ph_def, uint32_t tid, uint32_t at_def, uint32_t n_defs) {
+                                                   const uint32_t* ph_def, const uint32_t* ph_prev, uint32_t tid, uint32_t at_def, uint32_t n_defs) {
     TypeRec content{}; content.kind = TY_Error; content.alias = OPUSFE_NONE;
     for (uint32_t guard = 0; guard < n_defs + 2; guard++) {
         if (tid < TP_COUNT) { content.kind = prim_kind(tid); return content; }
         uint32_t def = ph_def[tid - TP_COUNT];
         if (def == OPUSFE_NONE) return types[tid];               // structured type: its record never changes
-        if (def >= at_def) { content.kind = TY_Error; return content; }   // not finalized yet (or itself)
+        // the placeholder of a name is written by every `type` definition of that name in turn: what it holds now is what the
+        // latest of them before `at_def` wrote (ph_prev links a definition to the previous one of the same name)
+        for (uint32_t g2 = 0; def != OPUSFE_NONE && def >= at_def && g2 <= n_defs; g2++) def = ph_prev[tid_of_node[def] - TP_COUNT];
+        if (def == OPUSFE_NONE || def >= at_def) { content.kind = TY_Error; return content; }   // not finalized yet (or itself)
         at_def = def;
         tid = tid_of_node[nodes[def].first_child];               // what that definition copied from
     }
@@ -548,7 +575,7 @@ __device__ __forceinline__ TypeRec sem_contents_at(const opusfe_node* nodes, con
 // before and after k_sem_finalize wrote the placeholders.
 __device__ __forceinline__ uint32_t sem_finalize_errors(const opusfe_node* __restrict__ nodes, const uint32_t* __restrict__ def_nodes, uint32_t n_defs, uint32_t d,
                                                         const uint32_t* __restrict__ tid_of_node, const uint8_t* __restrict__ undefined_flag,
-                                                        const uint32_t* __restrict__ ph_def, uint32_t n_nodes, const TypeRec* __restrict__ types, SemErr* out) {
+                                                        const uint32_t* __restrict__ ph_def, const uint32_t* __restrict__ ph_prev, uint32_t n_nodes, const TypeRec* __restrict__ types, SemErr* out) {
     const uint32_t dn = def_nodes[d];
     const uint32_t dn_end = d + 1 < n_defs ? def_nodes[d + 1] : n_nodes;
     const opusfe_node n = nodes[dn];
@@ -573,7 +600,7 @@ __device__ __forceinline__ uint32_t sem_finalize_errors(const opusfe_node* __res
                 const bool is_int = v.kind == E_Integer || (v.kind == E_Negate && nodes[v.first_child].kind == E_Integer);
                 uint32_t kind = OPUSFE_NONE;
                 if (!is_int) kind = SE_InvalidConstantExpression;
-                else if (!kind_is_integral(sem_contents_at(nodes, tid_of_node, types, ph_def, tid_of_node[ty], dn, n_defs).kind)) kind = SE_InvalidType;
+                else if (!kind_is_integral(sem_contents_at(nodes, tid_of_node, types, ph_def, ph_prev, tid_of_node[ty], dn, n_defs).kind)) kind = SE_InvalidType;
                 if (kind != OPUSFE_NONE) { if (out) out[nerr] = SemErr{kind, v.low, v.high - v.low}; nerr++; }
             }
             break;
@@ -588,13 +615,13 @@ __device__ __forceinline__ uint32_t sem_finalize_errors(const opusfe_node* __res
 // (has_errors): with any, frontend.rs:145 skips IR generation.
 __global__ void k_sem_finalize(const opusfe_node* __restrict__ nodes, const uint32_t* __restrict__ def_nodes, uint32_t n_defs,
                                const DefCnt* __restrict__ def_excl, const uint32_t* __restrict__ tid_of_node, const uint8_t* __restrict__ undefined_flag,
-                               const uint32_t* __restrict__ ph_def, uint32_t n_nodes, TypeRec* __restrict__ types, FuncRec* __restrict__ funcs,
+                               const uint32_t* __restrict__ ph_def, const uint32_t* __restrict__ ph_prev, uint32_t n_nodes, TypeRec* __restrict__ types, FuncRec* __restrict__ funcs,
                                GlobalRec* __restrict__ globals, uint32_t* __restrict__ err) {
     uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= n_defs) return;
     const uint32_t dn = def_nodes[d];
     const opusfe_node n = nodes[dn];
-    const uint32_t nerr = sem_finalize_errors(nodes, def_nodes, n_defs, d, tid_of_node, undefined_flag, ph_def, n_nodes, types, nullptr);
+    const uint32_t nerr = sem_finalize_errors(nodes, def_nodes, n_defs, d, tid_of_node, undefined_flag, ph_def, ph_prev, n_nodes, types, nullptr);
     switch (n.kind) {
         case D_Function: case D_Extern: {
             FuncRec f{}; f.def_node = dn; f.name_tok = n.payload; f.flags = n.kind == D_Extern ? 1u : 0u;
@@ -611,7 +638,7 @@ __global__ void k_sem_finalize(const opusfe_node* __restrict__ nodes, const uint
             break;
         }
         case D_Type: {
-            TypeRec content = sem_contents_at(nodes, tid_of_node, types, ph_def, tid_of_node[n.first_child], dn, n_defs);
+            TypeRec content = sem_contents_at(nodes, tid_of_node, types, ph_def, ph_prev, tid_of_node[n.first_child], dn, n_defs);
             content.alias = n.payload;
             types[tid_of_node[dn]] = content;
             break;
@@ -623,16 +650,16 @@ __global__ void k_sem_finalize(const opusfe_node* __restrict__ nodes, const uint
 
 // The ordered diagnostics of a unit whose finalize reported errors (the rare path: two more launches and a scan).
 __global__ void k_sem_fin_count(const opusfe_node* __restrict__ nodes, const uint32_t* __restrict__ def_nodes, uint32_t n_defs, const uint32_t* __restrict__ tid_of_node,
-                                const uint8_t* __restrict__ undefined_flag, const uint32_t* __restrict__ ph_def, uint32_t n_nodes, const TypeRec* __restrict__ types,
+                                const uint8_t* __restrict__ undefined_flag, const uint32_t* __restrict__ ph_def, const uint32_t* __restrict__ ph_prev, uint32_t n_nodes, const TypeRec* __restrict__ types,
                                 uint32_t* __restrict__ cnt) {
     uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
-    if (d < n_defs) cnt[d] = sem_finalize_errors(nodes, def_nodes, n_defs, d, tid_of_node, undefined_flag, ph_def, n_nodes, types, nullptr);
+    if (d < n_defs) cnt[d] = sem_finalize_errors(nodes, def_nodes, n_defs, d, tid_of_node, undefined_flag, ph_def, ph_prev, n_nodes, types, nullptr);
 }
 __global__ void k_sem_fin_emit(const opusfe_node* __restrict__ nodes, const uint32_t* __restrict__ def_nodes, uint32_t n_defs, const uint32_t* __restrict__ tid_of_node,
-                               const uint8_t* __restrict__ undefined_flag, const uint32_t* __restrict__ ph_def, uint32_t n_nodes, const TypeRec* __restrict__ types,
+                               const uint8_t* __restrict__ undefined_flag, const uint32_t* __restrict__ ph_def, const uint32_t* __restrict__ ph_prev, uint32_t n_nodes, const TypeRec* __restrict__ types,
                                const uint32_t* __restrict__ excl, SemErr* __restrict__ out) {
     uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
-    if (d < n_defs) sem_finalize_errors(nodes, def_nodes, n_defs, d, tid_of_node, undefined_flag, ph_def, n_nodes, types, out + excl[d]);
+    if (d < n_defs) sem_finalize_errors(nodes, def_nodes, n_defs, d, tid_of_node, undefined_flag, ph_def, ph_prev, n_nodes, types, out + excl[d]);
 }
 
 }  // namespace opusfe

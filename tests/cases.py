@@ -141,3 +141,15 @@ FINALIZE_ERROR_CASES = [
     "f() int32\n\tvar x nosuch\n\treturn 1\nvar g nosuch2\n",
     "type P = record { x int32 }\nvar p P = 1\nvar q @int32 = 0\nvar r string = 1\n",
 ]
+
+# duplicate `type` names: every definition of a name writes the one placeholder type_resolution_map holds for it
+# (compile.rs:968-981, 1055-1062), in definition order; what a global between two of them sees is the earlier one's content
+DUPLICATE_TYPE_CASES = [
+    "type T = int32\nvar x T = 1\ntype T = float64\nvar y T = 2\n",
+    "type T = int32\nf(a T) T\n\treturn a\ntype T = float64\ng(a T) T\n\treturn a\n",
+    "type T = int32\ntype U = T\ntype T = bool\ntype V = T\nvar a U = 1\nvar b V = 1\nvar c T = 1\n",
+    "var w T = 1\ntype T = nat8\nvar x T = 1\ntype T = T\nvar y T = 1\ntype T = @T\nvar z T = 1\nf(t T) T return t\n",
+    "type A = B\ntype B = int32\ntype A = B\nvar p A = 1\ntype B = bool\ntype A = B\nvar q A = 1\n",
+    "type A = B\ntype B = int32\ntype A = B\nf(p A, q B) A\n\tvar r A = q\n\treturn r\n",
+]
+IR_CASES += DUPLICATE_TYPE_CASES

@@ -193,22 +193,22 @@ void emu_lower(EmuUnit& E) {
     TypeRec* types = exact<TypeRec>(type_cap);
     R->tid_of_node.assign(n_nodes, 0);
     std::vector<uint8_t> undefined_flag(n_nodes);
-    std::vector<uint32_t> ph_def(n_gtypes);
+    std::vector<uint32_t> ph_def(n_gtypes), ph_prev(n_gtypes);
     R->funcrecs.assign(n_funcs, FuncRec{}); R->globals.assign(n_globals, GlobalRec{});
     emu_launch(k_sem_resolve_types, grid_for(std::max<uint32_t>(n_nodes, TP_COUNT), 256), 256, E.src.data(), tok, nodes, n_nodes, slot_of_node.data(), slots, n_slots - 1,
-               entries, R->tid_of_node.data(), types, undefined_flag.data(), ph_def.data());
+               entries, R->tid_of_node.data(), types, undefined_flag.data(), ph_def.data(), ph_prev.data());
     uint32_t finerr = 0;
-    emu_launch(k_sem_finalize, grid_for(n_defs, 256), 256, nodes, def_nodes, n_defs, def_excl.data(), R->tid_of_node.data(), undefined_flag.data(), ph_def.data(), n_nodes,
+    emu_launch(k_sem_finalize, grid_for(n_defs, 256), 256, nodes, def_nodes, n_defs, def_excl.data(), R->tid_of_node.data(), undefined_flag.data(), ph_def.data(), ph_prev.data(), n_nodes,
                types, R->funcrecs.data(), R->globals.data(), &finerr);
     R->n_funcs = n_funcs; R->n_globals = n_globals; R->n_gtypes = n_gtypes;
     if (finerr) {
         std::vector<uint32_t> fin_cnt(n_defs);
         emu_launch(k_sem_fin_count, grid_for(n_defs, 256), 256, nodes, def_nodes, n_defs, (const uint32_t*)R->tid_of_node.data(), (const uint8_t*)undefined_flag.data(),
-                   (const uint32_t*)ph_def.data(), n_nodes, (const TypeRec*)types, fin_cnt.data());
+                   (const uint32_t*)ph_def.data(), (const uint32_t*)ph_prev.data(), n_nodes, (const TypeRec*)types, fin_cnt.data());
         { uint32_t run = 0; for (uint32_t d = 0; d < n_defs; d++) { uint32_t c = fin_cnt[d]; fin_cnt[d] = run; run += c; } }
         SemErr* errs = exact<SemErr>(finerr);   // exact-size block: an emit beyond the counted total is an ASan error
         emu_launch(k_sem_fin_emit, grid_for(n_defs, 256), 256, nodes, def_nodes, n_defs, (const uint32_t*)R->tid_of_node.data(), (const uint8_t*)undefined_flag.data(),
-                   (const uint32_t*)ph_def.data(), n_nodes, (const TypeRec*)types, (const uint32_t*)fin_cnt.data(), errs);
+                   (const uint32_t*)ph_def.data(), (const uint32_t*)ph_prev.data(), n_nodes, (const TypeRec*)types, (const uint32_t*)fin_cnt.data(), errs);
         R->errs.assign(errs, errs + finerr); R->n_errs = finerr;
         free(errs);
         R->n_sem_errors = finerr; u.status = OPUSFE_SEMANTIC; free(slots); free(entries); free(types); return;
