@@ -224,7 +224,8 @@ struct Lowerer {
     __device__ void report(uint32_t kind, uint32_t low, uint32_t high) {
         kind = uni(kind); low = uni(low); high = uni(high);
         if (nerrs < ecap) gst(errs + nerrs, SemErr{kind, low, high - low});
-        nerrs++;   // counting past the capacity is fine: has_errors is what matters, the list is clipped
+        else internal();   // more diagnostics than the region holds (one per node + 16): an internal-capacity status, never a clipped list
+        nerrs++;
     }
     __device__ void report_node(uint32_t kind, uint32_t node) { kind = uni(kind); node = uni(node); report(kind, N(node).low, N(node).high); }
     __device__ void report_tok(uint32_t kind, uint32_t t) { kind = uni(kind); t = uni(t); const opusfe_token x = TK(t); report(kind, x.low, x.low + x.len); }
