@@ -33,7 +33,7 @@ typedef struct opusfe_unit opusfe_unit;
 enum {
     OPUSFE_OK = 0,
     OPUSFE_SYNTAX = 1,        /* first syntax error available through opusfe_get_error */
-    OPUSFE_UNSUPPORTED = 2,   /* input on which the reference hangs/panics or needs unpinned Unicode tables */
+    OPUSFE_UNSUPPORTED = 2,   /* input on which the reference hangs/panics or needs unpinned Unicode tables (DESIGN.md §5) */
     OPUSFE_ERR_HIP = 3,       /* HIP failure, including "no GPU" */
     OPUSFE_ERR_OOM = 4,
     OPUSFE_ERR_ARG = 5,

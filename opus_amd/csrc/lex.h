@@ -165,6 +165,22 @@ __device__ __forceinline__ bool lx_is_run(int c) { return lx_is_identc(c) || c =
 __device__ __forceinline__ int lx_hex(int c) { return lx_is_digit(c) ? c - '0' : (c >= 'a' && c <= 'f') ? c - 'a' + 10 : (c >= 'A' && c <= 'F') ? c - 'A' + 10 : -1; }
 __device__ __forceinline__ uint32_t lx_utf8_len(int b0) { return b0 < 0x80 ? 1 : b0 >= 0xF0 ? 4 : b0 >= 0xE0 ? 3 : b0 >= 0xC0 ? 2 : 1; }
 
+// One UTF-8 scalar at p (the source is valid UTF-8: frontend.rs:85 read_to_string; a truncated tail is clamped to n)
+__device__ __forceinline__ uint32_t lx_decode(const uint8_t* __restrict__ s, uint32_t n, uint32_t p, uint32_t* len) {
+    uint32_t b0 = s[p];
+    uint32_t L = lx_utf8_len((int)b0);
+    if (p + L > n) L = n - p;
+    uint32_t c = L == 4 ? (b0 & 0x07) : L == 3 ? (b0 & 0x0F) : L == 2 ? (b0 & 0x1F) : b0;
+    for (uint32_t i = 1; i < L; i++) c = (c << 6) | (s[p + i] & 0x3Fu);
+    *len = L;
+    return c;
+}
+// char::is_whitespace = Unicode White_Space: 25 code points, unchanged since Unicode 6.3, hence the same in every Rust release
+// that builds the reference (unlike is_alphanumeric, whose tables are not pinned: identifiers stay ASCII here)
+__device__ __forceinline__ bool lx_unicode_ws(uint32_t c) {
+    return c == 0x85 || c == 0xA0 || c == 0x1680 || (c >= 0x2000 && c <= 0x200A) || c == 0x2028 || c == 0x2029 || c == 0x202F || c == 0x205F || c == 0x3000;
+}
+
 __device__ __forceinline__ uint64_t kw_pack(const char* s) {
     uint64_t v = 0;
     for (int i = 0; s[i] && i < 8; i++) v |= (uint64_t)(uint8_t)s[i] << (8 * i);
@@ -381,7 +397,11 @@ __device__ void lex_one(const uint8_t* __restrict__ s, uint32_t n, uint32_t pos,
         uint32_t h = (2166136261u ^ (uint32_t)c) * 16777619u;
         for (;;) {
             int d = lx_at(s, n, p);
-            if (d >= 0x80) { lx_unsupported(status, DS_UNSUPPORTED_NONASCII, p); break; }
+            if (d >= 0x80) {   // White_Space is never alphanumeric: the identifier ends; anything else needs the unpinned tables
+                uint32_t L;
+                if (!lx_unicode_ws(lx_decode(s, n, p, &L))) lx_unsupported(status, DS_UNSUPPORTED_NONASCII, pos);   // from the token's first byte: which token this is depends on the tables
+                break;
+            }
             if (!lx_is_identc(d)) break;
             if (p - pos < 8) w |= (uint64_t)d << (8 * (p - pos));
             h = (h ^ (uint32_t)d) * 16777619u;
@@ -442,8 +462,10 @@ __device__ void lex_one(const uint8_t* __restrict__ s, uint32_t n, uint32_t pos,
         if (strdst) { *reinterpret_cast<uint32_t*>(strdst) = nout; for (uint32_t k = nout; k < ((nout + 3) & ~3u); k++) dst[k] = 0; }
         return;
     }
-    if (c >= 0x80) { lx_unsupported(status, DS_UNSUPPORTED_NONASCII, pos); }
-    lx_error(o, PE_UnexpectedCharacter, pos, 1, (uint64_t)c, pos + 1);
+    // parse.rs:718: any other character, ASCII or not, is an UnexpectedCharacter error that spans the character
+    uint32_t L = 1, cp = (uint32_t)c;
+    if (c >= 0x80) cp = lx_decode(s, n, pos, &L);
+    lx_error(o, PE_UnexpectedCharacter, pos, L, (uint64_t)cp, pos + L);
 }
 
 // Walks one chunk [cbeg, cend) given the context state at cbeg; calls f(tok) for every token that
@@ -485,6 +507,11 @@ __device__ __forceinline__ void lex_chunk(const uint8_t* __restrict__ s, uint32_
     while (pos < cend) {
         int c = s[pos];
         if (lx_is_ws(c)) { pos++; continue; }
+        if (c >= 0x80) {
+            if (c < 0xC0) { pos++; continue; }   // continuation byte at the chunk start: the character belongs to the lane of its first byte
+            uint32_t L;
+            if (lx_unicode_ws(lx_decode(s, n, pos, &L))) { pos += L; continue; }   // parse.rs:432,474 char::is_whitespace
+        }
         if (c == ';') {   // comment: to the next '\n' (parse.rs:450-457); the '\n' itself is whitespace
             pos++;
             while (pos < n && s[pos] != '\n') pos++;

@@ -112,13 +112,14 @@ struct Parser {
     // parse.rs:423-425
     uint32_t peek() const { size_t n; return decode(real_position, &n); }
 
-    // char::is_whitespace restricted to ASCII; non-ASCII scalars outside strings/comments are
-    // rejected as Unsupported (SURVEY §7 hard part 7: Unicode tables are not pinned).
-    bool is_ws(uint32_t c) const {
-        if (c == NONE) return false;
-        if (c >= 0x80) throw Unsupported{"non-ASCII character outside string/comment", real_position};
-        return c == ' ' || (c >= 9 && c <= 13);
+    // char::is_whitespace = the Unicode White_Space property: 25 code points, unchanged since Unicode 6.3 (2013), so the
+    // same in every Rust release that can build the reference.  (is_alphanumeric is a different matter: its tables grow
+    // with every Unicode version and are not pinned, see the identifier loop below.)
+    static bool unicode_ws(uint32_t c) {
+        return c == ' ' || (c >= 9 && c <= 13) || c == 0x85 || c == 0xA0 || c == 0x1680 || (c >= 0x2000 && c <= 0x200A) || c == 0x2028 || c == 0x2029
+            || c == 0x202F || c == 0x205F || c == 0x3000;
     }
+    bool is_ws(uint32_t c) const { return c != NONE && unicode_ws(c); }
 
     // parse.rs:427-479.  The tail recursion at :458 is written as a loop; a recursive call starts
     // with new_indent = 0, measure_indents = check_indent = (real_position == 0) = false.
@@ -366,7 +367,10 @@ Token Parser::parse_token_inner() {
         for (;;) {
             uint32_t d = peek();
             if (d == NONE) break;
-            if (d >= 0x80) throw Unsupported{"non-ASCII character outside string/comment", real_position};
+            if (d >= 0x80) {
+                if (unicode_ws(d)) break;        // White_Space is never alphanumeric
+                throw Unsupported{"non-ASCII character behind an identifier (char::is_alphanumeric tables unpinned)", real_position};
+            }
             bool alnum = (d >= '0' && d <= '9') || (d >= 'a' && d <= 'z') || (d >= 'A' && d <= 'Z');
             if (alnum || d == '_' || d == '\\') { byte_len += 1; advance(); } else break;
         }
@@ -425,7 +429,7 @@ Token Parser::parse_token_inner() {
         }
         Token t; t.kind = Tok::String; t.bytes = std::move(chars); return t;
     }
-    if (c >= 0x80) throw Unsupported{"non-ASCII character outside string/comment", token_low};
+    // parse.rs:718: any other character, ASCII or not, is an UnexpectedCharacter error spanning that character
     ParseError e; e.kind = PErr::UnexpectedCharacter; e.span = char_at(token_low); e.ch = c; fail(e);
 }
 

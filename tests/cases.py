@@ -153,3 +153,10 @@ DUPLICATE_TYPE_CASES = [
     "type A = B\ntype B = int32\ntype A = B\nf(p A, q B) A\n\tvar r A = q\n\treturn r\n",
 ]
 IR_CASES += DUPLICATE_TYPE_CASES
+
+# non-ASCII in code (parse.rs:432,474 char::is_whitespace; :718 UnexpectedCharacter), placed so that the characters straddle
+# the 64-byte chunks of the GPU lexer; at top level the error token is dropped (Q7) and parsing goes on
+NON_ASCII_CASES = ([" " * k + ch + "\nf() null\n\treturn\n" for k in range(57, 67) for ch in ("\u2192", "\u00a0", "\U0001F600", "\u3000\u00e9")]
+                   + ["f() int32\n\treturn 1\u00a0+\u20282\n", "f() int32\n\treturn x\u00a0\n", "f() int32\n\treturn x\u00e9\n",
+                      "f() int32\n\treturn 1 \u2192 2\n", "f() int32\n\tvar in\u00e9t = 1\n", "; \u00e9 \u2192\nf() null\n\tvar s = \"\u00e9\u2192\"\n"])
+PARSE_CASES += NON_ASCII_CASES

@@ -104,7 +104,11 @@ BYTES = b"\t\t\t\n\n\n  ()[]{}:=<>+-*/%@~.,?\"\"\\\\;;#$!&|^`'0123456789abcdefxy
 # lexical errors behind which the reference resumes in the middle of a string body or swallows arbitrary characters
 # (bad escapes, invalid float suffixes): dropped by the parser at some positions (Q6/Q7), the resync passes of api.hip
 LEXICAL_TRAPS = [b'"ab\\q', b'\\q', b'"\\xZ1', b'1.5f";', b'"\\', b'"', b'\\x4', b'"\\xG', b'2.5f(7', b'"\\"', b'\\\\', b'3.5f\n',
-                 b'"a\\q"', b'"\\q\\w\\e', b'1.0f ;']
+                 b'"a\\q"', b'"\\q\\w\\e', b'1.0f ;',
+                 # non-ASCII in code: Unicode white space is skipped, any other character is an UnexpectedCharacter error of
+                 # its own length; right behind an identifier it is UNSUPPORTED (is_alphanumeric tables unpinned)
+                 "\u00a0".encode(), "\u3000 ".encode(), "\u2028".encode(), " \u2192 ".encode(), "\u00e9".encode(), " \U0001F600".encode(),
+                 "\u00a0\u00a0x".encode(), "\u0085".encode()]
 
 
 def trap_mutants(n, seed0=0, lo=700, hi=2500):
