@@ -14,7 +14,7 @@ def make_corpus(n, seed0=5_000_000):
         size = 1024 + (i * 7919) % (24 * 1024)
         src = O.generate(seed0 + i, size)
         if i % 10 == 7:                      # a share of the files carries exactly one injected fault
-            bad = O.inject(src, seed0 + i, i % 10)
+            bad = O.inject(src, seed0 + i, (i // 10) % 10)      # all ten fault kinds in turn
             src = bad or src
         files.append(src)
     return files
@@ -98,3 +98,30 @@ def test_semantic_mutants(fe):
             assert u.ir_view().text() == w[1]
         u.close()
     assert seen.get("ir", 0) > 100 and seen.get("syntax", 0) > 50 and seen.get("semantic", 0) > 0
+
+
+def test_config5_shape_at_scale(fe):
+    """BASELINE config 5 in small: 1000 files, sizes log-uniform in [1 KB, 64 KB], i = 7 (mod 100) carries exactly one injected
+    fault (all ten kinds in turn): error tuple for the faulty files, hash of the IR text for the rest"""
+    import math
+    import random
+    rnd = random.Random(55)
+    files = []
+    for i in range(1000):
+        size = int(math.exp(rnd.uniform(math.log(1024), math.log(65536))))
+        src = O.generate(5_000_000 + i, size)
+        if i % 100 == 7:
+            src = O.inject(src, 5_000_000 + i, (i // 100) % 10) or src
+        files.append(src)
+    units = fe.compile_corpus(files, lower=True)
+    faulty = 0
+    for src, u in zip(files, units):
+        want_err = O.dump(src, O.ERROR)
+        if want_err != "Ok\n":
+            faulty += 1
+            assert u.status == 1 and u.dump_error() == want_err
+        else:
+            assert u.status == 0, (u.status, src[:60])
+            assert hashlib.sha256(u.dump_ir().encode()).digest() == hashlib.sha256(O.dump(src, O.IR).encode()).digest()
+        u.close()
+    assert faulty >= 8
