@@ -110,3 +110,13 @@ def test_resync_passes_only_on_swallowed_lexical_errors(fe):
             assert u.compile_source() in (0, 7)
             assert u.dump_ir() == O.dump(src, O.IR)
     assert fe.get_definitions(b'f() int32\n\treturn 1\n"ab\\q\ng() int32\n\treturn 2\n').resync_passes() == 1
+
+
+def test_resync_pass_limit_is_unsupported_not_wrong(fe):
+    """16 swallowed lexical errors per unit are followed exactly; one more and the answer is OPUSFE_UNSUPPORTED"""
+    def src(k):
+        return b"".join(b'"a\\q\nf%d() int32\n\treturn %d\n' % (i, i) for i in range(k))
+    u = fe.get_definitions(src(16))
+    assert u.status == 0 and u.resync_passes() == 16 and u.dump_ast() == O.dump(src(16), O.AST)
+    assert u.compile_source() == 0 and u.dump_ir() == O.dump(src(16), O.IR)
+    assert fe.get_definitions(src(17)).status == 2
