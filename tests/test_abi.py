@@ -54,3 +54,10 @@ def test_no_gpu_means_loud_failure_not_a_cpu_path():
         assert e.code == F.ERR_HIP
     else:
         raise AssertionError("opusfe_create succeeded without a GPU")
+
+
+def test_integration_doc_binds_every_entry_point():
+    """INTEGRATION.md shows the reference-side binding: one extern declaration per function of include/opusfe.h"""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = [n for n in declared_functions() if f"pub fn {n}(" not in text]
+    assert not missing, missing
