@@ -48,6 +48,32 @@ class Program:
     def compile_source(self):
         return self.unit.compile_source()
 
+    def render_semantic_errors(self, read=None):
+        """stderr text of the unit's semantic diagnostics in report order (compile.rs:782-917 + frontend.rs:201-256), each
+        located in its own file.  The reference indexes `filenames` by the position of the source in `sources`
+        (frontend.rs:204-209), so after a duplicate import the printed name is the one pushed at that index, as there."""
+        from . import render as R
+        if read is None:
+            def read(path):
+                with open(path, "rb") as f:
+                    return f.read()
+        out = []
+        for e in self.unit.array(V.A_SEM_ERRORS):
+            i, off = self.locate(int(e["low"]))
+            out.append(R.render_semantic(int(e["kind"]), self.filenames[i], read(self.source_files[i]), off, int(e["len"])))
+        return "".join(out)
+
+
+def render_program_error(err):
+    """stderr text of the ProgramError that ended load_program: the unreadable-file line (frontend.rs:88) or the parse error
+    of the file it was found in (frontend.rs:130-133)"""
+    from . import render as R
+    if err.unit is None:
+        return str(err) + "\n"
+    if err.unit.status != F.SYNTAX:
+        return f"{err.filename}: {F._NAMES[err.unit.status]}\n"
+    return R.render_parse_error(err.unit, err.filename)
+
 
 def _directives(unit):
     """(kind, bytes) of the Import / Library definitions of a parsed unit, in definition order"""

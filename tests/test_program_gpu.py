@@ -85,3 +85,19 @@ def test_semantic_error_positions_map_back_to_their_file(fe):
     assert len(errs) == 1
     i, off = prog.locate(int(errs[0]["low"]))
     assert prog.source_files[i] == "u.opus" and files["u.opus"][off:off + int(errs[0]["len"])] == b"nosuch"
+
+
+def test_errors_of_a_program_are_rendered_in_their_file(fe, tmp_path):
+    from opus_amd import render as R
+    Y, RED, Z = "\x1b[33m", "\x1b[31;1m", "\x1b[0m"
+    (tmp_path / "m.opus").write_bytes(b'import "u.opus"\nf() int32\n\treturn 1\n')
+    (tmp_path / "u.opus").write_bytes(b"g() int32\n\treturn nosuch\n")
+    prog = P.load_program(fe, str(tmp_path / "m.opus"))
+    assert prog.compile_source() == 0
+    name = str(tmp_path / "u.opus")
+    assert prog.render_semantic_errors() == (f"{RED}Error:{Z} undefined variable: nosuch\n{Y}{name}:{Z}\n"
+                                             f"{Y}   2:{Z}     return {RED}nosuch{Z}\n")
+    (tmp_path / "u.opus").write_bytes(b"g() int32\n\treturn )\n")
+    with pytest.raises(P.ProgramError) as e:
+        P.load_program(fe, str(tmp_path / "m.opus"))
+    assert P.render_program_error(e.value) == (f"{RED}Error:{Z} unexpected token: )\n{Y}{name}:{Z}\n{Y}   2:{Z}     return {RED}){Z}\n")
