@@ -134,6 +134,14 @@ void opusfe_shard_free(opusfe_shard* shard);
    `hdr` is the parsed text of the other shards' headers (those of the ranks before this one first).  No counterpart in
    the reference (one file, one thread); for lowering a shard against the whole program's declarations. */
 int opusfe_unit_join(opusfe_ctx* ctx, opusfe_unit* own, opusfe_unit* hdr, uint64_t split_pos, opusfe_unit** out);
+/* A parsed unit from its six flat arrays (device pointers on ctx's device; the library copies them): the inverse of
+   opusfe_array for OPUSFE_A_SOURCE, _TOKENS, _VAL64, _STRINGS, _NODES and _DEFINITIONS.  For moving parsed units between
+   GPUs: the shards exchange their parsed definition headers and join them (opusfe_unit_join) instead of every rank parsing
+   every other rank's header text.  No counterpart in the reference (one file, one thread).  The arrays must come from
+   opusfe_array of a unit that parsed with OPUSFE_OK; indices are range-checked by the consumers as always. */
+int opusfe_unit_from_arrays(opusfe_ctx* ctx, const uint8_t* d_src, uint64_t src_len, const opusfe_token* d_tokens, uint64_t n_tokens,
+                            const uint64_t* d_val64, uint64_t n_val64, const uint8_t* d_strings, uint64_t n_strings,
+                            const opusfe_node* d_nodes, uint64_t n_nodes, const uint32_t* d_defs, uint64_t n_defs, opusfe_unit** out);
 /* device text (owned by the unit) that other shards prepend / append to see this unit's definitions: functions as
    `extern <signature>`, externs / types / globals verbatim, one per line, in file order */
 int opusfe_unit_headers(opusfe_unit* unit, const uint8_t** d_out, uint64_t* len);

@@ -565,6 +565,41 @@ int opusfe_unit_join(opusfe_ctx* ctx, opusfe_unit* own, opusfe_unit* hdr, uint64
     });
 }
 
+int opusfe_unit_from_arrays(opusfe_ctx* ctx, const uint8_t* d_src, uint64_t src_len, const opusfe_token* d_tokens, uint64_t n_tokens,
+                            const uint64_t* d_val64, uint64_t n_val64, const uint8_t* d_strings, uint64_t n_strings,
+                            const opusfe_node* d_nodes, uint64_t n_nodes, const uint32_t* d_defs, uint64_t n_defs, opusfe_unit** out) {
+    if (!ctx || !out) return OPUSFE_ERR_ARG;
+    *out = nullptr;
+    if ((src_len && !d_src) || (n_tokens && !d_tokens) || (n_val64 && !d_val64) || (n_strings && !d_strings) || (n_nodes && !d_nodes) || (n_defs && !d_defs)) return OPUSFE_ERR_ARG;
+    if (src_len > MAX_LEN || n_tokens >= 0xFFFFFFF0ull || n_nodes >= 0xFFFFFFF0ull || n_defs > n_nodes) return fail(ctx, OPUSFE_ERR_ARG, "opusfe_unit_from_arrays: sizes out of range");
+    return guarded(ctx, [&] {
+        hipStream_t st = ctx->stream;
+        opusfe_unit* u = new opusfe_unit();
+        u->ctx = ctx; u->status = OPUSFE_OK; u->len = src_len; u->own_src = true;
+        u->n_tokens = n_tokens; u->n_val64 = n_val64; u->n_strpool = n_strings; u->n_nodes = n_nodes; u->n_defs = n_defs;
+        uint8_t* src = dev_alloc_t<uint8_t>(ctx, src_len + 64);
+        u->d_src = src;
+        u->d_tokens = dev_alloc_t<opusfe_token>(ctx, n_tokens + 1);
+        u->d_val64 = dev_alloc_t<uint64_t>(ctx, n_val64 + 1);
+        u->d_strpool = dev_alloc_t<uint8_t>(ctx, n_strings + 16);
+        u->d_nodes = dev_alloc_t<opusfe_node>(ctx, n_nodes + 1);
+        u->d_def_nodes = dev_alloc_t<uint32_t>(ctx, n_defs + 1);
+        try {
+            HIP_TRY(hipMemsetAsync(src + src_len, '\n', 64, st));
+            if (src_len) HIP_TRY(hipMemcpyAsync(src, d_src, src_len, hipMemcpyDeviceToDevice, st));
+            if (n_tokens) HIP_TRY(hipMemcpyAsync(u->d_tokens, d_tokens, n_tokens * sizeof(opusfe_token), hipMemcpyDeviceToDevice, st));
+            if (n_val64) HIP_TRY(hipMemcpyAsync(u->d_val64, d_val64, n_val64 * 8, hipMemcpyDeviceToDevice, st));
+            if (n_strings) HIP_TRY(hipMemcpyAsync(u->d_strpool, d_strings, n_strings, hipMemcpyDeviceToDevice, st));
+            if (n_nodes) HIP_TRY(hipMemcpyAsync(u->d_nodes, d_nodes, n_nodes * sizeof(opusfe_node), hipMemcpyDeviceToDevice, st));
+            if (n_defs) HIP_TRY(hipMemcpyAsync(u->d_def_nodes, d_defs, n_defs * 4, hipMemcpyDeviceToDevice, st));
+            sync_stream(ctx);
+        } catch (...) { opusfe_free_unit(u); throw; }
+        u->parsed = true;
+        *out = u;
+        return (int)OPUSFE_OK;
+    });
+}
+
 // Text another shard needs to know about this unit's definitions (multi-GPU IR generation): device buffer owned by
 // the unit.  Functions appear as `extern <signature>`, everything else verbatim, one definition per line, file order.
 int opusfe_unit_headers(opusfe_unit* u, const uint8_t** d_out, uint64_t* len) {

@@ -70,6 +70,7 @@ def lib():
         L.opusfe_shard_free.argtypes = [vp]
         L.opusfe_unit_headers.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
         L.opusfe_unit_join.argtypes = [vp, vp, vp, u64, C.POINTER(vp)]
+        L.opusfe_unit_from_arrays.argtypes = [vp, vp, u64, vp, u64, vp, u64, vp, u64, vp, u64, vp, u64, C.POINTER(vp)]
         L.opusfe_lower.argtypes = [vp, vp]
         L.opusfe_unit_status.argtypes = [vp]
         L.opusfe_unit_resync_passes.argtypes = [vp, C.POINTER(u32)]
@@ -240,6 +241,15 @@ class Context:
     def get_definitions_device(self, d_ptr: int, length: int):
         out = C.c_void_p()
         return self._finish(lib().opusfe_parse_device(self.handle, C.c_void_p(d_ptr), length, C.byref(out)), out)
+
+    def unit_from_arrays(self, arrays):
+        """opusfe_unit_from_arrays: `arrays` = six (device pointer, element count) pairs in the order source, tokens, val64,
+        strings, nodes, definitions (what Unit.array_device gives for those arrays)"""
+        out = C.c_void_p()
+        args = []
+        for p, n in arrays:
+            args += [C.c_void_p(p), int(n)]
+        return self._finish(lib().opusfe_unit_from_arrays(self.handle, *args, C.byref(out)), out)
 
     def compile_corpus(self, sources, lower=True):
         """Corpus of independent files (one reference run per file): list of Units, each with its own status."""

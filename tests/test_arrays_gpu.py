@@ -102,3 +102,18 @@ def test_semantic_error_array_matches_the_dump(fe):
     for e, line in zip(errs, want):
         _, low, ln = line.split(" ")
         assert int(e["low"]) == int(low) and int(e["len"]) == int(ln)
+
+
+def test_unit_from_arrays_round_trip(fe):
+    """opusfe_unit_from_arrays is the inverse of opusfe_array for the six parse-side arrays: the rebuilt unit lowers to the same
+    IR and joins like the original"""
+    src = O.generate(32, 200_000)
+    u = fe.get_definitions(src)
+    assert u.status == 0
+    arrs = [u.array_device(w)[:2] for w in (V.A_SOURCE, V.A_TOKENS, V.A_VAL64, V.A_STRINGS, V.A_NODES, V.A_DEFINITIONS)]
+    v = fe.unit_from_arrays(arrs)
+    assert v.status == 0 and v.counts()["nodes"] == u.counts()["nodes"] and v.counts()["definitions"] == u.counts()["definitions"]
+    assert v.dump_ast() == u.dump_ast() == O.dump(src, O.AST)
+    assert v.compile_source() == 0 and v.dump_ir() == O.dump(src, O.IR)
+    with pytest.raises(Exception):
+        fe.unit_from_arrays([(0, 5)] + arrs[1:])       # a count without a pointer is an argument error
