@@ -359,13 +359,16 @@ __device__ void lex_one(const uint8_t* __restrict__ s, uint32_t n, uint32_t pos,
             }
             o.kind = T_Float; o.nval = 1; o.v0 = (uint64_t)__double_as_longlong(f);
             if (lx_at(s, n, p) == 'f') {
-                // parse.rs:563-581: after 'f' two advance()s regardless
-                int a = lx_at(s, n, p + 1), b = a < 0 ? -1 : lx_at(s, n, p + 2);
-                if (a >= 0x80 || b >= 0x80) lx_unsupported(status, DS_UNSUPPORTED_NONASCII, pos);
+                // parse.rs:563-581: after 'f' two advance()s regardless, over characters; the size arithmetic is on code points
+                uint32_t la = 0, lb = 0;
+                int a = -1, b = -1;
+                if (p + 1 < n) a = (int)lx_decode(s, n, p + 1, &la);
+                if (a >= 0 && p + 1 + la < n) b = (int)lx_decode(s, n, p + 1 + la, &lb);
+                const uint32_t e2 = p + 1 + la, e3 = e2 + lb;      // behind one / two swallowed characters
                 if (a == '3' && b == '2') { o.aux = 32; p += 3; }
                 else if (a == '6' && b == '4') { o.aux = 64; p += 3; }
-                else if (a >= 0 && b < 0) { lx_error(o, PE_InvalidNumericSize, pos, p + 2 - pos, (uint32_t)a - (uint32_t)'0', p + 2); if (!lx_is_run(a) && !rs_has(rs, p + 2)) o.flags |= OPUSFE_TF_RESYNC; return; }
-                else if (a >= 0 && b >= 0) { lx_error(o, PE_InvalidNumericSize, pos, p + 3 - pos, ((uint32_t)a - (uint32_t)'0') * 10u + ((uint32_t)b - (uint32_t)'0'), p + 3); if ((!lx_is_run(a) || !lx_is_run(b)) && !rs_has(rs, p + 3)) o.flags |= OPUSFE_TF_RESYNC; return; }
+                else if (a >= 0 && b < 0) { lx_error(o, PE_InvalidNumericSize, pos, e2 - pos, (uint32_t)a - (uint32_t)'0', e2); if (!lx_is_run(a) && !rs_has(rs, e2)) o.flags |= OPUSFE_TF_RESYNC; return; }
+                else if (a >= 0 && b >= 0) { lx_error(o, PE_InvalidNumericSize, pos, e3 - pos, ((uint32_t)a - (uint32_t)'0') * 10u + ((uint32_t)b - (uint32_t)'0'), e3); if ((!lx_is_run(a) || !lx_is_run(b)) && !rs_has(rs, e3)) o.flags |= OPUSFE_TF_RESYNC; return; }
                 else { lx_unsupported(status, DS_UNSUPPORTED_HANG, pos); p += 1; }   // `<float>f<EOF>`: the reference loops forever (Q4)
             }
             o.end = p;
@@ -468,6 +471,20 @@ __device__ void lex_one(const uint8_t* __restrict__ s, uint32_t n, uint32_t pos,
     lx_error(o, PE_UnexpectedCharacter, pos, L, (uint64_t)cp, pos + L);
 }
 
+// Is `cbeg` inside the two characters swallowed by an invalid float suffix whose error token ends at the resync point `nr`?
+// (`<digits>.<digits>f a b`: the `f` sits at nr - 1 - len(a) - len(b), or at nr - 1 - len(a) when the file ends behind a.)
+__device__ __forceinline__ bool lx_inside_suffix_error(const uint8_t* __restrict__ s, uint32_t n, uint32_t cbeg, uint32_t nr) {
+    for (uint32_t fp = nr >= 9 ? nr - 9 : 0; fp + 2 <= nr && fp < cbeg; fp++) {
+        if (s[fp] != 'f' || fp == 0 || !(lx_is_digit(s[fp - 1]) || s[fp - 1] == '.')) continue;
+        uint32_t la = 0, lb = 0;
+        lx_decode(s, n, fp + 1, &la);
+        if (fp + 1 + la == nr && nr == n) return true;
+        if (fp + 1 + la < n) lx_decode(s, n, fp + 1 + la, &lb);
+        if (lb && fp + 1 + la + lb == nr) return true;
+    }
+    return false;
+}
+
 // Walks one chunk [cbeg, cend) given the context state at cbeg; calls f(tok) for every token that
 // starts inside the chunk.  Returns nothing; `f` accumulates.
 template <class F>
@@ -477,9 +494,9 @@ __device__ __forceinline__ void lex_chunk(const uint8_t* __restrict__ s, uint32_
     if (rs.n) {
         uint32_t nr = rs_next(rs, cbeg);
         if (nr == cbeg) { state = CS_N; forced = true; }
-        // the invalid-float-suffix error swallows two characters (parse.rs:563-581): a chunk that starts on the second one,
-        // in code context behind a non-run first one, starts inside that Err token, which ends at the resync point cbeg + 1
-        else if (state == CS_N && cbeg > 0 && !lx_is_run(s[cbeg - 1]) && rs_has(rs, cbeg + 1)) { pos = cbeg + 1; forced = true; }
+        // the invalid-float-suffix error swallows two characters (parse.rs:563-581): a chunk that starts inside them, in code
+        // context, starts inside that Err token, which ends at the resync point
+        else if (state == CS_N && nr != 0xFFFFFFFFu && nr - cbeg <= 8 && lx_inside_suffix_error(s, n, cbeg, nr)) { pos = nr < cend ? nr : cend; forced = true; }
         // (a) as below, but a resync point ends the string: context N and a token boundary at pos (> cbeg: no look-back)
         while (state != CS_N && pos < cend) {
             if (pos == nr) { state = CS_N; break; }

@@ -312,16 +312,14 @@ Token Parser::parse_token_inner() {
             Token t; t.kind = Tok::Float; t.fval = f;
             if (peek() == 'f') {
                 advance();
-                uint32_t a = advance();
-                uint32_t b = advance();
+                uint32_t a = advance();      // two *characters*, whatever they are (parse.rs:565-566); the size arithmetic below
+                uint32_t b = advance();      // is on their code points (:572,577), so non-ASCII needs no Unicode table
                 if (a == '3' && b == '2') { t.has_meta = true; t.size = 32; }
                 else if (a == '6' && b == '4') { t.has_meta = true; t.size = 64; }
                 else if (a != NONE && b == NONE) {
-                    if (a >= 0x80) throw Unsupported{"non-ASCII character in float suffix", old_position};
                     ParseError e; e.kind = PErr::InvalidNumericSize; e.size = (uint32_t)a - (uint32_t)'0';
                     e.span = sp(old_position, real_position); fail(e);
                 } else if (a != NONE && b != NONE) {
-                    if (a >= 0x80 || b >= 0x80) throw Unsupported{"non-ASCII character in float suffix", old_position};
                     ParseError e; e.kind = PErr::InvalidNumericSize;
                     e.size = ((uint32_t)a - (uint32_t)'0') * 10u + ((uint32_t)b - (uint32_t)'0');  // wrapping u32 (release)
                     e.span = sp(old_position, real_position); fail(e);

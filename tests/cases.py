@@ -160,3 +160,8 @@ NON_ASCII_CASES = ([" " * k + ch + "\nf() null\n\treturn\n" for k in range(57, 6
                    + ["f() int32\n\treturn 1\u00a0+\u20282\n", "f() int32\n\treturn x\u00a0\n", "f() int32\n\treturn x\u00e9\n",
                       "f() int32\n\treturn 1 \u2192 2\n", "f() int32\n\tvar in\u00e9t = 1\n", "; \u00e9 \u2192\nf() null\n\tvar s = \"\u00e9\u2192\"\n"])
 PARSE_CASES += NON_ASCII_CASES
+
+# invalid float suffixes over multi-byte characters, straddling the lexer's 64-byte chunks; dropped at top level (Q7)
+NON_ASCII_SUFFIX_CASES = [" " * k + lit + "\nf() null\n\treturn\n" for k in range(52, 64) for lit in ("1.5f\u00e9\u2192", "2.5f\U0001F600\U0001F600", "3.5f(\u2192", "4.5f\u00e97x")] \
+                         + ["f() null\n\tx = 1.5f\u00e97\n", "f() null\n\treturn\n2.5f\u2192"]
+PARSE_CASES += NON_ASCII_SUFFIX_CASES

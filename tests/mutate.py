@@ -108,7 +108,9 @@ LEXICAL_TRAPS = [b'"ab\\q', b'\\q', b'"\\xZ1', b'1.5f";', b'"\\', b'"', b'\\x4',
                  # non-ASCII in code: Unicode white space is skipped, any other character is an UnexpectedCharacter error of
                  # its own length; right behind an identifier it is UNSUPPORTED (is_alphanumeric tables unpinned)
                  "\u00a0".encode(), "\u3000 ".encode(), "\u2028".encode(), " \u2192 ".encode(), "\u00e9".encode(), " \U0001F600".encode(),
-                 "\u00a0\u00a0x".encode(), "\u0085".encode()]
+                 "\u00a0\u00a0x".encode(), "\u0085".encode(),
+                 # invalid float suffixes that swallow non-ASCII characters (code-point arithmetic, parse.rs:572,577)
+                 "1.5f\u00e97".encode(), "2.5f\u2192".encode(), "1.5f\u00a0 ".encode(), "3.5f(\U0001F600".encode(), "4.5f\u2192\u2192x".encode()]
 
 
 def trap_mutants(n, seed0=0, lo=700, hi=2500):
