@@ -38,7 +38,7 @@ int status_to_code(uint32_t ds) {
 const char* status_text(uint32_t ds) {
     switch (ds) {
         case DS_UNSUPPORTED_NONASCII: return "non-ASCII character right behind an identifier (char::is_alphanumeric tables unpinned)";
-        case DS_UNSUPPORTED_FLOAT: return "float literal with more than 76 significant digits";
+        case DS_UNSUPPORTED_FLOAT: return "float literal with more than 300 significant digits";
         case DS_UNSUPPORTED_HANG: return "float literal followed by 'f' at end of file (the reference never terminates)";
         case DS_UNSUPPORTED_RESYNC: return "swallowed lexical error after which the reference re-lexes a string body as code";
         case DS_UNSUPPORTED_SEMANTIC: return "construct on which the reference panics (unreachable!/unwrap)";

@@ -236,7 +236,9 @@ __device__ __forceinline__ uint32_t lx_string_end(const uint8_t* __restrict__ s,
 // rational W / 10^frac.  Up to BIGDEC_DIGITS significant digits are converted exactly with fixed-size big integers:
 // Q = floor(W * 2^E / 10^frac) with E chosen so that Q has 55..56 bits, then 53 bits are kept and the rest plus the
 // division remainder decide the rounding.  (Rare path: the arrays live in scratch memory.)
-enum { BIGDEC_LIMBS = 24, BIGDEC_DIGITS = 76 };      // 768-bit integers; 10^76 < 2^253
+// 300 digits: W, D < 10^300 < 2^997, the scaled operands stay below 2^1053 (34 limbs), and every value is in f64's normal
+// range (10^-300 .. 10^300), so no subnormal / overflow rounding is needed
+enum { BIGDEC_LIMBS = 34, BIGDEC_DIGITS = 300 };
 struct BigDec { uint32_t w[BIGDEC_LIMBS]; };
 __device__ __forceinline__ void bd_zero(BigDec& a) {
     _Pragma("unroll 1") for (int i = 0; i < BIGDEC_LIMBS; i++) a.w[i] = 0;
@@ -355,7 +357,7 @@ __device__ void lex_one(const uint8_t* __restrict__ s, uint32_t n, uint32_t pos,
                 const double P10[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
                 f = (double)w / P10[frac];
             } else if (!lx_decimal_to_f64(s, pos, p - 1 - frac, p - frac, p, &f)) {
-                lx_unsupported(status, DS_UNSUPPORTED_FLOAT, pos);      // more than 76 significant digits
+                lx_unsupported(status, DS_UNSUPPORTED_FLOAT, pos);      // more than 300 significant digits
             }
             o.kind = T_Float; o.nval = 1; o.v0 = (uint64_t)__double_as_longlong(f);
             if (lx_at(s, n, p) == 'f') {

@@ -11,8 +11,8 @@ LEX_CASES = ["5s", "5i8", "5n", "5i80", "5in", "7i12", "1.5f32", "2.", "1..2", "
              "0.30000000000000004 9007199254740993.0 9007199254740992.5 4503599627370497.5 123456789012345678901234567890.5",
              "0.000000000000000000000000000001 1.0000000000000000000000000000000000000001 3.14159265358979323846264338327950288",
              "1.50000000000000000000000000 000.000 179769313486231570000000000000000000000.0 0.1000000000000000055511151231257827"]
-# more than 76 significant digits: OPUSFE_UNSUPPORTED, never a wrong value
-TOO_LONG_FLOAT = "var x = 1." + "1" * 80 + "\n"
+# more than 300 significant digits: OPUSFE_UNSUPPORTED, never a wrong value
+TOO_LONG_FLOAT = "var x = 1." + "1" * 301 + "\n"
 
 # parser inputs: valid programs first, then one construct per syntax error
 PARSE_CASES = [

@@ -58,19 +58,19 @@ def test_float_literals_are_correctly_rounded(fe):
     rnd = random.Random(7)
     lits = []
     for _ in range(1500):
-        ni = rnd.randint(1, 40)
-        nf = min(rnd.randint(1, 40), 76 - ni)
+        ni = rnd.randint(1, 40) if rnd.random() < 0.7 else rnd.randint(1, 290)
+        nf = min(rnd.randint(1, 40) if rnd.random() < 0.7 else rnd.randint(1, 290), 300 - ni)
         lits.append("".join(rnd.choice("0123456789") for _ in range(ni)) + "." + "".join(rnd.choice("0123456789") for _ in range(nf)))
     for _ in range(300):
-        m, e = rnd.getrandbits(52) | (1 << 52), rnd.randint(-60, 60)
+        m, e = rnd.getrandbits(52) | (1 << 52), rnd.randint(-200, 200)
         v = Fraction(2 * m + 1) * Fraction(2) ** (e - 1)          # halfway between m * 2^e and (m + 1) * 2^e
         ip, r, fr = v.numerator // v.denominator, v.numerator % v.denominator, ""
-        while r and len(fr) < 75:
+        while r and len(fr) < 290:
             r *= 10
             fr += str(r // v.denominator)
             r %= v.denominator
         t = str(ip) + "." + (fr or "0")
-        if r == 0 and len(t.replace(".", "").lstrip("0")) <= 76:
+        if r == 0 and len(t.replace(".", "").lstrip("0")) <= 300:
             lits.append(t)
     src = "".join(f"const c{i} float64 = {t}\n" for i, t in enumerate(lits)).encode()
     u = fe.lex(src)
