@@ -124,6 +124,13 @@ int opusfe_parse_batch(opusfe_ctx* ctx, uint32_t n, const uint8_t* const* srcs, 
    start state, token-kind tails -> bracket depth, then picks as its cut the first top-level segment start. */
 typedef struct opusfe_shard opusfe_shard;
 int opusfe_shard_ctx(opusfe_ctx* ctx, const uint8_t* d_src, uint64_t len, uint32_t* fn);
+/* opusfe_shard_ctx for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that
+   forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.  It allocates nothing: the tile aggregates live in a static device
+   array of 256 KiB that every GPU the library runs on holds until the process ends, so `len` is limited to 1 GiB
+   (OPUSFE_ERR_ARG beyond that: split the range or use opusfe_shard_ctx); the composed context function is written to the
+   caller's device word *d_fn by work queued on ctx's stream (opusfe_stream), with no host synchronisation.  All calls on one
+   GPU share that GPU's array: calls that overlap in time on one GPU (two contexts / streams) race — serialise them. */
+int opusfe_shard_ctx_static(opusfe_ctx* ctx, const uint8_t* d_src, uint64_t len, uint32_t* d_fn);
 int opusfe_shard_lex(opusfe_ctx* ctx, const uint8_t* d_src, uint64_t len, uint32_t start_state, opusfe_shard** out,
                      uint64_t* n_tokens, uint64_t* tail_kinds);
 int opusfe_shard_net_depth(opusfe_shard* shard, uint64_t prev_kinds, int64_t* net);

@@ -230,6 +230,36 @@ int opusfe_shard_ctx(opusfe_ctx* ctx, const uint8_t* d_src, uint64_t len, uint32
     });
 }
 
+// ---- the one entry point that allocates nothing (no counterpart in the reference) -----------------------------------
+// opusfe_shard_ctx for callers that cannot call hipMalloc (HIP graph capture, tight serving loops, harnesses that forbid
+// it): same kernels, but the tile aggregates (one composed context function per 16 KiB tile, the only scratch
+// opusfe_shard_ctx needs when the per-chunk functions are not kept) live in a file-scope device array instead of the
+// caching allocator, and the result goes to a caller-provided device word instead of through a host read-back.
+// `scratch` is a host-side stand-in for the symbol, NOT a device address: opusfe_create resolves it once per device
+// with hipGetSymbolAddress and every use goes through that pointer (ctx->d_static_scratch).
+constexpr uint64_t STATIC_MAX_LEN = 1ull << 30;                                 // largest byte range the entry point accepts
+constexpr uint32_t STATIC_MAX_TILES = (uint32_t)(STATIC_MAX_LEN / LEX_TILE);    // 65536 tiles of 16 KiB -> 256 KiB of scratch
+static __device__ __align__(256) uint32_t scratch[STATIC_MAX_TILES];
+
+int opusfe_shard_ctx_static(opusfe_ctx* ctx, const uint8_t* d_src, uint64_t len, uint32_t* d_fn) {
+    if (!ctx || !d_fn || (len && !d_src)) return OPUSFE_ERR_ARG;
+    if (len > STATIC_MAX_LEN) { ctx->msg = "opusfe_shard_ctx_static: byte range larger than 1 GiB (the static scratch holds 65536 tile aggregates): split it or use opusfe_shard_ctx"; return OPUSFE_ERR_ARG; }
+    if (!ctx->d_static_scratch) { ctx->msg = "opusfe_shard_ctx_static: the static scratch of this device was not resolved at opusfe_create"; return OPUSFE_ERR_HIP; }
+    return guarded(ctx, [&] {
+        const uint32_t n = (uint32_t)len;
+        const uint64_t nchunks = ((uint64_t)n + LEX_CHUNK - 1) / LEX_CHUNK, ntiles = (nchunks + LEX_THREADS - 1) / LEX_THREADS;
+        // both kernels write every word they read later (tile_fn[0, ntiles) are all stored before k_ctx_tiles runs), so the
+        // array needs no clearing between calls; ntiles == 0 leaves the identity function in *d_fn
+        if (ntiles > 0) {
+            hipLaunchKernelGGL(k_ctx_chunk, dim3((unsigned)ntiles), dim3(LEX_THREADS), 0, ctx->stream, d_src, n, (uint32_t*)nullptr, ctx->d_static_scratch, Resync{nullptr, 0});
+            HIP_TRY(hipGetLastError());
+        }
+        hipLaunchKernelGGL(k_ctx_tiles, dim3(1), dim3(SCAN_THREADS), 0, ctx->stream, (const uint32_t*)ctx->d_static_scratch, (uint8_t*)nullptr, (uint32_t)ntiles, (uint32_t)CS_N, d_fn);
+        HIP_TRY(hipGetLastError());
+        return (int)OPUSFE_OK;
+    });
+}
+
 // raw (dent-free) tokens of a shard whose first byte is in context `start_state`; *n_tokens and the kinds of its last
 // (up to 8) tokens, most recent in the low byte, T_EndOfFile where there is none
 int opusfe_shard_lex(opusfe_ctx* ctx, const uint8_t* d_src, uint64_t len, uint32_t start_state, opusfe_shard** out, uint64_t* n_tokens, uint64_t* tail_kinds) {
@@ -350,6 +380,10 @@ int opusfe_create(opusfe_ctx** out, int device) {
         delete ctx;
         return OPUSFE_ERR_HIP;
     }
+    // the static scratch of opusfe_shard_ctx_static: every device holds its own copy of the array at its own address
+    void* sp = nullptr;
+    if (hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch)) != hipSuccess || !sp) { opusfe_destroy(ctx); return OPUSFE_ERR_HIP; }
+    ctx->d_static_scratch = (uint32_t*)sp;
     *out = ctx;
     return OPUSFE_OK;
 }

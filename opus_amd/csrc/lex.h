@@ -101,7 +101,7 @@ __global__ __launch_bounds__(LEX_THREADS) void k_ctx_chunk(const uint8_t* __rest
         } else {
             for (uint32_t i = (uint32_t)base; i < end; i++) f = ctx_compose(f, ctx_of_byte(src[i]));
         }
-        chunk_fn[chunk] = f;
+        if (chunk_fn) chunk_fn[chunk] = f;   // (null: only the tile aggregates are wanted, opusfe_shard_ctx_static)
     }
     uint32_t total;
     block_inclusive_scan(f, OpCtx(), lds, &total);
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_ctx_tiles(const uint32_t* __re
         else excl = ctx_compose(carry_s, prev);
         uint32_t run = excl;
 #pragma unroll
-        for (int i = 0; i < SCAN_ITEMS; i++) { if (b + i < ntiles) tile_state[b + i] = (uint8_t)ctx_apply(run, start_state); run = ctx_compose(run, v[i]); }
+        for (int i = 0; i < SCAN_ITEMS; i++) { if (tile_state && b + i < ntiles) tile_state[b + i] = (uint8_t)ctx_apply(run, start_state); run = ctx_compose(run, v[i]); }
         __syncthreads();
         if (threadIdx.x == 0) carry_s = ctx_compose(carry_s, total);
         __syncthreads();

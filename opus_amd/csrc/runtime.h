@@ -32,6 +32,7 @@ struct opusfe_ctx {
     std::vector<hipEvent_t> event_pool;
     uint32_t* d_status = nullptr;   // DevStatus word + scratch totals (64 words)
     uint32_t* h_status = nullptr;   // pinned mirror
+    uint32_t* d_static_scratch = nullptr;   // this device's address of api.hip `scratch` (hipGetSymbolAddress at opusfe_create)
     // opusfe_parse_batch: worker contexts (own stream and allocator each) owned by this context; units they created
     // are released before the context is destroyed
     std::vector<opusfe_ctx*> workers;

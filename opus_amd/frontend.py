@@ -64,6 +64,7 @@ def lib():
         L.opusfe_semantic_error_count.argtypes = [vp, C.POINTER(u64)]
         u32 = C.c_uint32
         L.opusfe_shard_ctx.argtypes = [vp, vp, u64, C.POINTER(u32)]
+        L.opusfe_shard_ctx_static.argtypes = [vp, vp, u64, vp]
         L.opusfe_shard_lex.argtypes = [vp, vp, u64, u32, C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]
         L.opusfe_shard_net_depth.argtypes = [vp, u64, C.POINTER(C.c_int64)]
         L.opusfe_shard_boundary.argtypes = [vp, C.c_int64, C.POINTER(u64)]
@@ -280,6 +281,12 @@ class Context:
         if rc != OK:
             raise OpusfeError(rc, self.message())
         return fn.value
+
+    def shard_ctx_static(self, d_ptr, length, d_out):
+        """opusfe_shard_ctx_static: no allocation, result written to the device word `d_out` on this context's stream"""
+        rc = lib().opusfe_shard_ctx_static(self.handle, C.c_void_p(d_ptr), length, C.c_void_p(d_out))
+        if rc != OK:
+            raise OpusfeError(rc, self.message())
 
     def shard_lex(self, d_ptr, length, start_state):
         h, n, tail = C.c_void_p(), C.c_uint64(), C.c_uint64()
