@@ -103,7 +103,9 @@ const char* opusfe_last_message(opusfe_ctx* ctx);          /* human-readable det
 void* opusfe_stream(opusfe_ctx* ctx);                      /* the hipStream_t all kernels of this ctx are launched on */
 
 /* ---- seam A: source -> tokens + AST (frontend.rs:120 get_definitions) ---- */
-/* host buffer: copied to HBM first (PCIe-inclusive path) */
+/* PRECONDITION of every entry point that takes source bytes: `src` is valid UTF-8, as the reference's &str is
+   (fs::read_to_string, frontend.rs:85, rejects anything else before the parser runs); the library does not validate it.
+   host buffer: copied to HBM first (PCIe-inclusive path) */
 int opusfe_parse(opusfe_ctx* ctx, const uint8_t* src, uint64_t len, opusfe_unit** out);
 /* source already resident in HBM on ctx's device (the timed path of bench.py) */
 int opusfe_parse_device(opusfe_ctx* ctx, const uint8_t* d_src, uint64_t len, opusfe_unit** out);

@@ -176,6 +176,9 @@ int guarded(opusfe_ctx* ctx, F&& f) {
     } catch (HipError& e) {
         ctx->pending.clear();
         return fail(ctx, e.e == hipErrorOutOfMemory ? OPUSFE_ERR_OOM : OPUSFE_ERR_HIP, std::string("HIP error: ") + hipGetErrorString(e.e) + " in " + e.what);
+    } catch (ScanLaunchError&) {
+        ctx->pending.clear();
+        return fail(ctx, OPUSFE_ERR_HIP, "HIP error: a scan kernel failed to launch");
     } catch (std::bad_alloc&) {
         return fail(ctx, OPUSFE_ERR_OOM, "host allocation failed");
     }
@@ -447,6 +450,7 @@ static uint32_t swallowed_resync_point(opusfe_ctx* ctx, opusfe_unit* u) {
     uint32_t* d_idx = ctx->d_status + 63;
     HIP_TRY(hipMemsetAsync(d_idx, 0xFF, 4, ctx->stream));
     hipLaunchKernelGGL(k_find_resync_token, dim3(grid_for(u->n_tokens, 256)), dim3(256), 0, ctx->stream, u->d_tokens, (uint32_t)u->n_tokens, pos, d_idx);
+    HIP_TRY(hipGetLastError());
     uint32_t idx = OPUSFE_NONE;
     HIP_TRY(hipMemcpyAsync(&idx, d_idx, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -776,7 +780,8 @@ int opusfe_dump(opusfe_unit* u, int what, char** out, uint64_t* out_len) {
                 s = dump_tokens(u, limit);
                 break;
             }
-            case 1: ensure_host_ast(u); s = dump_ast(u); break;
+            case 1: if (!u->parsed || u->status == OPUSFE_SYNTAX || !u->d_nodes) return (int)OPUSFE_ERR_ARG;   // no AST after a syntax error
+                    ensure_host_ast(u); s = dump_ast(u); break;
             case 2: ensure_host_ast(u); ensure_host_ir(u); s = dump_ir(u); break;
             case 4: ensure_host_ir(u); s = dump_semantic_errors(u); break;
             case 3: s = dump_error_line(u); break;

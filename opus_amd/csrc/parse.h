@@ -846,7 +846,8 @@ inline void run_parser(opusfe_ctx* ctx, opusfe_unit* u) {
     prof_collect(ctx);
     const uint32_t dev_status = ctx->h_status[0];
     const uint32_t first_err = ctx->h_status[WP_FIRST_ERR];
-    u->n_nodes = ctx->h_status[WP_TOTALS]; u->n_defs = ctx->h_status[WP_TOTALS + 1];
+    if (first_err != 0xFFFFFFFFu || dev_status != DS_OK) u->n_nodes = u->n_defs = 0;   // no AST: the counts must not promise arrays that do not exist
+    else { u->n_nodes = ctx->h_status[WP_TOTALS]; u->n_defs = ctx->h_status[WP_TOTALS + 1]; }
     if (first_err != 0xFFFFFFFFu) {
         // first syntax error of the file = error of the lowest failing segment
         uint32_t si[SI_WORDS];

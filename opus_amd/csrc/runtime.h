@@ -114,6 +114,7 @@ inline void prof_collect(opusfe_ctx* ctx) {
 #define LAUNCH(ctx, name, kernel, grid, block, ...) do { \
         opusfe::prof_begin(ctx, name); \
         hipLaunchKernelGGL(kernel, dim3((unsigned)(grid)), dim3((unsigned)(block)), 0, (ctx)->stream, __VA_ARGS__); \
+        HIP_TRY(hipGetLastError());   /* a launch that fails (LDS / register limits of a variant build) must not pass as OK */ \
         opusfe::prof_end(ctx); \
     } while (0)
 

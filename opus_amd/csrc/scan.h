@@ -130,6 +130,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const T* __restrict
 }
 
 #ifndef OPUSFE_EMU
+struct ScanLaunchError {};
 // Scans n elements of `in` into `out` (may alias).  `tmp` must hold ceil(n / SCAN_TILE) T's.
 // `total` (device pointer, may be null) receives the reduction of all elements.
 template <bool EXCL, class T, class Op>
@@ -139,6 +140,7 @@ void device_scan(const T* in, T* out, uint64_t n, Op op, T identity, T* tmp, T* 
     hipLaunchKernelGGL((k_scan_reduce<T, Op>), dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, stream, in, tmp, n, op, identity);
     hipLaunchKernelGGL((k_scan_aggregates<T, Op>), dim3(1), dim3(SCAN_THREADS), 0, stream, tmp, tiles, op, identity, total);
     hipLaunchKernelGGL((k_scan_apply<EXCL, T, Op>), dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, stream, in, out, tmp, n, op, identity);
+    if (hipGetLastError() != hipSuccess) throw ScanLaunchError{};
 }
 
 #endif  // OPUSFE_EMU

@@ -404,18 +404,36 @@ __global__ void k_sem_table_fill(const opusfe_node* __restrict__ nodes, const ui
     entries[pos] = NameEntry{def_nodes[d], (kind << 30) | index};
 }
 
-// one lane per slot: writes the offset and orders the slot's entries by definition (insertion sort; groups are tiny)
+// one lane per slot: writes the offset and orders the slot's entries by definition.  Groups are tiny (insertion sort up to
+// 16 entries); a name with very many definitions (1e5 overloads of one operator, generated code that reuses one name) is
+// ordered by an in-place heapsort, O(k log k) on the one lane instead of O(k^2).
 __global__ void k_sem_table_sort(NameSlot* __restrict__ slots, uint32_t n_slots, const uint32_t* __restrict__ slot_off, NameEntry* __restrict__ entries) {
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_slots) return;
     uint32_t off = slot_off[s], n = slots[s].count;
     slots[s].offset = off;
-    for (uint32_t i = 1; i < n; i++) {
-        NameEntry e = entries[off + i];
-        uint32_t j = i;
-        while (j > 0 && entries[off + j - 1].def_node > e.def_node) { entries[off + j] = entries[off + j - 1]; j--; }
-        entries[off + j] = e;
+    NameEntry* e = entries + off;
+    if (n <= 16) {
+        for (uint32_t i = 1; i < n; i++) {
+            NameEntry x = e[i];
+            uint32_t j = i;
+            while (j > 0 && e[j - 1].def_node > x.def_node) { e[j] = e[j - 1]; j--; }
+            e[j] = x;
+        }
+        return;
     }
+    auto sift = [&](uint32_t root, uint32_t end) {      // max-heap on def_node over e[0, end)
+        for (;;) {
+            uint32_t c = 2 * root + 1;
+            if (c >= end) return;
+            if (c + 1 < end && e[c + 1].def_node > e[c].def_node) c++;
+            if (e[root].def_node >= e[c].def_node) return;
+            NameEntry t = e[root]; e[root] = e[c]; e[c] = t;
+            root = c;
+        }
+    };
+    for (uint32_t i = n / 2; i > 0; i--) sift(i - 1, n);
+    for (uint32_t end = n; end > 1; end--) { NameEntry t = e[0]; e[0] = e[end - 1]; e[end - 1] = t; sift(0, end - 1); }
 }
 
 __global__ void k_sem_slots_init(NameSlot* __restrict__ slots, uint32_t n_slots) {

@@ -116,6 +116,10 @@ def load_program(ctx, root, read=None):
             src = read(path)
         except OSError:
             raise ProgramError(f"error: could not open file {path!r}", path)          # frontend.rs:86-90
+        try:
+            src.decode("utf-8")      # fs::read_to_string (frontend.rs:85) fails on invalid UTF-8: same message, same exit
+        except UnicodeDecodeError:
+            raise ProgramError(f"error: could not open file {path!r}", path)
         unit = ctx.get_definitions(src)
         if unit.status != F.OK:                                                          # frontend.rs:130-133 (or UNSUPPORTED)
             raise ProgramError(f"{path}: {F._NAMES[unit.status]}", path, unit)

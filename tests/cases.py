@@ -126,6 +126,21 @@ def big_function(n_locals=150, n_ifs=140, chain=90, depth=70):
     return "\n".join(L) + "\n"
 
 
+def many_overloads(n=40):
+    """one operator symbol and one function name with n definitions each: the name-table slot is ordered by the heapsort path
+    of k_sem_table_sort (> 16 entries) and lookup_function walks all of them in definition order (compile.rs:1083-1139)"""
+    L = []
+    for i in range(n):
+        L.append(f"type R{i} = record {{ a{i} int32 }}")
+    for i in reversed(range(n)):
+        L.append(f"operator +(x R{i}, y R{i}) R{i}\n\treturn x")
+        L.append(f"pick(x R{i}) int32\n\treturn {i}")
+    L.append(f"f(p R7, q R7, r R{n - 1}) int32\n\tvar s = p + q\n\tvar t = r + r\n\treturn pick(s) + pick(t) + pick(r)")
+    return "\n".join(L) + "\n"
+
+
+IR_CASES.append(many_overloads())
+
 # finalize_definition errors (compile.rs:1002-1065): reported in definition order, no IR is generated (frontend.rs:145)
 FINALIZE_ERROR_CASES = [
     "f(a nosuch, b int32, c other) missing\n\treturn 1\n",

@@ -95,3 +95,14 @@ def test_unreadable_file_and_syntax_error_end_the_run():
     with pytest.raises(P.ProgramError) as e:
         P.load_program(FakeCtx(bad=[FILES["r/c.opus"]]), "r/main.opus", read=read)
     assert os.path.normpath(e.value.filename) == "r/c.opus" and e.value.unit.status == 1
+
+
+def test_file_that_is_not_utf8_ends_the_run_like_an_unreadable_one():
+    """fs::read_to_string (frontend.rs:85-90) fails on invalid UTF-8: the file must never reach the lexer"""
+    files = dict(FILES)
+    files["r/lib/d.opus"] = b"h() null\n\tvar s = \"\xff\"\n"
+    ctx = FakeCtx()
+    with pytest.raises(P.ProgramError) as e:
+        P.load_program(ctx, "r/main.opus", read=lambda p: files[os.path.normpath(p)])
+    assert "could not open file" in str(e.value) and os.path.normpath(e.value.filename) == "r/lib/d.opus"
+    assert files["r/lib/d.opus"] not in ctx.parsed
