@@ -32,6 +32,8 @@ __host__ __device__ __forceinline__ uint64_t lower_cap(uint32_t mult, uint32_t n
 // per-function result header (sparse counts; dense bases are filled after the scans)
 struct FuncIr { uint32_t def_node, func, n_vars, n_instrs, n_bbs, n_types, n_cargs, n_errs, var_base, instr_base, bb_base, type_base, carg_base, err_base, status, pad; };
 struct IrCnt { uint32_t vars, instrs, bbs, types, cargs, errs; };
+struct FbIdx { uint32_t nodes, funcs; };   // exclusive (nodes, functions) of the functions lowered by the sequential machine
+struct OpAddFbIdx { __host__ __device__ FbIdx operator()(FbIdx a, FbIdx b) const { return FbIdx{a.nodes + b.nodes, a.funcs + b.funcs}; } };
 struct OpAddIrCnt { __host__ __device__ IrCnt operator()(IrCnt a, IrCnt b) const { return IrCnt{a.vars + b.vars, a.instrs + b.instrs, a.bbs + b.bbs, a.types + b.types, a.cargs + b.cargs, a.errs + b.errs}; } };
 
 struct LowerBuffers {
@@ -1330,7 +1332,8 @@ __global__ void k_sem_user_syms(SemView S, uint64_t* __restrict__ out) {
 // one lane per function definition
 __global__ MACHINE_ATTR(OPUSFE_LOWER_WAVES) __launch_bounds__(64) void k_lower_functions(SemView S, LowerBuffers B, const uint8_t* __restrict__ undefined_flag, const uint32_t* __restrict__ def_nodes,
                                                          uint32_t n_defs, uint32_t n_nodes, uint32_t n_tokens, const DefCnt* __restrict__ def_excl, FuncIr* __restrict__ out,
-                                                         uint32_t* __restrict__ status, uint64_t* __restrict__ prof_out, const uint64_t* __restrict__ user_syms, const uint32_t* __restrict__ order) {
+                                                         uint32_t* __restrict__ status, uint64_t* __restrict__ prof_out, const uint64_t* __restrict__ user_syms, const uint32_t* __restrict__ order,
+                                                         const uint32_t* __restrict__ fb_flag, const FbIdx* __restrict__ fbx) {
     const uint32_t slot = blockIdx.x * (blockDim.x / UNIT_LANES) + threadIdx.x / UNIT_LANES;
     const uint32_t lane = threadIdx.x % UNIT_LANES;
     if (slot >= n_defs) return;
@@ -1338,25 +1341,27 @@ __global__ MACHINE_ATTR(OPUSFE_LOWER_WAVES) __launch_bounds__(64) void k_lower_f
     const uint32_t dn = def_nodes[d];
     if (S.nodes[dn].kind != D_Function) return;
     const uint32_t fidx = def_excl[d].funcs;
-    // functions-with-bodies index == position in `out`: computed by the host from a second scan; here we use fidx and
-    // externs simply leave their slot empty (n_instrs == 0, func == NONE)
+    // only the functions that the node-parallel path (lower_par.h) declined come here; their sparse regions are laid out by
+    // (nodes, functions) of the declined functions before them
+    if (!fb_flag[fidx]) return;
+    const uint32_t sb_n = fbx[fidx].nodes, sb_f = fbx[fidx].funcs;
     const uint32_t dn_end = d + 1 < n_defs ? def_nodes[d + 1] : n_nodes;
     const uint32_t nn = dn_end - dn;
     Lowerer L;      // no fields of its own: the state is the static LDS block above
     L.user_syms = *user_syms;
     L.S = S; L.fidx = fidx; L.F = S.funcs[fidx]; L.undefined_flag = undefined_flag;
-    L.vars = B.vars + lower_base(CAP_VARS, dn, fidx); L.nvars = 0; L.vcap = (uint32_t)lower_cap(CAP_VARS, nn);
-    uint64_t ib = lower_base(CAP_INSTRS, dn, fidx);
+    L.vars = B.vars + lower_base(CAP_VARS, sb_n, sb_f); L.nvars = 0; L.vcap = (uint32_t)lower_cap(CAP_VARS, nn);
+    uint64_t ib = lower_base(CAP_INSTRS, sb_n, sb_f);
     L.instrs = B.instrs + ib; L.ibb = B.ibb + ib; L.irank = B.irank + ib; L.ninstrs = 0; L.iflushed = 0; L.icap = (uint32_t)lower_cap(CAP_INSTRS, nn);
-    uint64_t bbb = lower_base(CAP_BBS, dn, fidx);
+    uint64_t bbb = lower_base(CAP_BBS, sb_n, sb_f);
     L.bbcnt = B.bbcnt + bbb; L.bblast = B.bblast + bbb; L.nbbs = 0; L.bcap = (uint32_t)lower_cap(CAP_BBS, nn);
-    L.tbase = B.type_sparse_base + (uint32_t)lower_base(CAP_TYPES, dn, fidx); L.ntypes = 0; L.tcap = (uint32_t)lower_cap(CAP_TYPES, nn);
-    L.cargs = B.cargs + lower_base(CAP_CARGS, dn, fidx); L.ncargs = 0; L.ccap = (uint32_t)lower_cap(CAP_CARGS, nn);
-    uint64_t lb = lower_base(CAP_LOCALS, dn, fidx);
+    L.tbase = B.type_sparse_base + (uint32_t)lower_base(CAP_TYPES, sb_n, sb_f); L.ntypes = 0; L.tcap = (uint32_t)lower_cap(CAP_TYPES, nn);
+    L.cargs = B.cargs + lower_base(CAP_CARGS, sb_n, sb_f); L.ncargs = 0; L.ccap = (uint32_t)lower_cap(CAP_CARGS, nn);
+    uint64_t lb = lower_base(CAP_LOCALS, sb_n, sb_f);
     L.lname = B.lname + lb; L.lvar = B.lvar + lb; L.nlocals = 0; L.lcap = (uint32_t)lower_cap(CAP_LOCALS, nn);
     L.lstack = B.lstack + lb; L.nstack = 0;
-    L.frames = B.frames + lower_base(CAP_FRAMES, dn, fidx); L.sp = 0; L.fcap = (uint32_t)lower_cap(CAP_FRAMES, nn);
-    L.errs = B.errs + lower_base(CAP_ERRS, dn, fidx); L.nerrs = 0; L.ecap = (uint32_t)lower_cap(CAP_ERRS, nn);
+    L.frames = B.frames + lower_base(CAP_FRAMES, sb_n, sb_f); L.sp = 0; L.fcap = (uint32_t)lower_cap(CAP_FRAMES, nn);
+    L.errs = B.errs + lower_base(CAP_ERRS, sb_n, sb_f); L.nerrs = 0; L.ecap = (uint32_t)lower_cap(CAP_ERRS, nn);
     L.bb_index = 0; L.break_head = OPUSFE_NONE; L.loop_begin = OPUSFE_NONE; L.dev_status = DS_OK;
     L.rv = 0; L.rl = false; L.rdiv = false; L.sym_locals = false;
     for (uint32_t j = lane; j < (LDS_VARS + 31) / 32; j += UNIT_LANES) L.lds.vnamed[j] = 0;
@@ -1391,45 +1396,47 @@ __global__ void k_ir_counts(const FuncIr* __restrict__ f, uint32_t n, IrCnt* __r
 }
 
 // per function: dense bases + exclusive scan of its bb sizes into bb_offsets (global instruction indices)
-__global__ void k_ir_bb_offsets(FuncIr* __restrict__ f, uint32_t n, const IrCnt* __restrict__ base, LowerBuffers B, uint32_t* __restrict__ bb_offsets, IrCnt totals_hint) {
+__global__ void k_ir_bb_offsets(FuncIr* __restrict__ f, uint32_t n, const IrCnt* __restrict__ base, LowerBuffers B, uint32_t* __restrict__ bb_offsets, IrCnt totals_hint,
+                                const uint32_t* __restrict__ fb_flag, const FbIdx* __restrict__ fbx) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     FuncIr r = f[i];
     r.var_base = base[i].vars; r.instr_base = base[i].instrs; r.bb_base = base[i].bbs; r.type_base = base[i].types; r.carg_base = base[i].cargs; r.err_base = base[i].errs;
     f[i] = r;
-    if (r.n_bbs == 0) return;
-    const uint32_t* cnt = B.bbcnt + lower_base(CAP_BBS, r.def_node, r.func);
+    if (r.n_bbs == 0 || !fb_flag[i]) return;             // the node-parallel path writes its own block offsets
+    const uint32_t* cnt = B.bbcnt + lower_base(CAP_BBS, fbx[i].nodes, fbx[i].funcs);
     uint32_t run = r.instr_base;
     for (uint32_t b = 0; b < r.n_bbs; b++) { bb_offsets[r.bb_base + b] = run; run += cnt[b]; }
-    if (i + 1 == n) bb_offsets[r.bb_base + r.n_bbs] = run;   // sentinel after the last function (filled again below for safety)
     (void)totals_hint;
 }
 
 struct IrOut { opusfe_variable* vars; opusfe_instr* instrs; uint32_t* cargs; TypeRec* types; SemErr* errs; const uint32_t* bb_offsets; uint32_t n_gtypes; };
 
 // one wave per function (grid-stride)
-__global__ __launch_bounds__(256) void k_ir_compact(const FuncIr* __restrict__ f, uint32_t n, LowerBuffers B, const TypeRec* __restrict__ sparse_types, IrOut O) {
+__global__ __launch_bounds__(256) void k_ir_compact(const FuncIr* __restrict__ f, uint32_t n, LowerBuffers B, const TypeRec* __restrict__ sparse_types, IrOut O,
+                                                    const uint32_t* __restrict__ fb_flag, const FbIdx* __restrict__ fbx) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     for (uint32_t i = wave; i < n; i += nwaves) {
         const FuncIr r = f[i];
-        if (r.n_bbs == 0) continue;
-        const uint32_t tsb = B.type_sparse_base + (uint32_t)lower_base(CAP_TYPES, r.def_node, r.func);   // first sparse local type id
+        if (r.n_bbs == 0 || !fb_flag[i]) continue;
+        const uint32_t sb_n = fbx[i].nodes, sb_f = fbx[i].funcs;
+        const uint32_t tsb = B.type_sparse_base + (uint32_t)lower_base(CAP_TYPES, sb_n, sb_f);   // first sparse local type id
         const uint32_t tdb = O.n_gtypes + r.type_base;                                                   // first dense local type id
         #define REMAP_TYPE(x) ((x) < O.n_gtypes ? (x) : (x) - tsb + tdb)
-        const opusfe_variable* sv = B.vars + lower_base(CAP_VARS, r.def_node, r.func);
+        const opusfe_variable* sv = B.vars + lower_base(CAP_VARS, sb_n, sb_f);
         for (uint32_t j = lane; j < r.n_vars; j += 64) { opusfe_variable v = sv[j]; v.type_id = REMAP_TYPE(v.type_id); O.vars[r.var_base + j] = v; }
         for (uint32_t j = lane; j < r.n_types; j += 64) {
             TypeRec t = sparse_types[tsb + j];
             if (t.kind == TY_Pointer || t.kind == TY_Array || t.kind == TY_Function) t.sub = REMAP_TYPE(t.sub);
             O.types[tdb + j] = t;
         }
-        const uint32_t* sc = B.cargs + lower_base(CAP_CARGS, r.def_node, r.func);
+        const uint32_t* sc = B.cargs + lower_base(CAP_CARGS, sb_n, sb_f);
         for (uint32_t j = lane; j < r.n_cargs; j += 64) O.cargs[r.carg_base + j] = sc[j];
-        const SemErr* se = B.errs + lower_base(CAP_ERRS, r.def_node, r.func);
+        const SemErr* se = B.errs + lower_base(CAP_ERRS, sb_n, sb_f);
         for (uint32_t j = lane; j < r.n_errs; j += 64) O.errs[r.err_base + j] = se[j];
-        const uint64_t ib = lower_base(CAP_INSTRS, r.def_node, r.func);
+        const uint64_t ib = lower_base(CAP_INSTRS, sb_n, sb_f);
         for (uint32_t j = lane; j < r.n_instrs; j += 64) {
             opusfe_instr in = B.instrs[ib + j];
             if (in.opcode == I_Sizeof || in.opcode == I_Alignof) in.c = REMAP_TYPE(in.c);
@@ -1441,6 +1448,25 @@ __global__ __launch_bounds__(256) void k_ir_compact(const FuncIr* __restrict__ f
 }
 
 
+}  // namespace opusfe
+#include "lower_par.h"
+namespace opusfe {
+
+// which functions the node-parallel path declined, and how much sparse space the sequential machine needs for them
+__global__ void k_fb_mark(const FuncIr* __restrict__ f, uint32_t n_funcs, const uint32_t* __restrict__ def_nodes, uint32_t n_defs, uint32_t n_nodes, const DefCnt* __restrict__ def_excl,
+                          const opusfe_node* __restrict__ nodes, uint32_t* __restrict__ fb_flag, FbIdx* __restrict__ fbx) {
+    const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= n_defs) return;
+    const uint32_t dn = def_nodes[d];
+    const uint8_t k = nodes[dn].kind;
+    if (k != D_Function && k != D_Extern) return;
+    const uint32_t fidx = def_excl[d].funcs;
+    const bool fb = k == D_Function && f[fidx].status == par::DS_FALLBACK;
+    const uint32_t nn = (d + 1 < n_defs ? def_nodes[d + 1] : n_nodes) - dn;
+    fb_flag[fidx] = fb ? 1u : 0u;
+    fbx[fidx] = FbIdx{fb ? nn : 0u, fb ? 1u : 0u};
+}
+
 // ---- results ------------------------------------------------------------------------------------
 // Dense IR of one unit (device resident; host mirrors are filled lazily for the text dump).
 struct IrResult {
@@ -1449,6 +1475,7 @@ struct IrResult {
     uint32_t* d_cargs = nullptr; TypeRec* d_types = nullptr; SemErr* d_errs = nullptr; FuncRec* d_funcrecs = nullptr; GlobalRec* d_globals = nullptr;
     uint32_t* d_tid_of_node = nullptr;
     uint64_t n_funcs = 0, n_globals = 0, n_vars = 0, n_instrs = 0, n_bbs = 0, n_types = 0, n_gtypes = 0, n_cargs = 0, n_errs = 0, n_sem_errors = 0;
+    uint64_t n_fallback = 0;   // functions (with bodies) that the sequential machine lowered; the node-parallel path did the rest
     // host mirrors
     bool have_host = false;
     std::vector<FuncIr> funcs; std::vector<opusfe_variable> vars; std::vector<opusfe_instr> instrs; std::vector<uint32_t> bb_offsets, cargs, tid_of_node;
@@ -1465,7 +1492,7 @@ inline void free_ir(opusfe_ctx* ctx, opusfe_unit* u) {
     u->ir = nullptr;
 }
 
-enum { WL_STATUS = 32, WL_ERRS = 33, WL_DEFTOT = 36 /* DefCnt: 4 */, WL_GT = 40, WL_FINERR = 41, WL_IRTOT = 44 /* IrCnt: 6 */, WL_SLOTTOT = 50 };
+enum { WL_STATUS = 32, WL_ERRS = 33, WL_FBTOT = 34 /* FbIdx: 2 */, WL_DEFTOT = 36 /* DefCnt: 4 */, WL_GT = 40, WL_FINERR = 41, WL_IRTOT = 44 /* IrCnt: 6 */, WL_SLOTTOT = 50 };
 
 inline uint32_t next_pow2(uint64_t v) { uint32_t p = 16; while (p < v) p <<= 1; return p; }
 
@@ -1499,7 +1526,9 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
     HIP_TRY(hipStreamSynchronize(st));
     prof_collect(ctx);
     const uint32_t n_funcs = ctx->h_status[WL_DEFTOT], n_globals = ctx->h_status[WL_DEFTOT + 1], n_named = ctx->h_status[WL_DEFTOT + 3];
-    const uint32_t n_gtypes = TP_COUNT + ctx->h_status[WL_GT];
+    // global type ids: primitives, one per structured parse-tree type / `type` definition, then the pointer-to-primitive table
+    const uint32_t n_gt0 = TP_COUNT + ctx->h_status[WL_GT];
+    const uint32_t pp_base = n_gt0, n_gtypes = n_gt0 + par::PP_COUNT;
 
     // B. name table
     const uint32_t n_slots = next_pow2(2ull * n_named + 16);
@@ -1517,37 +1546,29 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
     LAUNCH(ctx, "sem_table_fill", k_sem_table_fill, grid_for(n_defs, 256), 256, u->d_nodes, u->d_def_nodes, n_defs, def_excl, def_slot, slot_off, slots, entries);
     LAUNCH(ctx, "sem_table_sort", k_sem_table_sort, grid_for(n_slots, 256), 256, slots, n_slots, slot_off, entries);
 
-    // C2. resolve every parse-tree type node; D. finalize
-    const uint64_t type_cap = (uint64_t)n_gtypes + (uint64_t)CAP_TYPES * n_nodes + (uint64_t)CAP_CONST * n_funcs + CAP_CONST;
-    if (type_cap >= 0xFFFFFFF0ull) { u->status = OPUSFE_ERR_ARG; ctx->msg = "unit too large for 32-bit type ids: shard it"; return; }
-    TypeRec* types = tmp.get<TypeRec>(type_cap);
+    // C2. resolve every parse-tree type node; D. finalize.  The global type records go straight into the result array when the
+    // unit lowers without sequential-machine functions; the machine's sparse type regions need one contiguous id space with them
+    TypeRec* gtypes = tmp.get<TypeRec>(n_gtypes);
     R->d_tid_of_node = dev_alloc_t<uint32_t>(ctx, n_nodes);
     uint8_t* undefined_flag = tmp.get<uint8_t>(n_nodes);
-    uint32_t* ph_def = tmp.get<uint32_t>(n_gtypes);
-    uint32_t* ph_prev = tmp.get<uint32_t>(n_gtypes);     // `type` definition -> the previous one of the same name (duplicates)
+    uint32_t* ph_def = tmp.get<uint32_t>(n_gt0);
+    uint32_t* ph_prev = tmp.get<uint32_t>(n_gt0);     // `type` definition -> the previous one of the same name (duplicates)
     R->d_funcrecs = dev_alloc_t<FuncRec>(ctx, n_funcs);
     R->d_globals = dev_alloc_t<GlobalRec>(ctx, n_globals);
     LAUNCH(ctx, "sem_resolve_types", k_sem_resolve_types, grid_for(std::max<uint32_t>(n_nodes, TP_COUNT), 256), 256, u->d_src, u->d_tokens, u->d_nodes, n_nodes,
-           slot_of_node, slots, n_slots - 1, entries, R->d_tid_of_node, types, undefined_flag, ph_def, ph_prev);
+           slot_of_node, slots, n_slots - 1, entries, R->d_tid_of_node, gtypes, undefined_flag, ph_def, ph_prev);
+    LAUNCH(ctx, "sem_pp_types", k_sem_pp_types, 1, 128, gtypes + pp_base);
     LAUNCH(ctx, "sem_finalize", k_sem_finalize, grid_for(n_defs, 256), 256, u->d_nodes, u->d_def_nodes, n_defs, def_excl, R->d_tid_of_node, undefined_flag,
-           ph_def, ph_prev, n_nodes, types, R->d_funcrecs, R->d_globals, ctx->d_status + WL_FINERR);
-
-    // E. lowering into sparse per-function regions
-    LowerBuffers B{};
-    B.vars = tmp.get<opusfe_variable>(lower_base(CAP_VARS, n_nodes, n_funcs) + CAP_CONST);
-    const uint64_t icap = lower_base(CAP_INSTRS, n_nodes, n_funcs) + CAP_CONST;
-    B.instrs = tmp.get<opusfe_instr>(icap); B.ibb = tmp.get<uint32_t>(icap); B.irank = tmp.get<uint32_t>(icap);
-    const uint64_t bcap = lower_base(CAP_BBS, n_nodes, n_funcs) + CAP_CONST;
-    B.bbcnt = tmp.get<uint32_t>(bcap); B.bblast = tmp.get<uint32_t>(bcap);
-    B.cargs = tmp.get<uint32_t>(lower_base(CAP_CARGS, n_nodes, n_funcs) + CAP_CONST);
-    const uint64_t lcap = lower_base(CAP_LOCALS, n_nodes, n_funcs) + CAP_CONST;
-    B.lname = tmp.get<uint32_t>(lcap); B.lvar = tmp.get<uint32_t>(lcap); B.lstack = tmp.get<uint32_t>(lcap);
-    B.frames = tmp.get<LFrame>(lower_base(CAP_FRAMES, n_nodes, n_funcs) + CAP_CONST);
-    B.errs = tmp.get<SemErr>(lower_base(CAP_ERRS, n_nodes, n_funcs) + CAP_CONST);
-    B.type_sparse_base = n_gtypes;
-    SemView S{u->d_src, u->d_tokens, u->d_val64, u->d_nodes, R->d_tid_of_node, types, slots, n_slots - 1, entries, R->d_funcrecs, R->d_globals, n_gtypes};
-    R->d_funcs = dev_alloc_t<FuncIr>(ctx, n_funcs);
-    HIP_TRY(hipMemsetAsync(R->d_funcs, 0, (size_t)n_funcs * sizeof(FuncIr), st));
+           ph_def, ph_prev, n_nodes, gtypes, R->d_funcrecs, R->d_globals, ctx->d_status + WL_FINERR);
+    // size classes of the definitions (largest first): which workgroup shape lowers a function, and the dispatch order of the machine
+    uint32_t* order = tmp.get<uint32_t>(n_defs);
+    uint32_t* order_hist = tmp.get<uint32_t>(33);
+    HIP_TRY(hipMemsetAsync(order_hist, 0, 33 * sizeof(uint32_t), st));
+    LAUNCH(ctx, "order_hist", k_order_hist, grid_for(n_defs, 256), 256, u->d_def_nodes, n_defs, n_nodes, order_hist);
+    LAUNCH(ctx, "order_scan", k_order_scan, 1, 64, order_hist);
+    LAUNCH(ctx, "order_scatter", k_order_scatter, grid_for(n_defs, 256), 256, u->d_def_nodes, n_defs, n_nodes, order_hist, order);
+    uint32_t class_end[33];
+    HIP_TRY(hipMemcpyAsync(class_end, order_hist, sizeof class_end, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(ctx->h_status, ctx->d_status, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     prof_collect(ctx);
@@ -1556,13 +1577,13 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
         R->n_sem_errors = ctx->h_status[WL_FINERR];
         // the diagnostics themselves, in the reference's report order (definitions in file order)
         uint32_t* fin_cnt = tmp.get<uint32_t>(n_defs);
-        LAUNCH(ctx, "sem_fin_count", k_sem_fin_count, grid_for(n_defs, 256), 256, u->d_nodes, u->d_def_nodes, n_defs, R->d_tid_of_node, undefined_flag, ph_def, ph_prev, n_nodes, types, fin_cnt);
+        LAUNCH(ctx, "sem_fin_count", k_sem_fin_count, grid_for(n_defs, 256), 256, u->d_nodes, u->d_def_nodes, n_defs, R->d_tid_of_node, undefined_flag, ph_def, ph_prev, n_nodes, gtypes, fin_cnt);
         prof_begin(ctx, "sem_fin_scan");
         device_scan<true>(fin_cnt, fin_cnt, n_defs, OpAddU32(), (uint32_t)0, scan_tmp, (uint32_t*)nullptr, st);
         prof_end(ctx);
         R->n_errs = R->n_sem_errors;
         R->d_errs = dev_alloc_t<SemErr>(ctx, R->n_errs);
-        LAUNCH(ctx, "sem_fin_emit", k_sem_fin_emit, grid_for(n_defs, 256), 256, u->d_nodes, u->d_def_nodes, n_defs, R->d_tid_of_node, undefined_flag, ph_def, ph_prev, n_nodes, types, fin_cnt, R->d_errs);
+        LAUNCH(ctx, "sem_fin_emit", k_sem_fin_emit, grid_for(n_defs, 256), 256, u->d_nodes, u->d_def_nodes, n_defs, R->d_tid_of_node, undefined_flag, ph_def, ph_prev, n_nodes, gtypes, fin_cnt, R->d_errs);
         HIP_TRY(hipStreamSynchronize(st));
         prof_collect(ctx);
         u->status = OPUSFE_SEMANTIC;
@@ -1570,32 +1591,98 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
         return;
     }
     if (n_funcs == 0) { u->status = OPUSFE_OK; R->have_host = true; return; }
+
+    // E1. node-parallel count pass (lower_par.h): every function it can lower gets its exact result sizes
+    SemView S{u->d_src, u->d_tokens, u->d_val64, u->d_nodes, R->d_tid_of_node, gtypes, slots, n_slots - 1, entries, R->d_funcrecs, R->d_globals, n_gtypes};
+    R->d_funcs = dev_alloc_t<FuncIr>(ctx, n_funcs);
+    HIP_TRY(hipMemsetAsync(R->d_funcs, 0, (size_t)n_funcs * sizeof(FuncIr), st));
     uint64_t* user_syms = tmp.get<uint64_t>(1);
     LAUNCH(ctx, "sem_user_syms", k_sem_user_syms, 1, 64, S, user_syms);
-    uint64_t* prof_buf = tmp.get<uint64_t>(LP_COUNT);
-    HIP_TRY(hipMemsetAsync(prof_buf, 0, LP_COUNT * 8, st));
-    uint32_t* order = tmp.get<uint32_t>(n_defs);
-    uint32_t* order_hist = tmp.get<uint32_t>(33);
-    HIP_TRY(hipMemsetAsync(order_hist, 0, 33 * sizeof(uint32_t), st));
-    LAUNCH(ctx, "order_hist", k_order_hist, grid_for(n_defs, 256), 256, u->d_def_nodes, n_defs, n_nodes, order_hist);
-    LAUNCH(ctx, "order_scan", k_order_scan, 1, 64, order_hist);
-    LAUNCH(ctx, "order_scatter", k_order_scatter, grid_for(n_defs, 256), 256, u->d_def_nodes, n_defs, n_nodes, order_hist, order);
-    LAUNCH(ctx, "lower_functions", k_lower_functions, grid_for((uint64_t)n_defs * UNIT_LANES, 64), 64, S, B, undefined_flag, u->d_def_nodes, n_defs, n_nodes, (uint32_t)u->n_tokens, def_excl, R->d_funcs,
-           ctx->d_status + WL_STATUS, prof_buf, user_syms, (const uint32_t*)order);
+    LAUNCH(ctx, "par_init", par::k_par_init, grid_for(n_defs, 256), 256, u->d_nodes, u->d_def_nodes, n_defs, def_excl, R->d_funcs);
+    par::ParArgs PA{};
+    PA.def_nodes = u->d_def_nodes; PA.n_defs = n_defs; PA.n_nodes = n_nodes; PA.def_excl = def_excl; PA.undefined_flag = undefined_flag; PA.user_syms = user_syms;
+    PA.pp_base = pp_base; PA.out = R->d_funcs; PA.status = ctx->d_status + WL_STATUS;
+    // class c = definitions whose node count has bit length c; order[] holds them largest class first, class c ends at class_end[c]
+    const uint32_t s_lo = class_end[9], s_hi = n_defs, m_lo = class_end[11], m_hi = class_end[9], l_lo = class_end[12], l_hi = class_end[11];
+    static const bool seq_only = getenv("OPUSFE_LOWER_SEQ") != nullptr;     // debugging aid: everything through the sequential machine
+    auto launch_par = [&](bool emit) {
+        struct Shape { uint32_t lo, hi, nmax, maxdef, threads; const char* name; };
+        const Shape shapes[3] = {{l_lo, l_hi, 2048, 256, 512, emit ? "lower_par_emit_L" : "lower_par_count_L"},
+                                 {m_lo, m_hi, 1024, 128, 256, emit ? "lower_par_emit_M" : "lower_par_count_M"},
+                                 {s_lo, s_hi, 256, 64, 64, emit ? "lower_par_emit_S" : "lower_par_count_S"}};
+        for (const Shape& sh : shapes) {
+            if (sh.hi <= sh.lo || seq_only) continue;
+            par::ParArgs a = PA;
+            a.list = order + sh.lo; a.n_list = sh.hi - sh.lo; a.nmax = sh.nmax; a.maxdef = sh.maxdef;
+            const size_t lds = par::lds_bytes(sh.nmax, sh.maxdef, sh.threads);
+            prof_begin(ctx, sh.name);
+            if (sh.threads == 512) {
+                if (emit) { HIP_TRY(hipFuncSetAttribute((const void*)par::k_lower_par<512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); hipLaunchKernelGGL((par::k_lower_par<512, true>), dim3(a.n_list), dim3(512), lds, st, S, a); }
+                else { HIP_TRY(hipFuncSetAttribute((const void*)par::k_lower_par<512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); hipLaunchKernelGGL((par::k_lower_par<512, false>), dim3(a.n_list), dim3(512), lds, st, S, a); }
+            } else if (sh.threads == 256) {
+                if (emit) { HIP_TRY(hipFuncSetAttribute((const void*)par::k_lower_par<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); hipLaunchKernelGGL((par::k_lower_par<256, true>), dim3(a.n_list), dim3(256), lds, st, S, a); }
+                else { HIP_TRY(hipFuncSetAttribute((const void*)par::k_lower_par<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); hipLaunchKernelGGL((par::k_lower_par<256, false>), dim3(a.n_list), dim3(256), lds, st, S, a); }
+            } else {
+                if (emit) hipLaunchKernelGGL((par::k_lower_par<64, true>), dim3(a.n_list), dim3(64), lds, st, S, a);
+                else hipLaunchKernelGGL((par::k_lower_par<64, false>), dim3(a.n_list), dim3(64), lds, st, S, a);
+            }
+            HIP_TRY(hipGetLastError());
+            prof_end(ctx);
+        }
+    };
+    launch_par(false);
+
+    // E2. the functions it declined go through the sequential machine, into sparse regions sized for them alone
+    uint32_t* fb_flag = tmp.get<uint32_t>(n_funcs);
+    FbIdx* fbx = tmp.get<FbIdx>(n_funcs);
+    LAUNCH(ctx, "fb_mark", k_fb_mark, grid_for(n_defs, 256), 256, R->d_funcs, n_funcs, u->d_def_nodes, n_defs, n_nodes, def_excl, u->d_nodes, fb_flag, fbx);
+    prof_begin(ctx, "fb_scan");
+    device_scan<true>(fbx, fbx, n_funcs, OpAddFbIdx(), FbIdx{0, 0}, (FbIdx*)scan_tmp, (FbIdx*)(ctx->d_status + WL_FBTOT), st);
+    prof_end(ctx);
+    HIP_TRY(hipMemcpyAsync(ctx->h_status, ctx->d_status, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    prof_collect(ctx);
+    const uint32_t fb_nodes = ctx->h_status[WL_FBTOT], fb_funcs = ctx->h_status[WL_FBTOT + 1];
+    R->n_fallback = fb_funcs;
+    LowerBuffers B{};
+    B.type_sparse_base = n_gtypes;
+    TypeRec* types = gtypes;                 // global records, followed by the machine's sparse per-function regions when there are any
+    if (fb_funcs) {
+        const uint64_t type_cap = (uint64_t)n_gtypes + lower_base(CAP_TYPES, fb_nodes, fb_funcs) + CAP_CONST;
+        if (type_cap >= 0xFFFFFFF0ull) { u->status = OPUSFE_ERR_ARG; ctx->msg = "unit too large for 32-bit type ids: shard it"; return; }
+        types = tmp.get<TypeRec>(type_cap);
+        HIP_TRY(hipMemcpyAsync(types, gtypes, (size_t)n_gtypes * sizeof(TypeRec), hipMemcpyDeviceToDevice, st));
+        S.types = types;
+        B.vars = tmp.get<opusfe_variable>(lower_base(CAP_VARS, fb_nodes, fb_funcs) + CAP_CONST);
+        const uint64_t icap = lower_base(CAP_INSTRS, fb_nodes, fb_funcs) + CAP_CONST;
+        B.instrs = tmp.get<opusfe_instr>(icap); B.ibb = tmp.get<uint32_t>(icap); B.irank = tmp.get<uint32_t>(icap);
+        const uint64_t bcap = lower_base(CAP_BBS, fb_nodes, fb_funcs) + CAP_CONST;
+        B.bbcnt = tmp.get<uint32_t>(bcap); B.bblast = tmp.get<uint32_t>(bcap);
+        B.cargs = tmp.get<uint32_t>(lower_base(CAP_CARGS, fb_nodes, fb_funcs) + CAP_CONST);
+        const uint64_t lcap = lower_base(CAP_LOCALS, fb_nodes, fb_funcs) + CAP_CONST;
+        B.lname = tmp.get<uint32_t>(lcap); B.lvar = tmp.get<uint32_t>(lcap); B.lstack = tmp.get<uint32_t>(lcap);
+        B.frames = tmp.get<LFrame>(lower_base(CAP_FRAMES, fb_nodes, fb_funcs) + CAP_CONST);
+        B.errs = tmp.get<SemErr>(lower_base(CAP_ERRS, fb_nodes, fb_funcs) + CAP_CONST);
+        uint64_t* prof_buf = tmp.get<uint64_t>(LP_COUNT);
+        HIP_TRY(hipMemsetAsync(prof_buf, 0, LP_COUNT * 8, st));
+        LAUNCH(ctx, "lower_functions", k_lower_functions, grid_for((uint64_t)n_defs * UNIT_LANES, 64), 64, S, B, undefined_flag, u->d_def_nodes, n_defs, n_nodes, (uint32_t)u->n_tokens, def_excl, R->d_funcs,
+               ctx->d_status + WL_STATUS, prof_buf, user_syms, (const uint32_t*)order, (const uint32_t*)fb_flag, (const FbIdx*)fbx);
 #ifdef OPUSFE_LOWER_PROF
-    {
-        uint64_t h[LP_COUNT];
-        HIP_TRY(hipMemcpyAsync(h, prof_buf, sizeof h, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        static const char* const NAMES[LP_NAMED] = {"total", "node loads", "local_find", "call_variables", "autocast", "try_cast_pointer", "lookup_name", "field_access",
-                                                    "push", "new_var", "frames", "compiler_lookup_function"};
-        fprintf(stderr, "lowering cycle accounting (inclusive, summed over functions):\n");
-        for (int i = 0; i < LP_NAMED; i++) fprintf(stderr, "  %-26s %14llu  %5.1f%%\n", NAMES[i], (unsigned long long)h[i], 100.0 * h[i] / (double)h[0]);
-        fprintf(stderr, "per machine state (index into enum LState): share of cycles, steps, cycles per step\n");
-        for (int i = 0; i < 48; i++) if (h[LP_STATE_STEPS + i]) fprintf(stderr, "  state %2d  %5.1f%%  %12llu steps  %8.0f cycles/step\n", i, 100.0 * h[LP_STATE_CYCLES + i] / (double)h[0],
-                                                                       (unsigned long long)h[LP_STATE_STEPS + i], (double)h[LP_STATE_CYCLES + i] / (double)h[LP_STATE_STEPS + i]);
-    }
+        {
+            uint64_t h[LP_COUNT];
+            HIP_TRY(hipMemcpyAsync(h, prof_buf, sizeof h, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            static const char* const NAMES[LP_NAMED] = {"total", "node loads", "local_find", "call_variables", "autocast", "try_cast_pointer", "lookup_name", "field_access",
+                                                        "push", "new_var", "frames", "compiler_lookup_function"};
+            fprintf(stderr, "lowering cycle accounting (inclusive, summed over functions):\n");
+            for (int i = 0; i < LP_NAMED; i++) fprintf(stderr, "  %-26s %14llu  %5.1f%%\n", NAMES[i], (unsigned long long)h[i], 100.0 * h[i] / (double)h[0]);
+            fprintf(stderr, "per machine state (index into enum LState): share of cycles, steps, cycles per step\n");
+            for (int i = 0; i < 48; i++) if (h[LP_STATE_STEPS + i]) fprintf(stderr, "  state %2d  %5.1f%%  %12llu steps  %8.0f cycles/step\n", i, 100.0 * h[LP_STATE_CYCLES + i] / (double)h[0],
+                                                                           (unsigned long long)h[LP_STATE_STEPS + i], (double)h[LP_STATE_CYCLES + i] / (double)h[LP_STATE_STEPS + i]);
+        }
 #endif
+    }
+    // E3. dense bases of every function
     IrCnt* cnt = tmp.get<IrCnt>(n_funcs);
     LAUNCH(ctx, "ir_counts", k_ir_counts, grid_for(n_funcs, 256), 256, R->d_funcs, n_funcs, cnt);
     prof_begin(ctx, "ir_scan");
@@ -1610,23 +1697,31 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
     R->n_sem_errors = ctx->h_status[WL_ERRS];
     const uint32_t* tot = ctx->h_status + WL_IRTOT;
     R->n_vars = tot[0]; R->n_instrs = tot[1]; R->n_bbs = tot[2]; R->n_types = (uint64_t)n_gtypes + tot[3]; R->n_cargs = tot[4]; R->n_errs = tot[5];
-    // F. dense output
+    if (R->n_types >= 0xFFFFFFF0ull) { u->status = OPUSFE_ERR_ARG; ctx->msg = "unit too large for 32-bit type ids: shard it"; return; }
+    // F. dense output: the node-parallel emit pass writes it directly; the machine's functions are compacted into it
     R->d_vars = dev_alloc_t<opusfe_variable>(ctx, R->n_vars);
     R->d_instrs = dev_alloc_t<opusfe_instr>(ctx, R->n_instrs);
     R->d_bb_offsets = dev_alloc_t<uint32_t>(ctx, R->n_bbs + 1);
     R->d_cargs = dev_alloc_t<uint32_t>(ctx, R->n_cargs);
     R->d_types = dev_alloc_t<TypeRec>(ctx, R->n_types);
     R->d_errs = dev_alloc_t<SemErr>(ctx, R->n_errs);
-    HIP_TRY(hipMemcpyAsync(R->d_types, types, (size_t)n_gtypes * sizeof(TypeRec), hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(R->d_types, gtypes, (size_t)n_gtypes * sizeof(TypeRec), hipMemcpyDeviceToDevice, st));
     const uint32_t n_instrs32 = (uint32_t)R->n_instrs;
     HIP_TRY(hipMemcpyAsync(R->d_bb_offsets + R->n_bbs, &n_instrs32, 4, hipMemcpyHostToDevice, st));
-    LAUNCH(ctx, "ir_bb_offsets", k_ir_bb_offsets, grid_for(n_funcs, 64), 64, R->d_funcs, n_funcs, cnt, B, R->d_bb_offsets, IrCnt{});
-    IrOut O{R->d_vars, R->d_instrs, R->d_cargs, R->d_types, R->d_errs, R->d_bb_offsets, n_gtypes};
-    unsigned grid = (unsigned)((n_funcs + 3) / 4);
-    if (grid > 8192) grid = 8192;
-    LAUNCH(ctx, "ir_compact", k_ir_compact, grid, 256, R->d_funcs, n_funcs, B, types, O);
+    LAUNCH(ctx, "ir_bb_offsets", k_ir_bb_offsets, grid_for(n_funcs, 64), 64, R->d_funcs, n_funcs, cnt, B, R->d_bb_offsets, IrCnt{}, (const uint32_t*)fb_flag, (const FbIdx*)fbx);
+    if (fb_funcs) {
+        IrOut O{R->d_vars, R->d_instrs, R->d_cargs, R->d_types, R->d_errs, R->d_bb_offsets, n_gtypes};
+        unsigned grid = (unsigned)((n_funcs + 3) / 4);
+        if (grid > 8192) grid = 8192;
+        LAUNCH(ctx, "ir_compact", k_ir_compact, grid, 256, R->d_funcs, n_funcs, B, types, O, (const uint32_t*)fb_flag, (const FbIdx*)fbx);
+    }
+    PA.fb_flag = fb_flag; PA.vars = R->d_vars; PA.instrs = R->d_instrs; PA.bb_offsets = R->d_bb_offsets; PA.cargs = R->d_cargs; PA.types_out = R->d_types;
+    S.types = gtypes;
+    launch_par(true);
+    HIP_TRY(hipMemcpyAsync(ctx->h_status, ctx->d_status, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     prof_collect(ctx);
+    if (ctx->h_status[WL_STATUS] >= DS_INTERNAL_CAPACITY) { u->status = OPUSFE_ERR_INTERNAL; ctx->msg = "lowering: the count and emit passes of the node-parallel path disagree"; return; }
     u->n_funcs = n_funcs; u->n_instrs = R->n_instrs; u->n_vars = R->n_vars; u->n_bbs = R->n_bbs; u->n_types = R->n_types;
     u->status = OPUSFE_OK;
 }

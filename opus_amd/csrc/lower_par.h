@@ -1,0 +1,1493 @@
+// Node-parallel IR generation (generate_ir.rs:100-1199 as count -> scan -> emit instead of a sequential walk).
+//
+// One workgroup lowers one function with ONE LANE PER AST NODE (strided); all per-node state lives in LDS.
+//
+//   structure   parent / subtree end / depth of every node of the function (nodes are in pre-order)
+//   names       every local definition (arguments, `var`, `for` variables) goes to a small table; every name use finds
+//               its definition by (definition point <= use < end of the defining block): lookups are structural,
+//               no scope stack is walked (generate_ir.rs:176-185, 857-893)
+//   contexts    how a node is evaluated: generate_ir_from_expression with which expected type (:510) or
+//               try_generate_pointer_from_expression with which pointer kind (:985), decided by the parent
+//   types       bottom-up fixpoint: a node is lowered as soon as its operands (and the locals it reads) have types.
+//               Lowering a node = running its slice of the reference's emission schema against an
+//               emitter that only COUNTS: variables, types, instructions and basic blocks per EVENT.  Events are the
+//               points of the Euler tour of the tree: ENTER(node) and EXIT(node) (= what the parent emits right after
+//               this child).
+//   scan        exclusive scan of the counts in Euler order: variable ids, block ids and instruction slots.  Two facts make
+//               this the final layout: (1) the current block is always the newest block (every `bb_index = x` of the
+//               reference assigns the block it has just created), so emission order IS block-major order; (2) every
+//               deferred terminator (`bbs[branch].push(..)`, :310-312, 357-359) goes to a block at the moment that block stops
+//               being current, so it can be emitted right there (last paragraph).
+//   emit        the same visitor again, now writing variables / instructions / types at the scanned positions, straight
+//               into the dense result arrays.
+//
+// The fast path declines (the function is lowered by the sequential machine of lower.h instead, bit-identical by
+// construction) whenever it meets something it does not model: any semantic error, shadowing, structural type
+// comparisons of records / function types with different ids, E_Proc / CallOrIndex / `is`, functions larger than the
+// LDS tables.  How many functions decline is reported (FuncIr.status == DS_FALLBACK, IrResult::n_fallback).
+#pragma once
+// (included from lower.h, behind the sequential machine: uses FuncIr, DefCnt, the tables of sem.h)
+
+namespace opusfe {
+namespace par {
+
+#ifdef OPUSFE_EMU
+#define PAR_SYNC() do { } while (0)
+inline bool par_sync_or(bool v) { return v; }
+inline void par_fence() {}
+inline uint32_t* g_emu_lds = nullptr;          // tests/emu: heap block of exactly the kernel's dynamic LDS size (ASan checks it)
+#define PAR_LDS_BASE() (::opusfe::par::g_emu_lds)
+#else
+#define PAR_SYNC() __syncthreads()
+__device__ __forceinline__ bool par_sync_or(bool v) { return __syncthreads_or(v ? 1 : 0) != 0; }
+__device__ __forceinline__ void par_fence() { __threadfence_block(); }
+extern __shared__ __align__(16) uint32_t par_dyn_lds[];
+#define PAR_LDS_BASE() (::opusfe::par::par_dyn_lds)
+#endif
+
+enum : uint32_t { DS_FALLBACK = 0x100 };      // FuncIr.status of a function the fast path declined (never a unit status)
+enum { PP_COUNT = 4 * TP_COUNT };             // pointer-to-primitive type ids: pp_base + PtrKind * TP_COUNT + primitive
+
+// ---- type descriptors ---------------------------------------------------------------------------------------------
+// A type as the fast path sees it: an id that exists before lowering (primitive, parse-tree type, pointer-to-primitive)
+// or `function type of function f`, wrapped in up to 12 pointer levels created during lowering.  Only the structure is
+// observable (TypePrinter, compile.rs:200-274); the emit pass materialises the wrappers as fresh type records.
+typedef uint64_t Desc;
+constexpr Desc DESC_NONE = ~0ull;
+enum { DESC_MAXW = 12 };
+__host__ __device__ __forceinline__ uint32_t d_base(Desc d) { return (uint32_t)d; }
+__host__ __device__ __forceinline__ uint32_t d_nw(Desc d) { return (uint32_t)(d >> 32) & 15u; }
+__host__ __device__ __forceinline__ bool d_fn(Desc d) { return ((d >> 60) & 1u) != 0; }
+__host__ __device__ __forceinline__ uint32_t d_wrap(Desc d, uint32_t k) { return (uint32_t)(d >> (36 + 2 * k)) & 3u; }
+__host__ __device__ __forceinline__ Desc d_id(uint32_t id) { return (Desc)id; }
+__host__ __device__ __forceinline__ Desc d_func(uint32_t f) { return (Desc)f | (1ull << 60); }
+__host__ __device__ __forceinline__ bool d_plain(Desc d) { return (d >> 32) == 0; }
+__host__ __device__ __forceinline__ Desc d_inner(Desc d) {      // nw > 0: the pointee
+    const uint32_t nw = d_nw(d);
+    d &= ~(3ull << (36 + 2 * (nw - 1)));
+    d = (d & ~(15ull << 32)) | ((uint64_t)(nw - 1) << 32);
+    return d;
+}
+
+struct ParArgs {
+    const uint32_t* def_nodes; uint32_t n_defs, n_nodes; const DefCnt* def_excl; const uint8_t* undefined_flag; const uint64_t* user_syms;
+    const uint32_t* list; uint32_t n_list; uint32_t nmax, maxdef; uint32_t pp_base;
+    FuncIr* out; uint32_t* status; const uint32_t* fb_flag;   // emit pass: functions the sequential machine lowered
+    // emit pass: the dense result arrays
+    opusfe_variable* vars; opusfe_instr* instrs; uint32_t* bb_offsets; uint32_t* cargs; TypeRec* types_out;
+};
+
+struct DefEnt { uint32_t hash, low, len, node, dpoint, send, var; uint32_t pad; Desc vt; };   // a local definition, visible to nodes of pre-order rank [dpoint, send); vt = type of its variable
+struct ArgEnt { uint32_t hash, low, len, pad; Desc vt; };
+enum { MAX_ARGS = 16, MAX_CALL_ARGS = 8 };
+
+// per-node state bits (st[])
+enum : uint32_t { ST_DONE = 1u, ST_STAGE1 = 2u /* for: the loop variable has its type */, ST_DIV = 4u, ST_DEAD = 8u, ST_CTX = 16u /* rank, depth and context assigned */, ST_HASBREAK = 32u, ST_SIZED = 64u, ST_SPREAD = 128u /* children have theirs */,
+                  ST_MODE_E = 1u << 8, ST_MODE_P = 2u << 8, ST_MODE_MASK = 3u << 8, ST_PT_SHIFT = 10, ST_DEREF = 1u << 12, ST_MUSTLV = 1u << 13,
+                  ST_EXP_SHIFT = 16, ST_EXP_MASK = 15u << 16 };
+enum : uint32_t { EXP_NONE = 0, EXP_GENINT, EXP_BOOL, EXP_RET, EXP_SIZE, EXP_ASSIGN, EXP_FIELD, EXP_ARG };
+// name resolution results (ref[]): tag in the top 3 bits
+enum : uint32_t { RF_NONE = 0u, RF_LOCAL = 1u << 29, RF_ARG = 2u << 29, RF_GLOBAL = 3u << 29, RF_CONST = 4u << 29, RF_FUNC = 5u << 29, RF_CALL = 6u << 29, RF_TAG = 7u << 29, RF_VAL = ~(7u << 29) };
+// result-variable info (rvi[]): who created the variable that holds a node's result
+enum : uint32_t { RV_OWN = 0u, RV_PASS = 1u << 29, RV_LOCAL = 2u << 29, RV_ARG = 3u << 29, RV_RESOLVED = 7u << 29, RV_TAG = 7u << 29, RV_VAL = ~(7u << 29) };
+enum : uint8_t { TAIL_NONE = 0, TAIL_INSTR = 1, TAIL_TERM = 2, TAIL_NEWBB = 3 };
+
+struct Cnt4 { uint32_t v, t, i, b; };
+__device__ __forceinline__ uint64_t pack4(const Cnt4& c) { return (uint64_t)c.v | ((uint64_t)c.t << 16) | ((uint64_t)c.i << 32) | ((uint64_t)c.b << 48); }
+__device__ __forceinline__ Cnt4 unpack4(uint64_t w) { return Cnt4{(uint32_t)(w & 0xFFFF), (uint32_t)((w >> 16) & 0xFFFF), (uint32_t)((w >> 32) & 0xFFFF), (uint32_t)(w >> 48)}; }
+
+// The function being lowered: tables, LDS arrays, result bases.  Lives in registers (everything is inlined into the kernel).
+struct Fn {
+    SemView S; ParArgs A;
+    uint32_t dn, nn, fidx, nargs; FuncRec F; uint64_t user_syms;
+    // LDS
+    uint64_t* rt; uint64_t* cnt; uint32_t* kn; uint32_t* st; uint32_t* ref; uint32_t* rvi;
+    uint16_t* fc; uint16_t* nx; uint16_t* pa; uint16_t* rk; uint16_t* sz; uint16_t* pe; uint16_t* cg; uint8_t* tail;
+    DefEnt* defs; ArgEnt* args; uint32_t* misc; uint64_t* scratch;
+    // emit bases
+    uint32_t var_base, instr_base, bb_base, type_base, carg_base, n_vars_tot, n_instrs_tot, n_bbs_tot, n_types_tot, n_cargs_tot;
+    uint32_t tid, nthreads;
+};
+enum { MI_FB = 0, MI_NDEFS = 1, MI_SUM_V = 2, MI_SUM_T = 3, MI_SUM_I = 4, MI_SUM_B = 5, MI_BAD = 6, MI_WHY = 7, MI_WORDS = 8 };
+
+__host__ __device__ inline size_t lds_bytes(uint32_t nmax, uint32_t maxdef, uint32_t nthreads) {
+    size_t b = 0;
+    b += 8ull * nmax;            // rt
+    b += 8ull * 2 * nmax;        // cnt
+    b += 4ull * 4 * nmax;        // kn st ref rvi
+    b += 2ull * 7 * nmax;        // fc nx pa rk sz pe cg
+    b += 2ull * nmax;            // tail (2 per node)
+    b = (b + 7) & ~(size_t)7;
+    b += sizeof(DefEnt) * maxdef + sizeof(ArgEnt) * MAX_ARGS + 4 * MI_WORDS;
+    b = (b + 7) & ~(size_t)7;
+    b += 8ull * (nthreads + 1);   // scan scratch
+    return (b + 15) & ~(size_t)15;
+}
+
+#define NONE16 0xFFFFu
+// declines the function; the first reason (source line of the check) is kept for the fallback statistics
+__device__ __forceinline__ void fallback_at(Fn& f, uint32_t line) { if (!f.misc[MI_FB]) f.misc[MI_WHY] = line; f.misc[MI_FB] = 1; }
+#define fallback(f) fallback_at(f, __LINE__)
+__device__ __forceinline__ bool failed(const Fn& f) { return f.misc[MI_FB] != 0; }
+__device__ __forceinline__ opusfe_node ND(const Fn& f, uint32_t i) { return f.S.nodes[f.dn + i]; }
+__device__ __forceinline__ uint8_t KIND(const Fn& f, uint32_t i) { return (uint8_t)f.kn[i]; }
+__device__ __forceinline__ uint8_t SUB(const Fn& f, uint32_t i) { return (uint8_t)(f.kn[i] >> 8); }
+__device__ __forceinline__ uint32_t NCH(const Fn& f, uint32_t i) { return f.kn[i] >> 16; }
+__device__ __forceinline__ uint32_t POS_ENTER(const Fn& f, uint32_t i) { return f.pe[i]; }
+__device__ __forceinline__ uint32_t POS_EXIT(const Fn& f, uint32_t i) { return (uint32_t)f.pe[i] + 2u * (uint32_t)f.sz[i] - 1u; }
+// pre-order rank of a node, and of the first node behind its subtree (nodes are stored in creation order, not pre-order)
+__device__ __forceinline__ uint32_t RANK(const Fn& f, uint32_t i) { return f.rk[i]; }
+__device__ __forceinline__ uint32_t RANK_END(const Fn& f, uint32_t i) { return (uint32_t)f.rk[i] + f.sz[i]; }
+__device__ __forceinline__ uint32_t child_at(const Fn& f, uint32_t i, uint32_t k) { uint32_t c = f.fc[i]; while (k-- && c != NONE16) c = f.nx[c]; return c; }
+__device__ __forceinline__ uint32_t last_child(const Fn& f, uint32_t i) { uint32_t c = f.fc[i], l = NONE16; while (c != NONE16) { l = c; c = f.nx[c]; } return l; }
+// global type id of a parse-tree type node of this function
+__device__ __forceinline__ uint32_t TID(const Fn& f, uint32_t local_node) { return f.S.tid_of_node[f.dn + local_node]; }
+
+// ---- views of a type ------------------------------------------------------------------------------------------------
+struct TView { uint8_t kind, ptr; bool plain; Desc sub; TypeRec rec; };
+__device__ __forceinline__ TView view(const Fn& f, Desc d) {
+    TView v{}; v.plain = false; v.sub = DESC_NONE;
+    if (d == DESC_NONE) { v.kind = TY_Error; return v; }      // no type (an input that is not ready / a declined function)
+    const uint32_t nw = d_nw(d);
+    if (nw) { v.kind = TY_Pointer; v.ptr = (uint8_t)d_wrap(d, nw - 1); v.sub = d_inner(d); return v; }
+    if (d_fn(d)) { v.kind = TY_Function; v.rec.kind = TY_Function; v.rec.src = TS_FUNC; v.rec.ref = d_base(d); v.sub = d_id(f.S.funcs[d_base(d)].ret); return v; }
+    const uint32_t id = d_base(d);
+    v.plain = true;
+    if (id < TP_COUNT) { v.kind = prim_kind(id); return v; }
+    if (id >= f.A.pp_base && id < f.A.pp_base + PP_COUNT) { v.kind = TY_Pointer; v.ptr = (uint8_t)((id - f.A.pp_base) / TP_COUNT); v.sub = d_id((id - f.A.pp_base) % TP_COUNT); return v; }
+    v.rec = gld(f.S.types + id);
+    v.kind = v.rec.kind; v.ptr = v.rec.ptr;
+    if (v.kind == TY_Pointer || v.kind == TY_Array || v.kind == TY_Function) v.sub = d_id(v.rec.sub);
+    return v;
+}
+// pointer to `sub` (type_pointer, compile.rs:563-589); pointers to primitives are pre-made ids
+__device__ __forceinline__ Desc d_ptr(Fn& f, uint32_t pt, Desc sub) {
+    if (sub == DESC_NONE) return DESC_NONE;
+    if (d_plain(sub) && d_base(sub) < TP_COUNT) return d_id(f.A.pp_base + pt * TP_COUNT + d_base(sub));
+    const uint32_t nw = d_nw(sub);
+    if (nw >= DESC_MAXW) { fallback(f); return DESC_NONE; }
+    return (sub & ~(15ull << 32)) | ((uint64_t)(nw + 1) << 32) | ((uint64_t)pt << (36 + 2 * nw));
+}
+__device__ __forceinline__ uint32_t type_records(Desc d) { return d_nw(d) + (d_fn(d) ? 1u : 0u); }   // records the emit pass writes for a variable of this type
+
+enum { M_NO = 0, M_YES = 1, M_UNSURE = 2 };
+__device__ __forceinline__ uint64_t array_len(const Fn& f, const TypeRec& r) {
+    const opusfe_token t = f.S.tok[r.ref];
+    return (t.flags & OPUSFE_TF_INLINE) ? (uint64_t)t.payload : f.S.val64[t.payload];
+}
+// compile.rs:698-751 on descriptors; records and function types are only compared by id (M_UNSURE otherwise)
+__device__ __forceinline__ int match3(const Fn& f, Desc a, Desc b) {
+    for (uint32_t guard = 0; guard < 64; guard++) {
+        if (a == DESC_NONE || b == DESC_NONE) return M_UNSURE;
+        if (a == b) return M_YES;
+        const TView va = view(f, a), vb = view(f, b);
+        if (va.kind != vb.kind) return M_NO;
+        switch (va.kind) {
+            case TY_Pointer: if (va.ptr != vb.ptr) return M_NO; a = va.sub; b = vb.sub; break;
+            case TY_Array: if (array_len(f, va.rec) != array_len(f, vb.rec)) return M_NO; a = va.sub; b = vb.sub; break;
+            case TY_Record: case TY_Function: return M_UNSURE;
+            default: return M_YES;
+        }
+    }
+    return M_UNSURE;
+}
+__device__ __forceinline__ int match_allow_generic3(const Fn& f, Desc a, Desc b) {      // compile.rs:753-763
+    const uint8_t ka = view(f, a).kind, kb = view(f, b).kind;
+    if ((ka == TY_GenericInteger && kind_is_integral(kb)) || (kb == TY_GenericInteger && kind_is_integral(ka))) return M_YES;
+    if (ka == TY_Generic || kb == TY_Generic) return M_YES;
+    return match3(f, a, b);
+}
+__device__ __forceinline__ int match_default_generic3(const Fn& f, Desc a, Desc b) {    // compile.rs:765-775
+    const uint8_t ka = view(f, a).kind, kb = view(f, b).kind;
+    if ((ka == TY_GenericInteger && kb == TY_Integer32) || (ka == TY_Integer32 && kb == TY_GenericInteger)) return M_YES;
+    if (ka == TY_Generic || kb == TY_Generic) return M_NO;
+    return match3(f, a, b);
+}
+enum { CA_NO = -1, CA_UNSURE = -2 };
+// compile.rs:624-670; CastKind, CA_NO or CA_UNSURE
+__device__ __forceinline__ int can_autocast3(const Fn& f, Desc from, Desc to) {
+    int m = match3(f, from, to);
+    if (m == M_UNSURE) return CA_UNSURE;
+    if (m == M_YES) return CT_None;
+    const TView t1 = view(f, from), t2 = view(f, to);
+    if (t1.kind == TY_Error || t2.kind == TY_Error) return CT_Error;
+    if (t1.kind == TY_GenericInteger && kind_is_integral(t2.kind)) return CT_Error;
+    if (t1.kind == TY_Generic) return CT_Error;
+    if (t1.kind == TY_Pointer && t2.kind == TY_Pointer) {
+        const uint8_t p1 = t1.ptr, p2 = t2.ptr;
+        if (p1 == p2 || (p1 == PT_Mutable && p2 == PT_Reference) || (p1 == PT_ArrayMutable && p2 == PT_Array)) {
+            m = match3(f, t1.sub, t2.sub);
+            if (m == M_UNSURE) return CA_UNSURE;
+            if (m == M_YES) return CT_PointerType;
+        }
+        if ((p1 == PT_Mutable && p2 == PT_ArrayMutable) || (p1 == PT_Mutable && p2 == PT_Array) || (p1 == PT_Reference && p2 == PT_Array)) {
+            m = match3(f, t2.sub, d_id(TP_Natural8));
+            if (m == M_UNSURE) return CA_UNSURE;
+            if (m == M_YES) return CT_PointerType;
+        }
+        if ((p1 == PT_ArrayMutable && p2 == PT_Mutable) || (p1 == PT_ArrayMutable && p2 == PT_Reference) || (p1 == PT_Array && p2 == PT_Reference)) {
+            m = match3(f, t1.sub, d_id(TP_Natural8));
+            if (m == M_UNSURE) return CA_UNSURE;
+            if (m == M_YES) return CT_PointerType;
+        }
+        const TView s1 = view(f, t1.sub);
+        if (s1.kind == TY_Array) {
+            m = match3(f, s1.sub, t2.sub);
+            if (m == M_UNSURE) return CA_UNSURE;
+            if (m == M_YES) {
+                if ((p1 == PT_Reference && p2 == PT_Array) || (p1 == PT_Mutable && p2 == PT_ArrayMutable) || (p1 == PT_Mutable && p2 == PT_Array)) return CT_PointerToArray;
+                return CA_NO;
+            }
+        }
+        return CA_NO;
+    }
+    return CA_NO;
+}
+// compile.rs:682-696
+__device__ __forceinline__ int can_cast3(const Fn& f, Desc from, Desc to) {
+    const int c = can_autocast3(f, from, to);
+    if (c != CA_NO) return c;
+    const TView t1 = view(f, from), t2 = view(f, to);
+    if (kind_is_integral(t1.kind) && kind_is_integral(t2.kind)) return CT_Integer;
+    if (t1.kind == TY_Pointer && t2.kind == TY_Pointer && t1.ptr == t2.ptr) return CT_Pointer;
+    if ((t1.kind == TY_Pointer || t1.kind == TY_Function) && kind_is_integral(t2.kind)) return CT_PointerToInteger;
+    if ((t2.kind == TY_Pointer || t2.kind == TY_Function) && kind_is_integral(t1.kind)) return CT_IntegerToPointer;
+    return CA_NO;
+}
+
+// ---- the emitter ------------------------------------------------------------------------------------------------------
+// COUNT: v / t / i / b count what an event creates.  EMIT: they are the next function-relative variable id, local type
+// index, instruction index and block id (from the scan) and everything is written to the dense arrays.
+template <bool EMIT> struct Em {
+    uint32_t v, t, i, b; uint8_t tail; uint32_t pos;
+    __device__ __forceinline__ uint32_t emit_type(Fn& f, const TypeRec& r) {
+        const uint32_t id = f.S.n_gtypes + f.type_base + t;
+        if (EMIT) { if (t < f.n_types_tot) gst(f.A.types_out + id, r); else f.misc[MI_BAD] = 1; }
+        t++;
+        return id;
+    }
+    __device__ __forceinline__ uint32_t type_id(Fn& f, Desc d) {
+        if (d_plain(d)) return d_base(d);
+        uint32_t cur = d_base(d);
+        if (d_fn(d)) { TypeRec r{}; r.kind = TY_Function; r.src = TS_FUNC; r.ref = d_base(d); r.sub = f.S.funcs[d_base(d)].ret; r.alias = OPUSFE_NONE; cur = emit_type(f, r); }
+        const uint32_t nw = d_nw(d);
+        for (uint32_t k = 0; k < nw; k++) { TypeRec r{}; r.kind = TY_Pointer; r.ptr = (uint8_t)d_wrap(d, k); r.sub = cur; r.alias = OPUSFE_NONE; cur = emit_type(f, r); }
+        return cur;
+    }
+    __device__ __forceinline__ uint32_t newvar(Fn& f, Desc ty, bool temp) {
+        if (ty == DESC_NONE) { fallback(f); ty = d_id(TP_Error); }
+        const uint32_t tid = type_id(f, ty);
+        if (EMIT) { if (v < f.n_vars_tot) gst(f.A.vars + f.var_base + v, opusfe_variable{tid, temp ? 1u : 0u}); else f.misc[MI_BAD] = 1; }
+        return v++;
+    }
+    __device__ __forceinline__ void ins(Fn& f, uint16_t op, uint32_t dst = 0, uint32_t a = 0, uint32_t b_ = 0, uint32_t c = 0, uint32_t extra = 0, uint16_t sub = 0) {
+        if (EMIT) {
+            opusfe_instr in; in.opcode = op; in.sub = sub; in.dst = dst; in.a = a; in.b = b_; in.c = c; in.extra = extra;
+            if (i < f.n_instrs_tot) gst(f.A.instrs + f.instr_base + i, in); else f.misc[MI_BAD] = 1;
+        }
+        i++;
+        tail = (op == I_Return || op == I_Jump || op == I_Branch || op == I_Unreachable) ? TAIL_TERM : TAIL_INSTR;
+    }
+    __device__ __forceinline__ uint32_t newbb(Fn& f) {
+        if (EMIT) { if (b < f.n_bbs_tot) gst(f.A.bb_offsets + f.bb_base + b, f.instr_base + i); else f.misc[MI_BAD] = 1; }
+        tail = TAIL_NEWBB;
+        return b++;
+    }
+};
+template <bool EMIT> __device__ __forceinline__ Em<EMIT> open_slot(Fn& f, uint32_t pos) {
+    Em<EMIT> e; e.pos = pos; e.tail = TAIL_NONE;
+    if (EMIT) { const Cnt4 c = unpack4(f.cnt[pos]); e.v = c.v; e.t = c.t; e.i = c.i; e.b = c.b; }
+    else { e.v = e.t = e.i = e.b = 0; }
+    return e;
+}
+template <bool EMIT> __device__ __forceinline__ void close_slot(Fn& f, const Em<EMIT>& e) {
+    if (!EMIT) {
+        if (e.v > 0xFFF || e.t > 0xFFF || e.i > 0xFFF || e.b > 0xFFF) fallback(f);
+        f.cnt[e.pos] = pack4(Cnt4{e.v, e.t, e.i, e.b});
+        f.tail[e.pos] = e.tail;
+    }
+}
+// first block created by the event at `pos` (emit pass: the scanned prefix)
+__device__ __forceinline__ uint32_t bb_at(const Fn& f, uint32_t pos) { return unpack4(f.cnt[pos]).b; }
+
+// ---- names --------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool bytes_eq(const Fn& f, uint32_t lo1, uint32_t lo2, uint32_t len) {
+    if (lo1 == lo2) return true;
+    for (uint32_t k = 0; k < len; k++) if (f.S.src[lo1 + k] != f.S.src[lo2 + k]) return false;
+    return true;
+}
+// definition of identifier token `t` visible at node `use`: RF_LOCAL | index, RF_ARG | index, or RF_NONE
+__device__ __forceinline__ uint32_t find_local(const Fn& f, const opusfe_token& t, uint32_t use_node) {
+    const uint32_t nd = f.misc[MI_NDEFS], use = RANK(f, use_node);
+    for (uint32_t k = 0; k < nd; k++) {
+        const DefEnt& d = f.defs[k];
+        if (d.hash == t.payload && d.len == t.len && d.dpoint <= use && use < d.send && bytes_eq(f, d.low, t.low, t.len)) return RF_LOCAL | k;
+    }
+    for (uint32_t k = 0; k < f.nargs; k++) {
+        const ArgEnt& a = f.args[k];
+        if (a.hash == t.payload && a.len == t.len && bytes_eq(f, a.low, t.low, t.len)) return RF_ARG | k;
+    }
+    return RF_NONE;
+}
+__device__ __forceinline__ bool slot_has_functions(const Fn& f, uint32_t slot) {
+    if (slot == OPUSFE_NONE) return false;
+    const NameSlot sl = f.S.slots[slot];
+    for (uint32_t j = 0; j < sl.count; j++) if ((f.S.entries[sl.offset + j].kind_index >> 30) == NK_FUNCTION) return true;
+    return false;
+}
+
+// ---- function values ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool fn_builtin(uint32_t fn) { return (fn & FN_BUILTIN) != 0; }
+__device__ __forceinline__ uint32_t fn_nargs(const Fn& f, uint32_t fn) { return fn_builtin(fn) ? builtin_nargs((fn >> 8) & 0xFF) : f.S.funcs[fn].nargs; }
+__device__ __forceinline__ uint32_t fn_ret(const Fn& f, uint32_t fn) { return fn_builtin(fn) ? builtin_ret_type((fn >> 8) & 0xFF, fn & 0xFF) : f.S.funcs[fn].ret; }
+__device__ __forceinline__ uint32_t fn_arg_type(const Fn& f, uint32_t fn, uint32_t k) {
+    if (fn_builtin(fn)) return builtin_arg_type((fn >> 8) & 0xFF, fn & 0xFF);
+    uint32_t c = f.S.funcs[fn].first_arg;
+    while (k--) c = f.S.nodes[c].next;
+    return f.S.tid_of_node[f.S.nodes[c].first_child];
+}
+// Compiler::lookup_function (compile.rs:1083-1139): builtins of the symbol, then the user overloads in definition order.
+// FN_NONE: an error the reference reports (the function falls back); the caller checks failed().
+__device__ __forceinline__ uint32_t lookup_function(Fn& f, NameKey name, const Desc* argt, uint32_t n) {
+    const uint8_t sym = name_sym(f.S.tok, name);
+    if (sym != T_Identifier && builtin_count(sym) > 0 && !((f.user_syms >> sym) & 1) && n == builtin_nargs(sym)) {
+        const Desc a0 = argt[0], a1 = n > 1 ? argt[1] : argt[0];
+        if (d_plain(a0) && d_plain(a1) && d_base(a0) < TP_COUNT && d_base(a1) < TP_COUNT && d_base(a0) != TP_Error && d_base(a1) != TP_Error) {
+            const int idx = builtin_pick(sym, d_base(a0), d_base(a1));
+            if (idx >= 0) return FN_BUILTIN | ((uint32_t)sym << 8) | (uint32_t)idx;
+        }
+    }
+    if (n > MAX_CALL_ARGS) { fallback(f); return FN_NONE; }
+    const uint32_t slot = name_find(f.S, name);
+    const uint32_t nb = sym != T_Identifier ? (uint32_t)builtin_count(sym) : 0u;
+    const bool has_user = slot_has_functions(f, slot);
+    if (nb == 0 && !has_user) { fallback(f); return FN_NONE; }                      // UndefinedFunction
+    const NameSlot sl = slot != OPUSFE_NONE ? f.S.slots[slot] : NameSlot{OPUSFE_NONE, 0, 0, 0};
+    const uint32_t total = nb + sl.count;
+    auto cand = [&](uint32_t c) -> uint32_t {
+        if (c < nb) return FN_BUILTIN | ((uint32_t)sym << 8) | c;
+        const NameEntry e = f.S.entries[sl.offset + (c - nb)];
+        return (e.kind_index >> 30) == NK_FUNCTION ? (e.kind_index & 0x3FFFFFFFu) : FN_NONE;
+    };
+    auto viable = [&](uint32_t fn) -> bool {
+        if (fn_nargs(f, fn) != n) return false;
+        for (uint32_t k = 0; k < n; k++) {
+            const int c = can_autocast3(f, argt[k], d_id(fn_arg_type(f, fn, k)));
+            if (c == CA_UNSURE) { fallback(f); return false; }
+            if (c < 0) return false;
+        }
+        return true;
+    };
+    uint32_t first = FN_NONE; uint32_t ignorable = ~0u;
+    for (uint32_t c = 0; c < total && !failed(f); c++) {
+        const uint32_t fn = cand(c);
+        if (fn == FN_NONE || !viable(fn)) continue;
+        if (first == FN_NONE) first = fn;
+        for (uint32_t k = 0; k < n; k++) {
+            if (!((ignorable >> k) & 1)) continue;
+            const int m = match_allow_generic3(f, d_id(fn_arg_type(f, fn, k)), d_id(fn_arg_type(f, first, k)));
+            if (m == M_UNSURE) { fallback(f); return FN_NONE; }
+            if (m == M_NO) ignorable &= ~(1u << k);
+        }
+    }
+    if (failed(f)) return FN_NONE;
+    if (first == FN_NONE) { fallback(f); return FN_NONE; }                           // NoOverloadForFunction
+    for (uint32_t c = 0; c < total; c++) {
+        const uint32_t fn = cand(c);
+        if (fn == FN_NONE || !viable(fn)) continue;
+        if (failed(f)) return FN_NONE;
+        bool all = true;
+        for (uint32_t k = 0; k < n; k++) {
+            if ((ignorable >> k) & 1) continue;
+            const int m = match_default_generic3(f, d_id(fn_arg_type(f, fn, k)), argt[k]);
+            if (m == M_UNSURE) { fallback(f); return FN_NONE; }
+            if (m == M_NO) { all = false; break; }
+        }
+        if (all) return fn;
+    }
+    fallback(f);                                                                      // AmbiguousOverload
+    return FN_NONE;
+}
+
+// ---- the visitor --------------------------------------------------------------------------------------------------------
+// Result variable of node c as an operand (emit pass: the id computed by the rv pass; count pass: unused)
+template <bool EMIT> __device__ __forceinline__ uint32_t RV(const Fn& f, uint32_t c) { return EMIT ? (f.rvi[c] & RV_VAL) : 0u; }
+__device__ __forceinline__ uint32_t own_rv(uint32_t pos, uint32_t off) { return RV_OWN | (pos << 12) | (off & 0xFFF); }
+
+// the node that created the variable holding the result of node c (follows pass-through results)
+__device__ __forceinline__ uint32_t creator_of(const Fn& f, uint32_t c) {
+    for (uint32_t guard = 0; guard < 4096; guard++) {
+        const uint32_t r = f.rvi[c];
+        if ((r & RV_TAG) != RV_PASS) return c;
+        c = r & 0xFFFF;
+    }
+    return c;
+}
+
+template <bool EMIT> struct Val { uint32_t var; Desc t; uint32_t info; };   // info: rvi encoding of `var` (count pass)
+
+// autocast_variable_to_type (generate_ir.rs:207-231) of the result of node `src` (type t, variable in val) to `want`
+template <bool EMIT> __device__ __forceinline__ Val<EMIT> autocast(Fn& f, Em<EMIT>& e, Val<EMIT> val, uint32_t src_node, Desc want) {
+    const int m = match3(f, val.t, want);
+    if (m == M_UNSURE) { fallback(f); return val; }
+    if (m == M_YES) return val;
+    const int ct = can_autocast3(f, val.t, want);
+    if (ct < 0) { fallback(f); return val; }                                           // UnexpectedType (or unsure)
+    const uint8_t fk = view(f, val.t).kind;
+    if (fk == TY_Error || view(f, want).kind == TY_Error) { fallback(f); return val; }
+    if (fk == TY_GenericInteger || fk == TY_Generic) {
+        // retype in place (:214-218): the creator of the variable writes it with its final type
+        if (src_node == NONE16) { fallback(f); return val; }
+        if (!EMIT) {
+            const uint32_t x = creator_of(f, src_node);
+            if (KIND(f, x) != E_Integer || !d_plain(want)) { fallback(f); return val; }
+            f.ref[x] = d_base(want);
+        }
+        val.t = want;
+        return val;
+    }
+    Val<EMIT> r; r.t = want;
+    r.info = own_rv(e.pos, e.v);
+    r.var = e.newvar(f, want, true);
+    e.ins(f, I_Cast, r.var, val.var, 0, 0, 0, (uint16_t)ct);
+    return r;
+}
+// try_cast_pointer (:808-855)
+template <bool EMIT> __device__ __forceinline__ Val<EMIT> try_cast_pointer(Fn& f, Em<EMIT>& e, Val<EMIT> val, uint32_t pt) {
+    const TView r = view(f, val.t);
+    if (r.kind != TY_Pointer) { fallback(f); return val; }
+    if (r.ptr == pt) return val;
+    const uint32_t p2 = r.ptr;
+    if ((p2 == PT_Mutable && pt == PT_Reference) || (p2 == PT_ArrayMutable && pt == PT_Array) || (p2 == PT_Array && pt == PT_Reference)
+        || (p2 == PT_ArrayMutable && pt == PT_Mutable) || (p2 == PT_ArrayMutable && pt == PT_Reference)) {
+        Val<EMIT> o; o.t = d_ptr(f, pt, r.sub);
+        o.info = own_rv(e.pos, e.v);
+        o.var = e.newvar(f, o.t, true);
+        e.ins(f, I_Cast, o.var, val.var, 0, 0, 0, CT_PointerType);
+        return o;
+    }
+    fallback(f);                                                                       // ImmutableLvalue / ArrayPointerToNonArray
+    return val;
+}
+// pointee of a pointer-typed variable (get_lvalue_type :235-242)
+__device__ __forceinline__ Desc pointee(Fn& f, Desc t) {
+    const TView r = view(f, t);
+    if (r.kind != TY_Pointer) { fallback(f); return DESC_NONE; }
+    return r.sub;
+}
+// p_result of lower.h: generate_pointer_from_expression's lvalue check (:970-979) and the rvalue load (:577-585)
+template <bool EMIT> __device__ __forceinline__ Val<EMIT> p_result(Fn& f, Em<EMIT>& e, Val<EMIT> val, bool lv, uint32_t st) {
+    if ((st & ST_MUSTLV) && !lv) { fallback(f); return val; }                          // InvalidLvalue
+    if ((st & ST_DEREF) && lv) {
+        Val<EMIT> o; o.t = pointee(f, val.t);
+        o.info = own_rv(e.pos, e.v);
+        o.var = e.newvar(f, o.t, true);
+        e.ins(f, I_Load, o.var, val.var);
+        return o;
+    }
+    return val;
+}
+template <bool EMIT> __device__ __forceinline__ void set_result(Fn& f, uint32_t i, const Val<EMIT>& v) {
+    if (!EMIT) { f.rt[i] = v.t; f.rvi[i] = v.info; }
+}
+template <bool EMIT> __device__ __forceinline__ Val<EMIT> child_val(const Fn& f, uint32_t c) {
+    Val<EMIT> v; v.var = RV<EMIT>(f, c); v.t = f.rt[c]; v.info = RV_PASS | c;
+    return v;
+}
+
+// field of a record type (get_field_type :1090-1101): type id of the field or NONE
+__device__ __forceinline__ uint32_t record_field(const Fn& f, const TypeRec& rec, const opusfe_token& name) {
+    if (rec.src != TS_NODE) return OPUSFE_NONE;
+    uint32_t c = f.S.nodes[rec.ref].first_child;
+    const uint32_t n = f.S.nodes[rec.ref].nchild;
+    for (uint32_t k = 0; k < n && c != OPUSFE_NONE; k++) {
+        const opusfe_node m = f.S.nodes[c];
+        const opusfe_token t = f.S.tok[m.payload];
+        if (t.kind == name.kind && (t.kind != T_Identifier || (t.payload == name.payload && t.len == name.len && bytes_eq(f, t.low, name.low, t.len)))) return f.S.tid_of_node[m.first_child];
+        c = m.next;
+    }
+    return OPUSFE_NONE;
+}
+// generate_ir_for_field_access (:1103-1149) on the record pointer `rec`
+template <bool EMIT> __device__ __forceinline__ Val<EMIT> field_access(Fn& f, Em<EMIT>& e, Val<EMIT> rec, uint32_t field_tok, uint32_t pt) {
+    Val<EMIT> o = rec;
+    if (pt == PT_Array || pt == PT_ArrayMutable) { fallback(f); return o; }
+    const Desc pt_t = pointee(f, rec.t);
+    if (failed(f)) return o;
+    const TView r = view(f, pt_t);
+    const opusfe_token name = f.S.tok[field_tok];
+    if (r.kind == TY_Record && r.plain) {
+        const uint32_t ft = record_field(f, r.rec, name);
+        if (ft == OPUSFE_NONE) { fallback(f); return o; }
+        o.t = d_ptr(f, pt, d_id(ft));
+        o.info = own_rv(e.pos, e.v);
+        o.var = e.newvar(f, o.t, true);
+        e.ins(f, I_Field, o.var, rec.var, 0, field_tok);
+        return o;
+    }
+    if (r.kind == TY_String) {
+        uint32_t idx; Desc ft;
+        if (name_is(f.S.src, f.S.tok, field_tok, "data", 4)) { idx = 0; ft = d_ptr(f, PT_Array, d_id(TP_Natural8)); }
+        else if (name_is(f.S.src, f.S.tok, field_tok, "length", 6)) { idx = 1; ft = d_id(TP_Size); }
+        else { fallback(f); return o; }
+        o.t = d_ptr(f, pt, ft);
+        o.info = own_rv(e.pos, e.v);
+        o.var = e.newvar(f, o.t, true);
+        e.ins(f, I_BuiltinField, o.var, rec.var, 0, idx);
+        return o;
+    }
+    fallback(f);
+    return o;
+}
+
+// type of an unsuffixed integer literal from the expected type of its position (generate_ir.rs:514-549)
+__device__ __forceinline__ Desc expected_of(Fn& f, uint32_t i, bool* ready) {
+    *ready = true;
+    const uint32_t exp = (f.st[i] & ST_EXP_MASK) >> ST_EXP_SHIFT;
+    switch (exp) {
+        case EXP_GENINT: return d_id(TP_GenericInteger);
+        case EXP_BOOL: return d_id(TP_Bool);
+        case EXP_RET: return d_id(f.F.ret);
+        case EXP_SIZE: return d_id(TP_Size);
+        case EXP_ASSIGN: case EXP_FIELD: case EXP_ARG: {
+            uint32_t a = f.pa[i];
+            while (a != NONE16 && (KIND(f, a) == E_Parentheses || KIND(f, a) == E_Negate)) a = f.pa[a];
+            if (a == NONE16) { fallback(f); return DESC_NONE; }
+            if (exp == EXP_ARG) return d_id((f.ref[a] & RF_TAG) == RF_CALL ? (uint32_t)TP_GenericInteger : (uint32_t)TP_Size);   // call argument / index
+            if (exp == EXP_ASSIGN) {
+                const uint32_t lhs = f.fc[a];
+                if (!(f.st[lhs] & ST_DONE)) { *ready = false; return DESC_NONE; }
+                return pointee(f, f.rt[lhs]);
+            }
+            // X_FieldInit under E_Record: the type of the named field, or none when the record has no such field
+            const uint32_t recnode = f.pa[a];
+            const TView r = view(f, d_id(TID(f, f.fc[recnode])));
+            if (r.kind != TY_Record) return DESC_NONE;
+            const uint32_t ft = record_field(f, r.rec, f.S.tok[ND(f, a).payload]);
+            return ft == OPUSFE_NONE ? DESC_NONE : d_id(ft);
+        }
+        default: return DESC_NONE;
+    }
+}
+
+// the loop a `break` / `continue` at node i belongs to (generate_ir.rs:327-331, 432-436: the loop target is set for the then-block only)
+__device__ __forceinline__ uint32_t enclosing_loop(const Fn& f, uint32_t i) {
+    uint32_t c = i, a = f.pa[i];
+    while (a != NONE16) {
+        const uint8_t k = KIND(f, a);
+        if (k == S_While) { if (f.nx[f.fc[a]] == c) return a; }
+        else if (k == S_For) { const uint32_t iter = SUB(f, a) ? f.nx[f.fc[a]] : f.fc[a]; if (f.nx[iter] == c) return a; }
+        c = a; a = f.pa[a];
+    }
+    return NONE16;
+}
+// then-block and else-block (or NONE16) of an if / while / for node
+__device__ __forceinline__ void blocks_of(const Fn& f, uint32_t s, uint32_t* cond, uint32_t* then_b, uint32_t* else_b) {
+    uint32_t c = f.fc[s];
+    if (KIND(f, s) == S_For && SUB(f, s)) c = f.nx[c];
+    *cond = c; *then_b = f.nx[c]; *else_b = f.nx[*then_b];
+}
+// block ids of a loop (emit pass)
+__device__ __forceinline__ uint32_t loop_start_bb(const Fn& f, uint32_t loop) {
+    if (KIND(f, loop) == S_While) return bb_at(f, POS_ENTER(f, loop));
+    uint32_t cond, tb, eb; blocks_of(f, loop, &cond, &tb, &eb);
+    return bb_at(f, POS_EXIT(f, cond));
+}
+__device__ __forceinline__ uint32_t merge_bb(const Fn& f, uint32_t s) {
+    uint32_t cond, tb, eb; blocks_of(f, s, &cond, &tb, &eb);
+    return eb != NONE16 ? bb_at(f, POS_EXIT(f, eb)) : bb_at(f, POS_EXIT(f, tb)) + 1;
+}
+
+// Type of the variable of `for x [T] in e` (generate_ir.rs:363-431): `@mut T`, or without a type the parameter type of the
+// `continue` overload that the (iterator, <unknown>) call resolves to (Q13).  Needs the type of e; the body waits for this.
+__device__ __forceinline__ Desc for_variable_type(Fn& f, uint32_t i) {
+    uint32_t cond, tb, eb; blocks_of(f, i, &cond, &tb, &eb);
+    const uint32_t tnode = SUB(f, i) ? f.fc[i] : NONE16;
+    if (tnode != NONE16) return d_ptr(f, PT_Mutable, d_id(TID(f, tnode)));
+    Desc at[2]; at[0] = f.rt[cond];
+    if (at[0] == DESC_NONE || view(f, at[0]).kind == TY_Error) { fallback(f); return DESC_NONE; }
+    const uint32_t ff = lookup_function(f, key_sym(T_For), at, 1);
+    if (failed(f) || ff == FN_NONE || fn_builtin(ff)) { fallback(f); return DESC_NONE; }
+    at[0] = d_ptr(f, PT_Mutable, d_id(fn_ret(f, ff))); at[1] = d_id(TP_Generic);
+    const uint32_t cf = lookup_function(f, key_sym(T_Continue), at, 2);
+    if (failed(f) || cf == FN_NONE || fn_builtin(cf)) { fallback(f); return DESC_NONE; }
+    return d_id(fn_arg_type(f, cf, 1));
+}
+
+// Are all operands of node i typed?  (A node is lowered in the sweep after its last operand.)
+__device__ __forceinline__ bool operands_done(const Fn& f, uint32_t i) {
+    const uint8_t k = KIND(f, i);
+    if (k == E_Operator && SUB(f, i) == OP_Not) return (f.st[f.nx[f.fc[i]]] & ST_DONE) != 0;
+    for (uint32_t c = f.fc[i]; c != NONE16; c = f.nx[c]) if (!(f.st[c] & (ST_DONE | ST_DEAD))) return false;
+    return true;
+}
+
+// Lowers node i: all events it owns.  Returns false when an input is not ready yet (count pass only).
+template <bool EMIT> __device__ bool visit(Fn& f, uint32_t i) {
+    const uint32_t st = f.st[i];
+    const uint8_t kind = KIND(f, i);
+    const uint32_t mode = st & ST_MODE_MASK;
+    const uint32_t pt = (st >> ST_PT_SHIFT) & 3u;
+    // ---- statements, blocks, the function itself ----
+    if (mode == 0) {
+        switch (kind) {
+            case D_Function: {
+                // prologue (generate_ir.rs:133-149) at ENTER; epilogue (:151-171) after the body
+                const uint32_t body = last_child(f, i);
+                Em<EMIT> e = open_slot<EMIT>(f, POS_ENTER(f, i));
+                e.newbb(f);
+                for (uint32_t k = 0; k < f.nargs; k++) e.newvar(f, pointee(f, f.args[k].vt), true);
+                for (uint32_t k = 0; k < f.nargs; k++) { const uint32_t v = e.newvar(f, f.args[k].vt, false); e.ins(f, I_Allocate, v); e.ins(f, I_Store, 0, v, k); }
+                close_slot(f, e);
+                const bool returns_null = view(f, d_id(f.F.ret)).kind == TY_Null;
+                const bool rdiv = (f.st[body] & ST_DIV) != 0;
+                if (!(rdiv || returns_null)) { fallback(f); return true; }             // FunctionMightNotReturn
+                // last thing emitted before this point: an instruction (which?) or a new block
+                Em<EMIT> x = open_slot<EMIT>(f, POS_EXIT(f, body));
+                uint32_t p = POS_EXIT(f, body);
+                uint8_t tl = TAIL_NONE;
+                while (p > 0 && tl == TAIL_NONE) { p--; tl = f.tail[p]; }
+                if (tl != TAIL_TERM) {
+                    if (returns_null) { const uint32_t v = x.newvar(f, d_id(TP_Null), true); x.ins(f, I_Null, v); x.ins(f, I_Return, 0, v); }
+                    else x.ins(f, I_Unreachable);
+                }
+                close_slot(f, x);
+                return true;
+            }
+            case X_Block: {
+                uint32_t div = 0;
+                for (uint32_t c = f.fc[i]; c != NONE16; c = f.nx[c]) div |= f.st[c] & ST_DIV;
+                if (!EMIT) f.st[i] |= div;
+                return true;
+            }
+            case S_Expression: return true;
+            case S_VariableDefinition: {   // :252-264
+                const uint32_t c = f.fc[i];
+                Em<EMIT> e = open_slot<EMIT>(f, POS_EXIT(f, c));
+                const Desc t = f.rt[c];
+                if (view(f, t).kind == TY_Error) { fallback(f); return true; }
+                const Desc vt = d_ptr(f, PT_Mutable, t);
+                const uint32_t info = own_rv(e.pos, e.v);
+                const uint32_t nv = e.newvar(f, vt, false);
+                e.ins(f, I_Allocate, nv);
+                e.ins(f, I_Store, 0, nv, RV<EMIT>(f, c));
+                close_slot(f, e);
+                if (!EMIT) { DefEnt& d = f.defs[f.ref[i]]; d.vt = vt; d.var = info; }
+                return true;
+            }
+            case S_Assignment: {           // :265-274
+                const uint32_t l = f.fc[i], r = f.nx[l];
+                Em<EMIT> e = open_slot<EMIT>(f, POS_EXIT(f, r));
+                const Desc T = pointee(f, f.rt[l]);
+                if (failed(f)) return true;
+                Val<EMIT> fin = autocast<EMIT>(f, e, child_val<EMIT>(f, r), r, T);
+                e.ins(f, I_Store, 0, RV<EMIT>(f, l), fin.var);
+                close_slot(f, e);
+                return true;
+            }
+            case S_Return: {               // :275-283
+                const uint32_t c = f.fc[i];
+                Em<EMIT> e = open_slot<EMIT>(f, POS_EXIT(f, c));
+                Val<EMIT> fin = autocast<EMIT>(f, e, child_val<EMIT>(f, c), c, d_id(f.F.ret));
+                e.ins(f, I_Return, 0, fin.var);
+                close_slot(f, e);
+                if (!EMIT) f.st[i] |= ST_DIV;
+                return true;
+            }
+            case S_If: case S_While: case S_For: {
+                uint32_t cond, tb, eb; blocks_of(f, i, &cond, &tb, &eb);
+                if (tb == NONE16) { fallback(f); return true; }
+                uint32_t loop_bb = 0;
+                Val<EMIT> cv = child_val<EMIT>(f, cond);
+                if (kind == S_While) {     // :315-326
+                    Em<EMIT> e0 = open_slot<EMIT>(f, POS_ENTER(f, i));
+                    loop_bb = e0.b;
+                    e0.ins(f, I_Jump, 0, 0, 0, loop_bb);
+                    e0.newbb(f);
+                    close_slot(f, e0);
+                }
+                Em<EMIT> e = open_slot<EMIT>(f, POS_EXIT(f, cond));
+                uint32_t cg = EMIT ? f.carg_base + f.cg[i] : 0u;
+                if (kind == S_For) {       // :363-431
+                    const uint32_t tnode = SUB(f, i) ? f.fc[i] : NONE16;
+                    Desc at[2]; at[0] = cv.t;
+                    if (view(f, cv.t).kind == TY_Error) { fallback(f); return true; }
+                    const uint32_t ff = lookup_function(f, key_sym(T_For), at, 1);
+                    if (failed(f) || ff == FN_NONE || fn_builtin(ff)) { fallback(f); return true; }
+                    const uint32_t for_fn = e.newvar(f, d_func(ff), true);
+                    e.ins(f, I_Function, for_fn, 0, 0, ff);
+                    Val<EMIT> it = autocast<EMIT>(f, e, cv, cond, d_id(fn_arg_type(f, ff, 0)));
+                    const Desc ret_t = d_id(fn_ret(f, ff));
+                    const uint32_t ret_var = e.newvar(f, ret_t, true);
+                    const Desc iter_t = d_ptr(f, PT_Mutable, ret_t);
+                    const uint32_t iterator_variable = e.newvar(f, iter_t, true);
+                    if (EMIT) gst(f.A.cargs + cg, it.var);
+                    e.ins(f, I_Call, ret_var, for_fn, 0, cg, 0, 1);
+                    e.ins(f, I_Allocate, iterator_variable);
+                    e.ins(f, I_Store, 0, iterator_variable, ret_var);
+                    loop_bb = e.b;
+                    e.ins(f, I_Jump, 0, 0, 0, loop_bb);
+                    e.newbb(f);
+                    Desc pointer_type = tnode != NONE16 ? d_ptr(f, PT_Mutable, d_id(TID(f, tnode))) : d_id(TP_Generic);
+                    const uint32_t info = own_rv(e.pos, e.v);
+                    // the variable is created with its FINAL type: `<unknown>` is retyped in place by the autocast below (Q13)
+                    at[0] = iter_t; at[1] = pointer_type;
+                    const uint32_t cf = lookup_function(f, key_sym(T_Continue), at, 2);
+                    if (failed(f) || cf == FN_NONE || fn_builtin(cf)) { fallback(f); return true; }
+                    if (tnode == NONE16) {
+                        pointer_type = d_id(fn_arg_type(f, cf, 1));
+                        if (view(f, pointer_type).kind == TY_Error) { fallback(f); return true; }
+                    }
+                    const uint32_t iteration_variable = e.newvar(f, pointer_type, false);
+                    e.ins(f, I_Allocate, iteration_variable);
+                    if (!EMIT) { DefEnt& d = f.defs[f.ref[i]]; d.vt = pointer_type; d.var = info; }
+                    const uint32_t cont_fn = e.newvar(f, d_func(cf), true);
+                    e.ins(f, I_Function, cont_fn, 0, 0, cf);
+                    Val<EMIT> a0; a0.var = iterator_variable; a0.t = iter_t; a0.info = 0;
+                    a0 = autocast<EMIT>(f, e, a0, NONE16, d_id(fn_arg_type(f, cf, 0)));
+                    Val<EMIT> a1; a1.var = iteration_variable; a1.t = pointer_type; a1.info = 0;
+                    a1 = autocast<EMIT>(f, e, a1, NONE16, d_id(fn_arg_type(f, cf, 1)));
+                    if (failed(f)) return true;
+                    cv.t = d_id(fn_ret(f, cf));
+                    cv.var = e.newvar(f, cv.t, true);
+                    if (EMIT) { gst(f.A.cargs + cg + 1, a0.var); gst(f.A.cargs + cg + 2, a1.var); }
+                    e.ins(f, I_Call, cv.var, cont_fn, 0, cg + 1, 0, 2);
+                    cond = NONE16;         // the condition is no node's result: a <integer> cannot reach the autocast below
+                }
+                cv = autocast<EMIT>(f, e, cv, cond, d_id(TP_Bool));
+                if (failed(f)) return true;
+                const uint32_t then_bb = e.b;
+                uint32_t else_bb = 0, merge = 0;
+                if (EMIT) { else_bb = bb_at(f, POS_EXIT(f, tb)); merge = merge_bb(f, i); }
+                e.ins(f, I_Branch, 0, cv.var, then_bb, else_bb);
+                e.newbb(f);
+                close_slot(f, e);
+                Em<EMIT> e2 = open_slot<EMIT>(f, POS_EXIT(f, tb));
+                e2.ins(f, I_Jump, 0, 0, 0, kind == S_If ? merge : loop_bb);
+                e2.newbb(f);
+                if (eb == NONE16) { e2.ins(f, I_Jump, 0, 0, 0, merge); e2.newbb(f); }
+                close_slot(f, e2);
+                if (eb != NONE16) {
+                    Em<EMIT> e3 = open_slot<EMIT>(f, POS_EXIT(f, eb));
+                    e3.ins(f, I_Jump, 0, 0, 0, merge);
+                    e3.newbb(f);
+                    close_slot(f, e3);
+                }
+                if (!EMIT) {
+                    const bool tdiv = (f.st[tb] & ST_DIV) != 0, ediv = eb != NONE16 && (f.st[eb] & ST_DIV) != 0;
+                    bool div;
+                    if (kind == S_If) div = tdiv && ediv;
+                    else if (kind == S_For) div = ediv;
+                    else div = ediv || (KIND(f, f.fc[i]) == E_Bool && SUB(f, f.fc[i]) && !(f.st[i] & ST_HASBREAK));
+                    if (div) f.st[i] |= ST_DIV;
+                }
+                return true;
+            }
+            case S_Break: case S_Continue: {   // :470-489
+                const uint32_t loop = f.ref[i];
+                if (loop == NONE16) { fallback(f); return true; }
+                Em<EMIT> e = open_slot<EMIT>(f, POS_ENTER(f, i));
+                uint32_t target = 0;
+                if (EMIT) target = kind == S_Break ? merge_bb(f, loop) : loop_start_bb(f, loop);
+                e.ins(f, I_Jump, 0, 0, 0, target);
+                e.newbb(f);
+                close_slot(f, e);
+                return true;
+            }
+            default: return true;          // type nodes, field-init / named-type carriers: nothing of their own
+        }
+    }
+    // ---- expressions ----
+    if (mode == ST_MODE_E) {
+        switch (kind) {
+            case E_Integer: {
+                const opusfe_token t = f.S.tok[ND(f, i).payload];
+                Desc typ;
+                if (t.aux & 0x8000) {
+                    const uint32_t size = t.aux & 0xFF; const bool sg = (t.aux & 0x100) != 0;
+                    uint32_t p;
+                    if (!sg) p = size == 8 ? TP_Natural8 : size == 16 ? TP_Natural16 : size == 32 ? TP_Natural32 : size == 64 ? TP_Natural64 : TP_Size;
+                    else p = size == 8 ? TP_Integer8 : size == 16 ? TP_Integer16 : size == 32 ? TP_Integer32 : size == 64 ? TP_Integer64 : TP_Offset;
+                    typ = d_id(p);
+                } else {
+                    bool ready;
+                    const Desc exp = expected_of(f, i, &ready);
+                    if (!ready) return false;
+                    if (failed(f)) return true;
+                    uint8_t k = TY_Error;
+                    if (exp != DESC_NONE) k = view(f, exp).kind;
+                    typ = (exp != DESC_NONE && (kind_is_integral(k) || k == TY_GenericInteger)) ? exp : d_id(TP_Integer32);
+                }
+                uint64_t val = (t.flags & OPUSFE_TF_INLINE) ? (uint64_t)t.payload : f.S.val64[t.payload];
+                // a <integer> literal under unary minus is negated in place (generate_ir.rs:766-780): one sign flip per Negate above it
+                if (view(f, typ).kind == TY_GenericInteger) {
+                    uint32_t a = f.pa[i]; bool neg = false;
+                    while (a != NONE16 && (KIND(f, a) == E_Parentheses || KIND(f, a) == E_Negate)) { if (KIND(f, a) == E_Negate) neg = !neg; a = f.pa[a]; }
+                    if (neg) val = 0 - val;
+                }
+                Em<EMIT> e = open_slot<EMIT>(f, POS_ENTER(f, i));
+                Val<EMIT> o; o.t = typ; o.info = own_rv(e.pos, e.v);
+                if (!EMIT) f.ref[i] = OPUSFE_NONE;
+                const Desc final_t = (EMIT && f.ref[i] != OPUSFE_NONE) ? d_id(f.ref[i]) : typ;
+                o.var = e.newvar(f, final_t, true);
+                e.ins(f, I_Integer, o.var, 0, 0, (uint32_t)val, (uint32_t)(val >> 32));
+                close_slot(f, e);
+                set_result<EMIT>(f, i, o);
+                return true;
+            }
+            case E_Float: case E_Null: case E_Bool: case E_String: {
+                const opusfe_node nd = ND(f, i);
+                Em<EMIT> e = open_slot<EMIT>(f, POS_ENTER(f, i));
+                Val<EMIT> o; o.info = own_rv(e.pos, e.v);
+                if (kind == E_Float) {
+                    const opusfe_token t = f.S.tok[nd.payload];
+                    const uint64_t bits = f.S.val64[t.payload];
+                    o.t = d_id(t.aux == 32 ? TP_Float32 : TP_Float64);
+                    o.var = e.newvar(f, o.t, true);
+                    e.ins(f, I_Float, o.var, 0, 0, (uint32_t)bits, (uint32_t)(bits >> 32));
+                } else if (kind == E_Null) { o.t = d_id(TP_Null); o.var = e.newvar(f, o.t, true); e.ins(f, I_Null, o.var); }
+                else if (kind == E_Bool) { o.t = d_id(TP_Bool); o.var = e.newvar(f, o.t, true); e.ins(f, I_Bool, o.var, 0, 0, 0, 0, nd.sub); }
+                else { o.t = d_id(TP_String); o.var = e.newvar(f, o.t, true); e.ins(f, I_String, o.var, 0, 0, nd.payload); }
+                close_slot(f, e);
+                set_result<EMIT>(f, i, o);
+                return true;
+            }
+            case E_Operator: {
+                const uint32_t l = f.fc[i], r = f.nx[l];
+                const uint8_t op = SUB(f, i);
+                if (op == OP_Is) { fallback(f); return true; }
+                if (op == OP_And || op == OP_Or) {   // :635-669
+                    Em<EMIT> e = open_slot<EMIT>(f, POS_EXIT(f, l));
+                    Val<EMIT> c = autocast<EMIT>(f, e, child_val<EMIT>(f, l), l, d_id(TP_Bool));
+                    if (failed(f)) return true;
+                    const uint32_t branch_bb = e.b - 1, then_bb = e.b;
+                    uint32_t merge = 0;
+                    if (EMIT) merge = bb_at(f, POS_EXIT(f, r));
+                    if (op == OP_And) e.ins(f, I_Branch, 0, c.var, then_bb, merge); else e.ins(f, I_Branch, 0, c.var, merge, then_bb);
+                    e.newbb(f);
+                    close_slot(f, e);
+                    if (match3(f, f.rt[r], d_id(TP_Bool)) != M_YES) { fallback(f); return true; }   // Q15
+                    Em<EMIT> e2 = open_slot<EMIT>(f, POS_EXIT(f, r));
+                    const uint32_t then_end = e2.b - 1;
+                    e2.ins(f, I_Jump, 0, 0, 0, e2.b);
+                    e2.newbb(f);
+                    Val<EMIT> o; o.t = d_id(TP_Bool); o.info = own_rv(e2.pos, e2.v);
+                    o.var = e2.newvar(f, o.t, true);
+                    e2.ins(f, I_Phi, o.var, c.var, RV<EMIT>(f, r), branch_bb, then_end);
+                    close_slot(f, e2);
+                    set_result<EMIT>(f, i, o);
+                    return true;
+                }
+                // `not` (the left operand is never evaluated, Q9) and the binary builtin / overloaded operators (:603-718)
+                const bool is_not = op == OP_Not;
+                const uint8_t sym = sym_of_op(op);
+                Em<EMIT> e = open_slot<EMIT>(f, POS_EXIT(f, r));
+                Desc at[2]; uint32_t n;
+                if (is_not) { at[0] = f.rt[r]; n = 1; } else { at[0] = f.rt[l]; at[1] = f.rt[r]; n = 2; }
+                for (uint32_t k = 0; k < n; k++) if (at[k] == DESC_NONE || view(f, at[k]).kind == TY_Error) { fallback(f); return true; }
+                const uint32_t fn = lookup_function(f, key_sym(sym), at, n);
+                if (failed(f) || fn == FN_NONE) { fallback(f); return true; }
+                uint32_t fv = 0;
+                if (!fn_builtin(fn)) { fv = e.newvar(f, d_func(fn), true); e.ins(f, I_Function, fv, 0, 0, fn); }
+                Val<EMIT> a0, a1{};
+                if (is_not) a0 = autocast<EMIT>(f, e, child_val<EMIT>(f, r), r, d_id(fn_arg_type(f, fn, 0)));
+                else {
+                    a0 = autocast<EMIT>(f, e, child_val<EMIT>(f, l), l, d_id(fn_arg_type(f, fn, 0)));
+                    a1 = autocast<EMIT>(f, e, child_val<EMIT>(f, r), r, d_id(fn_arg_type(f, fn, 1)));
+                }
+                if (failed(f)) return true;
+                Val<EMIT> o; o.t = d_id(fn_ret(f, fn)); o.info = own_rv(e.pos, e.v);
+                o.var = e.newvar(f, o.t, true);
+                if (fn_builtin(fn)) {
+                    uint16_t opc;
+                    switch (op) {
+                        case OP_Plus: opc = I_Add; break; case OP_Minus: opc = I_Subtract; break; case OP_Times: opc = I_Multiply; break;
+                        case OP_Divide: opc = I_Divide; break; case OP_Modulo: opc = I_Modulo; break; case OP_Equals: opc = I_Equals; break;
+                        case OP_LessThan: opc = I_LessThan; break; case OP_GreaterThan: opc = I_GreaterThan; break;
+                        case OP_LessThanEquals: opc = I_LessThanEquals; break; case OP_Not: opc = I_Not; break; default: opc = I_GreaterThanEquals; break;
+                    }
+                    if (is_not) e.ins(f, I_Not, o.var, a0.var); else e.ins(f, opc, o.var, a0.var, a1.var);
+                } else {
+                    const uint32_t cg = EMIT ? f.carg_base + f.cg[i] : 0u;
+                    if (EMIT) { gst(f.A.cargs + cg, a0.var); if (n > 1) gst(f.A.cargs + cg + 1, a1.var); }
+                    e.ins(f, I_Call, o.var, fv, 0, cg, 0, (uint16_t)n);
+                }
+                close_slot(f, e);
+                set_result<EMIT>(f, i, o);
+                return true;
+            }
+            case E_Cast: {                   // :720-732
+                const uint32_t c = f.fc[i], ty = f.nx[c];
+                Em<EMIT> e = open_slot<EMIT>(f, POS_EXIT(f, ty));
+                const Desc typ = d_id(TID(f, ty));
+                const int ct = can_cast3(f, f.rt[c], typ);
+                if (ct < 0 || view(f, f.rt[c]).kind == TY_Error || view(f, typ).kind == TY_Error) { fallback(f); return true; }
+                Val<EMIT> o; o.t = typ; o.info = own_rv(e.pos, e.v);
+                o.var = e.newvar(f, typ, true);
+                e.ins(f, I_Cast, o.var, RV<EMIT>(f, c), 0, 0, 0, (uint16_t)ct);
+                close_slot(f, e);
+                set_result<EMIT>(f, i, o);
+                return true;
+            }
+            case E_Reference: case E_MutableReference: case E_ArrayReference: case E_MutableArrayReference: {   // :733-748: the child's pointer itself
+                Val<EMIT> o = child_val<EMIT>(f, f.fc[i]);
+                set_result<EMIT>(f, i, o);
+                return true;
+            }
+            case E_Negate: {                 // :749-789
+                const uint32_t c = f.fc[i];
+                const Desc stp = f.rt[c];
+                const uint8_t k = view(f, stp).kind;
+                if (k == TY_Integer8 || k == TY_Integer16 || k == TY_Integer32 || k == TY_Integer64 || k == TY_Offset) {
+                    Em<EMIT> e = open_slot<EMIT>(f, POS_EXIT(f, c));
+                    Val<EMIT> o; o.t = stp; o.info = own_rv(e.pos, e.v);
+                    o.var = e.newvar(f, stp, true);
+                    e.ins(f, I_Negate, o.var, RV<EMIT>(f, c));
+                    close_slot(f, e);
+                    set_result<EMIT>(f, i, o);
+                } else if (k == TY_GenericInteger) {
+                    // folded into the literal (its lane flips the sign); the literal must be what this chain ends in
+                    if (KIND(f, creator_of(f, c)) != E_Integer && !EMIT) { fallback(f); return true; }
+                    set_result<EMIT>(f, i, child_val<EMIT>(f, c));
+                } else fallback(f);
+                return true;
+            }
+            case E_Sizeof: case E_Alignof: {  // :790-801
+                Em<EMIT> e = open_slot<EMIT>(f, POS_ENTER(f, i));
+                Val<EMIT> o; o.t = d_id(TP_Size); o.info = own_rv(e.pos, e.v);
+                o.var = e.newvar(f, o.t, true);
+                e.ins(f, kind == E_Sizeof ? I_Sizeof : I_Alignof, o.var, 0, 0, TID(f, f.fc[i]));
+                close_slot(f, e);
+                set_result<EMIT>(f, i, o);
+                return true;
+            }
+            case E_Parentheses: set_result<EMIT>(f, i, child_val<EMIT>(f, f.fc[i])); return true;
+            default: fallback(f); return true;   // E_Proc and anything unexpected
+        }
+    }
+    // ---- pointers / lvalues (try_generate_pointer_from_expression :985-1088) ----
+    switch (kind) {
+        case E_Variable: {
+            const uint32_t r = f.ref[i], tag = r & RF_TAG, idx = r & RF_VAL;
+            Em<EMIT> e = open_slot<EMIT>(f, POS_ENTER(f, i));
+            Val<EMIT> v{}; bool lv = true;
+            if (tag == RF_LOCAL) {
+                const DefEnt& d = f.defs[idx];
+                if (!EMIT && d.vt == DESC_NONE) return false;   // its type is not known yet
+                v.t = d.vt; v.info = RV_LOCAL | idx; v.var = EMIT ? d.var : 0u;
+                v = try_cast_pointer<EMIT>(f, e, v, pt);
+            } else if (tag == RF_ARG) {
+                v.t = f.args[idx].vt; v.info = RV_ARG | idx; v.var = f.nargs + idx;
+                v = try_cast_pointer<EMIT>(f, e, v, pt);
+            } else if (tag == RF_GLOBAL) {
+                v.t = d_ptr(f, PT_Mutable, d_id(f.S.globals[idx].type_id));
+                v.info = own_rv(e.pos, e.v);
+                v.var = e.newvar(f, v.t, true);
+                e.ins(f, I_GlobalVariable, v.var, 0, 0, idx);
+                v = try_cast_pointer<EMIT>(f, e, v, pt);
+            } else if (tag == RF_CONST) {
+                v.t = d_id(f.S.globals[idx].type_id);
+                v.info = own_rv(e.pos, e.v);
+                v.var = e.newvar(f, v.t, true);
+                e.ins(f, I_GlobalConstant, v.var, 0, 0, idx);
+                lv = false;
+            } else if (tag == RF_FUNC) {
+                v.t = d_func(idx);
+                v.info = own_rv(e.pos, e.v);
+                v.var = e.newvar(f, v.t, true);
+                e.ins(f, I_Function, v.var, 0, 0, idx);
+                lv = false;
+            } else { fallback(f); return true; }
+            if (failed(f)) return true;
+            v = p_result<EMIT>(f, e, v, lv, st);
+            close_slot(f, e);
+            set_result<EMIT>(f, i, v);
+            return true;
+        }
+        case E_VariableDefinition: {         // :1008-1021
+            Em<EMIT> e = open_slot<EMIT>(f, POS_EXIT(f, f.fc[i]));
+            Val<EMIT> v; v.t = f.defs[f.ref[i]].vt; v.info = own_rv(e.pos, e.v);
+            v.var = e.newvar(f, v.t, false);
+            if (!EMIT) f.defs[f.ref[i]].var = v.info;
+            e.ins(f, I_Allocate, v.var);
+            v = try_cast_pointer<EMIT>(f, e, v, pt);
+            if (failed(f)) return true;
+            v = p_result<EMIT>(f, e, v, true, st);
+            close_slot(f, e);
+            set_result<EMIT>(f, i, v);
+            return true;
+        }
+        case E_Dereference: {                // :1022-1026
+            const uint32_t c = f.fc[i];
+            Em<EMIT> e = open_slot<EMIT>(f, POS_EXIT(f, c));
+            Val<EMIT> v = try_cast_pointer<EMIT>(f, e, child_val<EMIT>(f, c), pt);
+            if (failed(f)) return true;
+            v = p_result<EMIT>(f, e, v, true, st);
+            close_slot(f, e);
+            set_result<EMIT>(f, i, v);
+            return true;
+        }
+        case E_Field: {                      // :1027-1030
+            const uint32_t c = f.fc[i];
+            Em<EMIT> e = open_slot<EMIT>(f, POS_EXIT(f, c));
+            Val<EMIT> v = field_access<EMIT>(f, e, child_val<EMIT>(f, c), ND(f, i).payload, pt);
+            if (failed(f)) return true;
+            v = p_result<EMIT>(f, e, v, true, st);
+            close_slot(f, e);
+            set_result<EMIT>(f, i, v);
+            return true;
+        }
+        case E_NamedCall: {
+            const uint32_t r = f.ref[i], tag = r & RF_TAG, idx = r & RF_VAL;
+            const uint32_t n = NCH(f, i);
+            const uint32_t lastc = last_child(f, i);
+            if (tag == RF_CALL) {              // :1031-1045 + get_function_call_variables :1181-1198
+                if (n > MAX_CALL_ARGS) { fallback(f); return true; }
+                Em<EMIT> e = open_slot<EMIT>(f, n ? POS_EXIT(f, lastc) : POS_ENTER(f, i));
+                Desc at[MAX_CALL_ARGS]; uint32_t an[MAX_CALL_ARGS];
+                uint32_t k = 0;
+                for (uint32_t c = f.fc[i]; c != NONE16 && k < MAX_CALL_ARGS; c = f.nx[c], k++) { at[k] = f.rt[c]; an[k] = c; if (at[k] == DESC_NONE || view(f, at[k]).kind == TY_Error) { fallback(f); return true; } }
+                const uint32_t fn = lookup_function(f, key_tok(ND(f, i).payload), at, n);
+                if (failed(f) || fn == FN_NONE || fn_builtin(fn)) { fallback(f); return true; }
+                const uint32_t fv = e.newvar(f, d_func(fn), true);
+                e.ins(f, I_Function, fv, 0, 0, fn);
+                const uint32_t cg = EMIT ? f.carg_base + f.cg[i] : 0u;
+                for (k = 0; k < n; k++) {
+                    Val<EMIT> a = autocast<EMIT>(f, e, child_val<EMIT>(f, an[k]), an[k], d_id(fn_arg_type(f, fn, k)));
+                    if (EMIT) gst(f.A.cargs + cg + k, a.var);
+                }
+                if (failed(f)) return true;
+                Val<EMIT> o; o.t = d_id(fn_ret(f, fn)); o.info = own_rv(e.pos, e.v);
+                o.var = e.newvar(f, o.t, true);
+                e.ins(f, I_Call, o.var, fv, 0, cg, 0, (uint16_t)n);
+                o = p_result<EMIT>(f, e, o, false, st);
+                if (failed(f)) return true;
+                close_slot(f, e);
+                set_result<EMIT>(f, i, o);
+                return true;
+            }
+            // index through a variable (:1046-1052 + generate_ir_for_index :895-967); the indexee is an lvalue
+            if (n != 1) { fallback(f); return true; }
+            Em<EMIT> e = open_slot<EMIT>(f, POS_ENTER(f, i));
+            Val<EMIT> v{};
+            if (tag == RF_LOCAL) {
+                const DefEnt& d = f.defs[idx];
+                if (!EMIT && d.vt == DESC_NONE) return false;
+                v.t = d.vt; v.var = EMIT ? d.var : 0u;
+            } else if (tag == RF_ARG) { v.t = f.args[idx].vt; v.var = f.nargs + idx; }
+            else if (tag == RF_GLOBAL) { v.t = d_ptr(f, PT_Mutable, d_id(f.S.globals[idx].type_id)); v.var = e.newvar(f, v.t, true); e.ins(f, I_GlobalVariable, v.var, 0, 0, idx); }
+            else { fallback(f); return true; }
+            v = try_cast_pointer<EMIT>(f, e, v, pt);
+            if (failed(f)) return true;
+            const Desc indexee_t = pointee(f, v.t);
+            const TView it = view(f, indexee_t);
+            bool is_ptr;
+            if (it.kind == TY_Pointer) {       // a pointer variable: load it, it must be an array pointer
+                Val<EMIT> ld; ld.t = indexee_t; ld.var = e.newvar(f, indexee_t, true); ld.info = 0;
+                e.ins(f, I_Load, ld.var, v.var);
+                v = ld; is_ptr = true;
+                if (it.ptr != PT_Array && it.ptr != PT_ArrayMutable) { fallback(f); return true; }
+            } else if (it.kind == TY_Array) is_ptr = false;
+            else { fallback(f); return true; } // functions through variables, errors
+            close_slot(f, e);
+            Em<EMIT> e2 = open_slot<EMIT>(f, POS_EXIT(f, lastc));
+            const TView vt = view(f, v.t);
+            Val<EMIT> o;
+            o.t = is_ptr ? d_ptr(f, vt.ptr, vt.sub) : d_ptr(f, vt.ptr, it.sub);
+            o.info = own_rv(e2.pos, e2.v);
+            o.var = e2.newvar(f, o.t, true);
+            e2.ins(f, is_ptr ? I_IndexPointer : I_IndexArray, o.var, v.var, RV<EMIT>(f, lastc));
+            o = try_cast_pointer<EMIT>(f, e2, o, pt);
+            if (failed(f)) return true;
+            o = p_result<EMIT>(f, e2, o, true, st);
+            if (failed(f)) return true;
+            close_slot(f, e2);
+            set_result<EMIT>(f, i, o);
+            return true;
+        }
+        case E_Record: {                     // :1064-1078
+            const uint32_t tyn = f.fc[i];
+            Em<EMIT> e = open_slot<EMIT>(f, POS_EXIT(f, tyn));
+            const Desc rec_t = d_id(TID(f, tyn));
+            if (view(f, rec_t).kind != TY_Record) { fallback(f); return true; }
+            Val<EMIT> out; out.t = d_ptr(f, PT_Mutable, rec_t); out.info = own_rv(e.pos, e.v);
+            out.var = e.newvar(f, out.t, true);
+            e.ins(f, I_Allocate, out.var);
+            Val<EMIT> res = out;
+            uint32_t fi = f.nx[tyn];
+            if (fi == NONE16) { res = p_result<EMIT>(f, e, out, true, st); }
+            close_slot(f, e);
+            for (; fi != NONE16; fi = f.nx[fi]) {
+                Em<EMIT> e2 = open_slot<EMIT>(f, POS_EXIT(f, fi));
+                const uint32_t val = f.fc[fi];
+                Val<EMIT> fv = field_access<EMIT>(f, e2, out, ND(f, fi).payload, PT_Mutable);
+                if (failed(f)) return true;
+                e2.ins(f, I_Store, 0, fv.var, RV<EMIT>(f, val));
+                if (f.nx[fi] == NONE16) res = p_result<EMIT>(f, e2, out, true, st);
+                close_slot(f, e2);
+            }
+            if (failed(f)) return true;
+            set_result<EMIT>(f, i, res);
+            return true;
+        }
+        case E_Parentheses: set_result<EMIT>(f, i, child_val<EMIT>(f, f.fc[i])); return true;
+        default: fallback(f); return true;     // E_CallOrIndex
+    }
+}
+
+// ---- block-wide exclusive scan of an LDS array (packed event counters; call-argument counts); returns the total -------
+template <class E> __device__ __forceinline__ uint64_t block_scan(Fn& f, E* a, uint32_t n) {
+    const uint32_t T = f.nthreads, per = (n + T - 1) / T;
+    const uint32_t lo = f.tid * per < n ? f.tid * per : n, hi = lo + per < n ? lo + per : n;
+    uint64_t sum = 0;
+    for (uint32_t k = lo; k < hi; k++) sum += a[k];
+    PAR_SYNC();
+    f.scratch[f.tid] = sum;
+    PAR_SYNC();
+    if (f.tid == 0) { uint64_t run = 0; for (uint32_t k = 0; k < T; k++) { const uint64_t v = f.scratch[k]; f.scratch[k] = run; run += v; } f.scratch[T] = run; }
+    PAR_SYNC();
+    uint64_t run = f.scratch[f.tid];
+    for (uint32_t k = lo; k < hi; k++) { const uint64_t v = a[k]; a[k] = (E)run; run += v; }
+    const uint64_t total = f.scratch[T];
+    PAR_SYNC();
+    return total;
+}
+
+// One function per workgroup.
+template <bool EMIT> __device__ void lower_function(Fn& f) {
+    const uint32_t nn = f.nn, tid = f.tid, T = f.nthreads;
+    if (tid == 0) { for (uint32_t k = 0; k < MI_WORDS; k++) f.misc[k] = 0; }
+    PAR_SYNC();
+    // ---- structure ----
+    for (uint32_t i = tid; i < nn; i += T) {
+        const opusfe_node n = ND(f, i);
+        f.kn[i] = (uint32_t)n.kind | ((uint32_t)n.sub << 8) | ((uint32_t)n.nchild << 16);
+        const uint32_t fc = n.first_child == OPUSFE_NONE ? NONE16 : n.first_child - f.dn, nx = n.next == OPUSFE_NONE ? NONE16 : n.next - f.dn;
+        if ((fc != NONE16 && fc >= nn) || (nx != NONE16 && nx >= nn)) fallback(f);      // links must stay inside the function
+        f.fc[i] = (uint16_t)fc; f.nx[i] = (uint16_t)nx;
+        f.pa[i] = NONE16; f.st[i] = 0; f.ref[i] = 0; f.rvi[i] = 0; f.rt[i] = DESC_NONE; f.cg[i] = 0; f.rk[i] = 0; f.sz[i] = 0; f.pe[i] = 0;
+        f.cnt[2 * i] = 0; f.cnt[2 * i + 1] = 0; f.tail[2 * i] = TAIL_NONE; f.tail[2 * i + 1] = TAIL_NONE;
+        if (f.A.undefined_flag[f.dn + i]) fallback(f);                                // UndefinedType somewhere in the function
+    }
+    PAR_SYNC();
+    if (failed(f)) return;
+    for (uint32_t i = tid; i < nn; i += T) { uint32_t guard = 0; for (uint32_t c = f.fc[i]; c != NONE16 && guard <= nn; c = f.nx[c], guard++) f.pa[c] = (uint16_t)i; if (guard > nn) fallback(f); }
+    PAR_SYNC();
+    if (failed(f)) return;
+    // subtree sizes, bottom-up
+    for (uint32_t round = 0; round <= nn; round++) {
+        bool progress = false;
+        for (uint32_t i = tid; i < nn; i += T) {
+            if (f.st[i] & ST_SIZED) continue;
+            uint32_t size = 1; bool ready = true;
+            for (uint32_t c = f.fc[i]; c != NONE16; c = f.nx[c]) { if (!(f.st[c] & ST_SIZED)) { ready = false; break; } size += f.sz[c]; }
+            if (!ready) continue;
+            f.sz[i] = (uint16_t)size;
+            par_fence();
+            f.st[i] |= ST_SIZED; progress = true;
+        }
+        if (!par_sync_or(progress)) break;
+    }
+    if (!(f.st[0] & ST_SIZED) || f.sz[0] != nn) { fallback(f); }                       // every node must hang under the root (no cycles, no strays)
+    PAR_SYNC();
+    if (failed(f)) return;
+    // pre-order rank, depth and evaluation context, top-down: a node that has its own hands them to its children
+    if (tid == 0) { f.rk[0] = 0; f.pe[0] = 0; f.st[0] |= ST_CTX; }
+    PAR_SYNC();
+    for (uint32_t round = 0; round <= nn; round++) {
+        bool progress = false;
+        for (uint32_t p = tid; p < nn; p += T) {
+            const uint32_t ps = f.st[p];
+            if (!(ps & ST_CTX) || (ps & ST_SPREAD)) continue;
+            progress = true;
+            const uint8_t pk = KIND(f, p);
+            const uint32_t pmode = ps & ST_MODE_MASK, ppt = (ps >> ST_PT_SHIFT) & 3u, pexp = (ps & ST_EXP_MASK) >> ST_EXP_SHIFT;
+            const uint32_t pdepth = 2u * f.rk[p] - f.pe[p];
+            uint32_t r = (uint32_t)f.rk[p] + 1u;
+            bool first = true;
+            for (uint32_t i = f.fc[p]; i != NONE16; i = f.nx[i]) {
+                const uint8_t k = KIND(f, i);
+                uint32_t m = 0;      // 0: not an evaluated expression
+                auto E = [&](uint32_t exp) { return (uint32_t)ST_MODE_E | (exp << ST_EXP_SHIFT); };
+                auto P = [&](uint32_t pt_, uint32_t flags) { return (uint32_t)ST_MODE_P | (pt_ << ST_PT_SHIFT) | flags; };
+                const bool is_expr = k >= E_Integer && k <= E_Parentheses;
+                bool dead = (ps & ST_DEAD) != 0 || (pk == E_Operator && SUB(f, p) == OP_Not && first);   // Q9: the left operand of `not` is never evaluated
+                if (is_expr && !dead) {
+                    switch (pk) {
+                        case S_Expression: case S_VariableDefinition: m = E(EXP_NONE); break;
+                        case S_Assignment: m = first ? P(PT_Mutable, ST_MUSTLV) : E(EXP_ASSIGN); break;
+                        case S_Return: m = E(EXP_RET); break;
+                        case S_If: case S_While: m = E(EXP_BOOL); break;
+                        case S_For: m = E(EXP_NONE); break;
+                        case E_Operator: { const uint8_t op = SUB(f, p); m = op == OP_Is ? E(EXP_NONE) : (op == OP_And || op == OP_Or) ? E(EXP_BOOL) : E(EXP_GENINT); break; }
+                        case E_Cast: case E_Dereference: m = E(EXP_NONE); break;
+                        case E_Reference: m = P(PT_Reference, ST_MUSTLV); break;
+                        case E_MutableReference: m = P(PT_Mutable, ST_MUSTLV); break;
+                        case E_ArrayReference: m = P(PT_Array, ST_MUSTLV); break;
+                        case E_MutableArrayReference: m = P(PT_ArrayMutable, ST_MUSTLV); break;
+                        case E_Negate: m = E(pmode == ST_MODE_E ? pexp : (uint32_t)EXP_NONE); break;
+                        case E_Parentheses: m = pmode == ST_MODE_E ? E(pexp) : P(ppt, ps & (ST_DEREF | ST_MUSTLV)); break;
+                        case E_Field: m = P(ppt, ST_MUSTLV); break;                         // (a field node is always in pointer mode, see below)
+                        case E_NamedCall: m = E(EXP_ARG); break;                            // <integer> for a call, size for an index: known once the name is resolved
+                        case X_FieldInit: m = E(EXP_FIELD); break;
+                        default: fallback(f); break;                                         // E_CallOrIndex
+                    }
+                    // expressions that are lvalue-shaped are lowered through the pointer path and loaded (generate_ir.rs:577-585);
+                    // everything else asked for as a pointer is an rvalue (:1082-1087)
+                    const bool pkind = k == E_Variable || k == E_Dereference || k == E_VariableDefinition || k == E_Field || k == E_NamedCall || k == E_CallOrIndex || k == E_Record;
+                    if ((m & ST_MODE_MASK) == ST_MODE_E && pkind) m = P(PT_Reference, ST_DEREF);
+                    else if ((m & ST_MODE_MASK) == ST_MODE_P && !pkind && k != E_Parentheses) {
+                        if (m & ST_MUSTLV) fallback(f);                                      // InvalidLvalue
+                        m = E(EXP_NONE);
+                    }
+                }
+                f.rk[i] = (uint16_t)r;
+                f.pe[i] = (uint16_t)(2u * r - (pdepth + 1u));
+                r += f.sz[i];
+                par_fence();
+                f.st[i] = (f.st[i] & ST_SIZED) | m | (dead ? (uint32_t)ST_DEAD : 0u) | ST_CTX;
+                first = false;
+            }
+            f.st[p] = ps | ST_SPREAD;
+        }
+        if (!par_sync_or(progress)) break;
+    }
+    if (failed(f)) return;
+    // ---- arguments and local definitions ----
+    if (tid == 0) {
+        uint32_t a = f.fc[0], k = 0;
+        while (a != NONE16 && KIND(f, a) == X_NamedType) {
+            if (k >= MAX_ARGS) { fallback(f); break; }
+            const opusfe_token t = f.S.tok[ND(f, a).payload];
+            if (t.kind != T_Identifier) { fallback(f); break; }                         // a symbol as a variable name (sym_locals)
+            ArgEnt e; e.hash = t.payload; e.low = t.low; e.len = t.len; e.pad = 0; e.vt = d_ptr(f, PT_Mutable, d_id(TID(f, f.fc[a])));
+            f.args[k++] = e;
+            a = f.nx[a];
+        }
+        if (k != f.nargs) fallback(f);
+    }
+    for (uint32_t i = tid; i < nn; i += T) {
+        const uint8_t k = KIND(f, i);
+        if (!(f.st[i] & ST_CTX)) { fallback(f); continue; }
+        if (k == S_VariableDefinition || k == E_VariableDefinition || k == S_For) {
+            if (f.st[i] & ST_DEAD) { fallback(f); continue; }                           // a definition in code that is never evaluated
+            const uint32_t slot = atomicAdd(&f.misc[MI_NDEFS], 1u);
+            if (slot >= f.A.maxdef) { fallback(f); continue; }
+            const opusfe_token t = f.S.tok[ND(f, i).payload];
+            if (t.kind != T_Identifier) { fallback(f); continue; }
+            DefEnt d; d.hash = t.payload; d.low = t.low; d.len = t.len; d.node = i; d.var = 0; d.pad = 0; d.vt = DESC_NONE;
+            if (k == S_For) { uint32_t cond, tb, eb; blocks_of(f, i, &cond, &tb, &eb); if (tb == NONE16) { fallback(f); continue; } d.dpoint = RANK(f, tb); d.send = RANK_END(f, tb); }
+            else {
+                // visible from behind the statement (`var x = e`: e is lowered first) / from the expression on (`var x T`), to the
+                // end of the enclosing block (generate_ir.rs:176-203)
+                uint32_t blk = f.pa[i];
+                while (blk != NONE16 && KIND(f, blk) != X_Block) blk = f.pa[blk];
+                if (blk == NONE16) { fallback(f); continue; }
+                d.dpoint = k == S_VariableDefinition ? RANK_END(f, i) : RANK(f, i) + 1;
+                d.send = RANK_END(f, blk);
+                if (k == E_VariableDefinition) d.vt = d_ptr(f, PT_Mutable, d_id(TID(f, f.fc[i])));
+            }
+            f.defs[slot] = d;
+            f.ref[i] = slot;
+        }
+        if (k == S_Break || k == S_Continue) {
+            const uint32_t loop = enclosing_loop(f, i);
+            f.ref[i] = loop;
+            if (loop != NONE16 && k == S_Break) atomicOr(&f.st[loop], (uint32_t)ST_HASBREAK);
+        }
+    }
+    PAR_SYNC();
+    if (failed(f)) return;
+    {   // shadowing (generate_ir.rs:255,410,1009) and redefinition of an argument (Q17): the sequential machine handles those
+        const uint32_t nd = f.misc[MI_NDEFS];
+        for (uint32_t a = tid; a < nd; a += T) {
+            const DefEnt da = f.defs[a];
+            for (uint32_t b = 0; b < nd; b++) {
+                if (b == a) continue;
+                const DefEnt& db = f.defs[b];
+                if (db.hash != da.hash || db.len != da.len || !bytes_eq(f, da.low, db.low, da.len)) continue;
+                // is a in scope when b's shadow check runs?  (a `var` statement checks after its initialiser, a `for` after its
+                // iteree, a `var x T` expression when it is reached)
+                const uint8_t bk = KIND(f, db.node);
+                const uint32_t at = (bk == S_VariableDefinition || bk == S_For) ? db.dpoint - 1 : RANK(f, db.node);
+                if (at >= da.dpoint && at < da.send) fallback(f);
+            }
+            for (uint32_t k = 0; k < f.nargs; k++) { const ArgEnt& g = f.args[k]; if (g.hash == da.hash && g.len == da.len && bytes_eq(f, g.low, da.low, da.len)) fallback(f); }
+        }
+        for (uint32_t a = tid; a < f.nargs; a += T) for (uint32_t b = 0; b < a; b++) { const ArgEnt& x = f.args[a]; const ArgEnt& y = f.args[b]; if (x.hash == y.hash && x.len == y.len && bytes_eq(f, x.low, y.low, x.len)) fallback(f); }
+    }
+    // ---- names ----
+    for (uint32_t i = tid; i < nn; i += T) {
+        const uint8_t k = KIND(f, i);
+        if ((k != E_Variable && k != E_NamedCall) || (f.st[i] & ST_DEAD)) continue;
+        const uint32_t name_tok = ND(f, i).payload;
+        const opusfe_token t = f.S.tok[name_tok];
+        if (t.kind != T_Identifier) { fallback(f); continue; }
+        const uint32_t local = find_local(f, t, i);
+        const uint32_t slot = name_find(f.S, key_tok(name_tok));
+        if (k == E_NamedCall && slot_has_functions(f, slot)) {
+            if (local != RF_NONE) { fallback(f); continue; }      // a local shadows the functions of that name (:1152-1158)
+            f.ref[i] = RF_CALL | (slot & RF_VAL);
+            f.cg[i] = (uint16_t)NCH(f, i);
+            continue;
+        }
+        if (local != RF_NONE) { f.ref[i] = local; continue; }
+        uint32_t r = RF_NONE;
+        if (slot != OPUSFE_NONE) {
+            const NameSlot sl = f.S.slots[slot];
+            uint32_t nfn = 0, only = 0;
+            for (uint32_t j = sl.count; j > 0; j--) {
+                const NameEntry e = f.S.entries[sl.offset + j - 1];
+                const uint32_t ek = e.kind_index >> 30;
+                if (ek == NK_GLOBAL && r == RF_NONE) { const uint32_t gid = e.kind_index & 0x3FFFFFFFu; r = (f.S.globals[gid].is_const ? RF_CONST : RF_GLOBAL) | gid; }
+                if (ek == NK_FUNCTION) { nfn++; only = e.kind_index & 0x3FFFFFFFu; }
+            }
+            if (r == RF_NONE && nfn == 1) r = RF_FUNC | only;
+        }
+        if (r == RF_NONE || (k == E_NamedCall && ((r & RF_TAG) == RF_CONST || (r & RF_TAG) == RF_FUNC))) { fallback(f); continue; }
+        f.ref[i] = r;
+    }
+    // operator calls and `for` reserve their call arguments too (user overloads only use them; sized for the worst case)
+    for (uint32_t i = tid; i < nn; i += T) {
+        const uint8_t k = KIND(f, i);
+        if (k == E_Operator && !(f.st[i] & ST_DEAD)) { const uint8_t sym = sym_of_op(SUB(f, i)); if ((f.user_syms >> sym) & 1) f.cg[i] = 2; }
+        if (k == S_For) f.cg[i] = 3;
+    }
+    PAR_SYNC();
+    if (failed(f)) return;
+    // ---- types, counts (bottom-up fixpoint) ----
+    for (uint32_t round = 0; round <= nn + 1; round++) {
+        bool progress = false;
+        for (uint32_t i = tid; i < nn; i += T) {
+            const uint32_t s = f.st[i];
+            if (s & (ST_DONE | ST_DEAD)) continue;
+            if (KIND(f, i) == S_For && !(s & ST_STAGE1)) {       // the loop variable gets its type as soon as the iteree has one
+                uint32_t cond, tb, eb; blocks_of(f, i, &cond, &tb, &eb);
+                if (cond != NONE16 && (f.st[cond] & ST_DONE)) {
+                    const Desc vt = for_variable_type(f, i);
+                    if (!failed(f)) { f.defs[f.ref[i]].vt = vt; par_fence(); f.st[i] |= ST_STAGE1; progress = true; }
+                }
+            }
+            if (!operands_done(f, i)) continue;
+            if (visit<false>(f, i)) { par_fence(); f.st[i] |= ST_DONE; progress = true; }
+        }
+        if (!par_sync_or(progress && !failed(f))) break;
+    }
+    if (failed(f)) return;
+    if (!(f.st[0] & ST_DONE)) { fallback(f); return; }
+    // ---- scans: Euler-order exclusive prefix of the event counters; call-argument slots in node order ----
+    {   // the packed 16-bit fields must not carry into each other: check the four sums first
+        uint32_t sv = 0, stt = 0, si = 0, sb = 0;
+        for (uint32_t p = tid; p < 2 * nn; p += T) { const Cnt4 c = unpack4(f.cnt[p]); sv += c.v; stt += c.t; si += c.i; sb += c.b; }
+        if (sv) atomicAdd(&f.misc[MI_SUM_V], sv);
+        if (stt) atomicAdd(&f.misc[MI_SUM_T], stt);
+        if (si) atomicAdd(&f.misc[MI_SUM_I], si);
+        if (sb) atomicAdd(&f.misc[MI_SUM_B], sb);
+        PAR_SYNC();
+        if (f.misc[MI_SUM_V] > 0xFFF0u || f.misc[MI_SUM_T] > 0xFFF0u || f.misc[MI_SUM_I] > 0xFFF0u || f.misc[MI_SUM_B] > 0xFFF0u) { fallback(f); return; }
+    }
+    const Cnt4 tot = unpack4(block_scan(f, f.cnt, 2 * nn));
+    const uint32_t tot_cargs = (uint32_t)block_scan(f, f.cg, nn);
+    if (tot_cargs > 0xFFF0u) { fallback(f); return; }
+    if (!EMIT) {
+        if (tid == 0) {
+            FuncIr r{};
+            r.def_node = f.dn; r.func = f.fidx; r.n_vars = tot.v; r.n_instrs = tot.i; r.n_bbs = tot.b; r.n_types = tot.t; r.n_cargs = tot_cargs; r.n_errs = 0; r.status = DS_OK;
+            f.A.out[f.fidx] = r;
+        }
+        return;
+    }
+    if (tot.v != f.n_vars_tot || tot.i != f.n_instrs_tot || tot.b != f.n_bbs_tot || tot.t != f.n_types_tot || tot_cargs != f.n_cargs_tot) { f.misc[MI_BAD] = 1; return; }
+    // ---- result variables: every node learns the id of the variable that holds its result ----
+    {
+        const uint32_t nd = f.misc[MI_NDEFS];
+        for (uint32_t k = tid; k < nd; k += T) { const uint32_t r = f.defs[k].var; f.defs[k].var = unpack4(f.cnt[(r >> 12) & 0x1FFFF]).v + (r & 0xFFF); }
+    }
+    PAR_SYNC();
+    for (uint32_t i = tid; i < nn; i += T) {
+        const uint32_t r = f.rvi[i], tag = r & RV_TAG;
+        if (tag == RV_OWN) f.rvi[i] = RV_RESOLVED | (unpack4(f.cnt[(r >> 12) & 0x1FFFF]).v + (r & 0xFFF));
+        else if (tag == RV_LOCAL) f.rvi[i] = RV_RESOLVED | f.defs[r & RV_VAL].var;
+        else if (tag == RV_ARG) f.rvi[i] = RV_RESOLVED | (f.nargs + (r & RV_VAL));
+    }
+    PAR_SYNC();
+    for (uint32_t i = tid; i < nn; i += T) {
+        uint32_t r = f.rvi[i];
+        if ((r & RV_TAG) != RV_PASS) continue;
+        for (uint32_t guard = 0; guard < nn && (r & RV_TAG) == RV_PASS; guard++) r = f.rvi[r & 0xFFFF];
+        if ((r & RV_TAG) != RV_RESOLVED) { f.misc[MI_BAD] = 1; continue; }
+        f.rvi[i] = r;
+    }
+    PAR_SYNC();
+    // ---- emit ----
+    for (uint32_t i = tid; i < nn; i += T) if (!(f.st[i] & ST_DEAD)) visit<true>(f, i);
+    PAR_SYNC();
+}
+
+// One workgroup per function of `list` (definition indices).  COUNT: FuncIr counts (or DS_FALLBACK).  EMIT: dense results.
+template <int THREADS, bool EMIT>
+__global__ __launch_bounds__(THREADS) void k_lower_par(SemView S, ParArgs A) {
+    const uint32_t slot = blockIdx.x;
+    if (slot >= A.n_list) return;
+    const uint32_t d = A.list ? A.list[slot] : slot;
+    const uint32_t dn = A.def_nodes[d];
+    if (S.nodes[dn].kind != D_Function) return;
+    const uint32_t fidx = A.def_excl[d].funcs;
+    const uint32_t dn_end = d + 1 < A.n_defs ? A.def_nodes[d + 1] : A.n_nodes;
+    const uint32_t nn = dn_end - dn;
+    if (nn > A.nmax || nn < 2) return;                       // stays DS_FALLBACK (k_par_init)
+    Fn f;
+    f.S = S; f.A = A; f.dn = dn; f.nn = nn; f.fidx = fidx; f.F = S.funcs[fidx]; f.nargs = f.F.nargs; f.user_syms = *A.user_syms;
+    f.tid = threadIdx.x; f.nthreads = blockDim.x;
+    f.var_base = f.instr_base = f.bb_base = f.type_base = f.carg_base = 0;
+    f.n_vars_tot = f.n_instrs_tot = f.n_bbs_tot = f.n_types_tot = f.n_cargs_tot = 0;
+    if (EMIT) {
+        const FuncIr r = A.out[fidx];
+        if (A.fb_flag[fidx]) return;                         // lowered by the sequential machine
+        f.var_base = r.var_base; f.instr_base = r.instr_base; f.bb_base = r.bb_base; f.type_base = r.type_base; f.carg_base = r.carg_base;
+        f.n_vars_tot = r.n_vars; f.n_instrs_tot = r.n_instrs; f.n_bbs_tot = r.n_bbs; f.n_types_tot = r.n_types; f.n_cargs_tot = r.n_cargs;
+    }
+    // carve the dynamic LDS block (same order as lds_bytes)
+    uint8_t* base = (uint8_t*)PAR_LDS_BASE();
+    const uint32_t nmax = A.nmax;
+    f.rt = (uint64_t*)base; base += 8ull * nmax;
+    f.cnt = (uint64_t*)base; base += 16ull * nmax;
+    f.kn = (uint32_t*)base; base += 4ull * nmax;
+    f.st = (uint32_t*)base; base += 4ull * nmax;
+    f.ref = (uint32_t*)base; base += 4ull * nmax;
+    f.rvi = (uint32_t*)base; base += 4ull * nmax;
+    f.fc = (uint16_t*)base; base += 2ull * nmax;
+    f.nx = (uint16_t*)base; base += 2ull * nmax;
+    f.pa = (uint16_t*)base; base += 2ull * nmax;
+    f.rk = (uint16_t*)base; base += 2ull * nmax;
+    f.sz = (uint16_t*)base; base += 2ull * nmax;
+    f.pe = (uint16_t*)base; base += 2ull * nmax;
+    f.cg = (uint16_t*)base; base += 2ull * nmax;
+    f.tail = (uint8_t*)base; base += 2ull * nmax;
+    base = (uint8_t*)(((uintptr_t)base + 7) & ~(uintptr_t)7);
+    f.defs = (DefEnt*)base; base += sizeof(DefEnt) * A.maxdef;
+    f.args = (ArgEnt*)base; base += sizeof(ArgEnt) * MAX_ARGS;
+    f.misc = (uint32_t*)base; base += 4 * MI_WORDS;
+    base = (uint8_t*)(((uintptr_t)base + 7) & ~(uintptr_t)7);
+    f.scratch = (uint64_t*)base;
+    lower_function<EMIT>(f);
+    PAR_SYNC();
+    if (f.tid == 0) {
+        if (EMIT) { if (f.misc[MI_BAD] || f.misc[MI_FB]) atomicMax(A.status, (uint32_t)DS_INTERNAL_CAPACITY); }   // the two passes must agree
+        else if (f.misc[MI_FB]) { FuncIr r{}; r.def_node = dn; r.func = fidx; r.status = DS_FALLBACK; r.pad = f.misc[MI_WHY]; A.out[fidx] = r; }
+    }
+}
+
+// every function starts as "declined": the count pass overwrites the ones it lowers
+__global__ void k_par_init(const opusfe_node* __restrict__ nodes, const uint32_t* __restrict__ def_nodes, uint32_t n_defs, const DefCnt* __restrict__ def_excl, FuncIr* __restrict__ out) {
+    const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= n_defs) return;
+    const uint32_t dn = def_nodes[d];
+    const uint8_t k = nodes[dn].kind;
+    if (k != D_Function && k != D_Extern) return;
+    FuncIr r{}; r.def_node = dn; r.func = def_excl[d].funcs; r.status = k == D_Function ? (uint32_t)DS_FALLBACK : (uint32_t)DS_OK;
+    out[r.func] = r;
+}
+
+}  // namespace par
+}  // namespace opusfe

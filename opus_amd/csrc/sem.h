@@ -556,6 +556,15 @@ __global__ void k_sem_resolve_types(const uint8_t* __restrict__ src, const opusf
     types[id] = r;
 }
 
+// the pointer-to-primitive table behind the parse-tree types: id = base + PtrKind * TP_COUNT + primitive.  The node-parallel
+// lowering (lower_par.h) names `@mut int32`, `@int32`, ... by these ids instead of creating a record per use.
+__global__ void k_sem_pp_types(TypeRec* __restrict__ pp) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 4 * TP_COUNT) return;
+    TypeRec r{}; r.kind = TY_Pointer; r.ptr = (uint8_t)(i / TP_COUNT); r.sub = i % TP_COUNT; r.alias = OPUSFE_NONE;
+    pp[i] = r;
+}
+
 struct SemErr { uint32_t kind, low, len; };
 // compile.rs:124-152 order
 enum SErrKind : uint32_t { SE_ParseError, SE_UndefinedVariable, SE_ShadowedName, SE_UndefinedFunction, SE_NoOverloadForFunction, SE_AmbiguousOverload,

@@ -178,7 +178,7 @@ void emu_lower(EmuUnit& E) {
     emu_launch(k_sem_type_flags, grid_for(n_nodes, 256), 256, nodes, n_nodes, slot_of_node.data());
     uint32_t gt = 0;
     for (uint32_t i = 0; i < n_nodes; i++) { uint32_t f = slot_of_node[i]; slot_of_node[i] = gt; gt += f; }
-    const uint32_t n_funcs = dt.funcs, n_globals = dt.globals, n_named = dt.named, n_gtypes = TP_COUNT + gt;
+    const uint32_t n_funcs = dt.funcs, n_globals = dt.globals, n_named = dt.named, n_gt0 = TP_COUNT + gt, pp_base = n_gt0, n_gtypes = n_gt0 + par::PP_COUNT;
     uint32_t n_slots = 16; while (n_slots < 2ull * n_named + 16) n_slots <<= 1;
     NameSlot* slots = exact<NameSlot>(n_slots);
     NameEntry* entries = exact<NameEntry>(n_named + 1);
@@ -189,63 +189,84 @@ void emu_lower(EmuUnit& E) {
     { uint32_t run = 0; for (uint32_t i = 0; i < n_slots; i++) { uint32_t c = slot_off[i]; slot_off[i] = run; run += c; } }
     emu_launch(k_sem_table_fill, grid_for(n_defs, 256), 256, nodes, def_nodes, n_defs, def_excl.data(), def_slot.data(), slot_off.data(), slots, entries);
     emu_launch(k_sem_table_sort, grid_for(n_slots, 256), 256, slots, n_slots, slot_off.data(), entries);
-    const uint64_t type_cap = (uint64_t)n_gtypes + (uint64_t)CAP_TYPES * n_nodes + (uint64_t)CAP_CONST * n_funcs + CAP_CONST;
-    TypeRec* types = exact<TypeRec>(type_cap);
+    TypeRec* gtypes = exact<TypeRec>(n_gtypes);
     R->tid_of_node.assign(n_nodes, 0);
     std::vector<uint8_t> undefined_flag(n_nodes);
-    std::vector<uint32_t> ph_def(n_gtypes), ph_prev(n_gtypes);
+    std::vector<uint32_t> ph_def(n_gt0), ph_prev(n_gt0);
     R->funcrecs.assign(n_funcs, FuncRec{}); R->globals.assign(n_globals, GlobalRec{});
     emu_launch(k_sem_resolve_types, grid_for(std::max<uint32_t>(n_nodes, TP_COUNT), 256), 256, E.src.data(), tok, nodes, n_nodes, slot_of_node.data(), slots, n_slots - 1,
-               entries, R->tid_of_node.data(), types, undefined_flag.data(), ph_def.data(), ph_prev.data());
+               entries, R->tid_of_node.data(), gtypes, undefined_flag.data(), ph_def.data(), ph_prev.data());
+    emu_launch(k_sem_pp_types, 1, 128, gtypes + pp_base);
     uint32_t finerr = 0;
     emu_launch(k_sem_finalize, grid_for(n_defs, 256), 256, nodes, def_nodes, n_defs, def_excl.data(), R->tid_of_node.data(), undefined_flag.data(), ph_def.data(), ph_prev.data(), n_nodes,
-               types, R->funcrecs.data(), R->globals.data(), &finerr);
+               gtypes, R->funcrecs.data(), R->globals.data(), &finerr);
     R->n_funcs = n_funcs; R->n_globals = n_globals; R->n_gtypes = n_gtypes;
     if (finerr) {
         std::vector<uint32_t> fin_cnt(n_defs);
         emu_launch(k_sem_fin_count, grid_for(n_defs, 256), 256, nodes, def_nodes, n_defs, (const uint32_t*)R->tid_of_node.data(), (const uint8_t*)undefined_flag.data(),
-                   (const uint32_t*)ph_def.data(), (const uint32_t*)ph_prev.data(), n_nodes, (const TypeRec*)types, fin_cnt.data());
+                   (const uint32_t*)ph_def.data(), (const uint32_t*)ph_prev.data(), n_nodes, (const TypeRec*)gtypes, fin_cnt.data());
         { uint32_t run = 0; for (uint32_t d = 0; d < n_defs; d++) { uint32_t c = fin_cnt[d]; fin_cnt[d] = run; run += c; } }
         SemErr* errs = exact<SemErr>(finerr);   // exact-size block: an emit beyond the counted total is an ASan error
         emu_launch(k_sem_fin_emit, grid_for(n_defs, 256), 256, nodes, def_nodes, n_defs, (const uint32_t*)R->tid_of_node.data(), (const uint8_t*)undefined_flag.data(),
-                   (const uint32_t*)ph_def.data(), (const uint32_t*)ph_prev.data(), n_nodes, (const TypeRec*)types, (const uint32_t*)fin_cnt.data(), errs);
+                   (const uint32_t*)ph_def.data(), (const uint32_t*)ph_prev.data(), n_nodes, (const TypeRec*)gtypes, (const uint32_t*)fin_cnt.data(), errs);
         R->errs.assign(errs, errs + finerr); R->n_errs = finerr;
         free(errs);
-        R->n_sem_errors = finerr; u.status = OPUSFE_SEMANTIC; free(slots); free(entries); free(types); return;
+        R->n_sem_errors = finerr; u.status = OPUSFE_SEMANTIC; free(slots); free(entries); free(gtypes); return;
     }
-    if (n_funcs == 0) { free(slots); free(entries); free(types); return; }
-    LowerBuffers B{};
-    B.vars = exact<opusfe_variable>(lower_base(CAP_VARS, n_nodes, n_funcs) + CAP_CONST);
-    const uint64_t icap = lower_base(CAP_INSTRS, n_nodes, n_funcs) + CAP_CONST;
-    B.instrs = exact<opusfe_instr>(icap); B.ibb = exact<uint32_t>(icap); B.irank = exact<uint32_t>(icap);
-    const uint64_t bcap = lower_base(CAP_BBS, n_nodes, n_funcs) + CAP_CONST;
-    B.bbcnt = exact<uint32_t>(bcap); B.bblast = exact<uint32_t>(bcap);
-    B.cargs = exact<uint32_t>(lower_base(CAP_CARGS, n_nodes, n_funcs) + CAP_CONST);
-    const uint64_t lcap = lower_base(CAP_LOCALS, n_nodes, n_funcs) + CAP_CONST;
-    B.lname = exact<uint32_t>(lcap); B.lvar = exact<uint32_t>(lcap); B.lstack = exact<uint32_t>(lcap);
-    B.frames = exact<LFrame>(lower_base(CAP_FRAMES, n_nodes, n_funcs) + CAP_CONST);
-    B.errs = exact<SemErr>(lower_base(CAP_ERRS, n_nodes, n_funcs) + CAP_CONST);
-    B.type_sparse_base = n_gtypes;
-    SemView S{E.src.data(), tok, u.h_val64.data(), nodes, R->tid_of_node.data(), types, slots, n_slots - 1, entries, R->funcrecs.data(), R->globals.data(), n_gtypes};
+    if (n_funcs == 0) { free(slots); free(entries); free(gtypes); return; }
+    // node-parallel count pass (lower_par.h), one emulated lane per function; EMU_PAR_NMAX / EMU_LOWER_SEQ steer what falls back
+    SemView S{E.src.data(), tok, u.h_val64.data(), nodes, R->tid_of_node.data(), gtypes, slots, n_slots - 1, entries, R->funcrecs.data(), R->globals.data(), n_gtypes};
     R->funcs.assign(n_funcs, FuncIr{});
     uint32_t lstatus[2] = {0, 0};
     uint64_t user_syms = 0;
     emu_launch(k_sem_user_syms, 1, 1, S, &user_syms);
-    emu_launch(k_lower_functions, grid_for(n_defs, 64), 64, S, B, (const uint8_t*)undefined_flag.data(), def_nodes, n_defs, n_nodes, (uint32_t)u.n_tokens, (const DefCnt*)def_excl.data(),
-               R->funcs.data(), lstatus, (uint64_t*)nullptr, (const uint64_t*)&user_syms, (const uint32_t*)nullptr);
+    emu_launch(par::k_par_init, grid_for(n_defs, 256), 256, nodes, def_nodes, n_defs, (const DefCnt*)def_excl.data(), R->funcs.data());
+    par::ParArgs PA{};
+    PA.def_nodes = def_nodes; PA.n_defs = n_defs; PA.n_nodes = n_nodes; PA.def_excl = def_excl.data(); PA.undefined_flag = undefined_flag.data(); PA.user_syms = &user_syms;
+    PA.pp_base = pp_base; PA.out = R->funcs.data(); PA.status = lstatus;
+    PA.list = nullptr; PA.n_list = n_defs; PA.nmax = getenv("EMU_PAR_NMAX") ? (uint32_t)atoi(getenv("EMU_PAR_NMAX")) : 2048u; PA.maxdef = getenv("EMU_PAR_MAXDEF") ? (uint32_t)atoi(getenv("EMU_PAR_MAXDEF")) : 256u;
+    const bool seq_only = getenv("EMU_LOWER_SEQ") != nullptr;
+    const size_t lds = par::lds_bytes(PA.nmax, PA.maxdef, 1);
+    if (!seq_only) {
+        par::g_emu_lds = (uint32_t*)malloc(lds);
+        memset(par::g_emu_lds, 0xA5, lds);
+        emu_launch((par::k_lower_par<64, false>), n_defs, 1, S, PA);
+        free(par::g_emu_lds); par::g_emu_lds = nullptr;
+    }
+    std::vector<uint32_t> fb_flag(n_funcs);
+    std::vector<FbIdx> fbx(n_funcs);
+    emu_launch(k_fb_mark, grid_for(n_defs, 256), 256, (const FuncIr*)R->funcs.data(), n_funcs, def_nodes, n_defs, n_nodes, (const DefCnt*)def_excl.data(), nodes, fb_flag.data(), fbx.data());
+    FbIdx fbt{0, 0};
+    for (uint32_t i = 0; i < n_funcs; i++) { FbIdx c = fbx[i]; fbx[i] = fbt; fbt = OpAddFbIdx()(fbt, c); }
+    const uint32_t fb_nodes = fbt.nodes, fb_funcs = fbt.funcs;
+    R->n_fallback = fb_funcs;
+    if (getenv("EMU_VERBOSE")) { fprintf(stderr, "functions lowered by the sequential machine: %u of %u\n", fb_funcs, n_funcs); for (auto& fr : R->funcs) if (fr.status == par::DS_FALLBACK) fprintf(stderr, "  function %u (node %u): declined at lower_par.h:%u\n", fr.func, fr.def_node, fr.pad); }
+    if (getenv("EMU_REQUIRE_PAR") && fb_funcs) { fprintf(stderr, "emu: %u functions fell back\n", fb_funcs); u.status = OPUSFE_ERR_INTERNAL; free(slots); free(entries); free(gtypes); return; }
+    LowerBuffers B{};
+    B.type_sparse_base = n_gtypes;
+    TypeRec* types = nullptr;
+    if (fb_funcs) {
+        const uint64_t type_cap = (uint64_t)n_gtypes + lower_base(CAP_TYPES, fb_nodes, fb_funcs) + CAP_CONST;
+        types = exact<TypeRec>(type_cap);
+        memcpy(types, gtypes, (size_t)n_gtypes * sizeof(TypeRec));
+        S.types = types;
+        B.vars = exact<opusfe_variable>(lower_base(CAP_VARS, fb_nodes, fb_funcs) + CAP_CONST);
+        const uint64_t icap = lower_base(CAP_INSTRS, fb_nodes, fb_funcs) + CAP_CONST;
+        B.instrs = exact<opusfe_instr>(icap); B.ibb = exact<uint32_t>(icap); B.irank = exact<uint32_t>(icap);
+        const uint64_t bcap = lower_base(CAP_BBS, fb_nodes, fb_funcs) + CAP_CONST;
+        B.bbcnt = exact<uint32_t>(bcap); B.bblast = exact<uint32_t>(bcap);
+        B.cargs = exact<uint32_t>(lower_base(CAP_CARGS, fb_nodes, fb_funcs) + CAP_CONST);
+        const uint64_t lcap = lower_base(CAP_LOCALS, fb_nodes, fb_funcs) + CAP_CONST;
+        B.lname = exact<uint32_t>(lcap); B.lvar = exact<uint32_t>(lcap); B.lstack = exact<uint32_t>(lcap);
+        B.frames = exact<LFrame>(lower_base(CAP_FRAMES, fb_nodes, fb_funcs) + CAP_CONST);
+        B.errs = exact<SemErr>(lower_base(CAP_ERRS, fb_nodes, fb_funcs) + CAP_CONST);
+        emu_launch(k_lower_functions, grid_for(n_defs, 64), 64, S, B, (const uint8_t*)undefined_flag.data(), def_nodes, n_defs, n_nodes, (uint32_t)u.n_tokens, (const DefCnt*)def_excl.data(),
+                   R->funcs.data(), lstatus, (uint64_t*)nullptr, (const uint64_t*)&user_syms, (const uint32_t*)nullptr, (const uint32_t*)fb_flag.data(), (const FbIdx*)fbx.data());
+    }
     std::vector<IrCnt> cnt(n_funcs);
     emu_launch(k_ir_counts, grid_for(n_funcs, 256), 256, (const FuncIr*)R->funcs.data(), n_funcs, cnt.data());
     IrCnt tot{0, 0, 0, 0, 0, 0};
     for (uint32_t i = 0; i < n_funcs; i++) { IrCnt c = cnt[i]; cnt[i] = tot; tot = OpAddIrCnt()(tot, c); }
-    if (getenv("EMU_VERBOSE")) {
-        double mv = 0, mi = 0, mb = 0, mt = 0;
-        for (auto& f : R->funcs) if (f.n_bbs) {
-            uint32_t d = 0; while (def_nodes[d] != f.def_node) d++;
-            double nn = (d + 1 < n_defs ? def_nodes[d + 1] : n_nodes) - f.def_node;
-            mv = std::max(mv, f.n_vars / nn); mi = std::max(mi, f.n_instrs / nn); mb = std::max(mb, f.n_bbs / nn); mt = std::max(mt, f.n_types / nn);
-        }
-        fprintf(stderr, "max per-node ratios: vars %.2f instrs %.2f bbs %.2f types %.2f\n", mv, mi, mb, mt);
-    }
     bool cleanup_only = false;
     if (lstatus[0] >= DS_INTERNAL_CAPACITY) { u.status = OPUSFE_ERR_INTERNAL; cleanup_only = true; }
     else if (lstatus[0] != DS_OK) { u.status = OPUSFE_UNSUPPORTED; u.dev_status = lstatus[0]; cleanup_only = true; }
@@ -255,17 +276,28 @@ void emu_lower(EmuUnit& E) {
         opusfe_variable* dv = exact<opusfe_variable>(R->n_vars); opusfe_instr* di = exact<opusfe_instr>(R->n_instrs);
         uint32_t* dbo = exact<uint32_t>(R->n_bbs + 1); uint32_t* dc = exact<uint32_t>(R->n_cargs);
         TypeRec* dty = exact<TypeRec>(R->n_types); SemErr* de = exact<SemErr>(R->n_errs);
-        memcpy(dty, types, (size_t)n_gtypes * sizeof(TypeRec));
+        memcpy(dty, gtypes, (size_t)n_gtypes * sizeof(TypeRec));
         dbo[R->n_bbs] = (uint32_t)R->n_instrs;
-        emu_launch(k_ir_bb_offsets, grid_for(n_funcs, 64), 64, R->funcs.data(), n_funcs, (const IrCnt*)cnt.data(), B, dbo, IrCnt{});
-        IrOut O{dv, di, dc, dty, de, dbo, n_gtypes};
-        emu_launch(k_ir_compact, 2, 256, (const FuncIr*)R->funcs.data(), n_funcs, B, (const TypeRec*)types, O);
+        emu_launch(k_ir_bb_offsets, grid_for(n_funcs, 64), 64, R->funcs.data(), n_funcs, (const IrCnt*)cnt.data(), B, dbo, IrCnt{}, (const uint32_t*)fb_flag.data(), (const FbIdx*)fbx.data());
+        if (fb_funcs) {
+            IrOut O{dv, di, dc, dty, de, dbo, n_gtypes};
+            emu_launch(k_ir_compact, 2, 256, (const FuncIr*)R->funcs.data(), n_funcs, B, (const TypeRec*)types, O, (const uint32_t*)fb_flag.data(), (const FbIdx*)fbx.data());
+        }
+        if (!seq_only) {
+            PA.fb_flag = fb_flag.data(); PA.vars = dv; PA.instrs = di; PA.bb_offsets = dbo; PA.cargs = dc; PA.types_out = dty;
+            S.types = gtypes;
+            par::g_emu_lds = (uint32_t*)malloc(lds);
+            memset(par::g_emu_lds, 0x5A, lds);
+            emu_launch((par::k_lower_par<64, true>), n_defs, 1, S, PA);
+            free(par::g_emu_lds); par::g_emu_lds = nullptr;
+            if (lstatus[0] >= DS_INTERNAL_CAPACITY) u.status = OPUSFE_ERR_INTERNAL;
+        }
         R->vars.assign(dv, dv + R->n_vars); R->instrs.assign(di, di + R->n_instrs); R->bb_offsets.assign(dbo, dbo + R->n_bbs + 1);
         R->cargs.assign(dc, dc + R->n_cargs); R->types.assign(dty, dty + R->n_types); R->errs.assign(de, de + R->n_errs);
         free(dv); free(di); free(dbo); free(dc); free(dty); free(de);
         u.n_funcs = n_funcs; u.n_instrs = R->n_instrs; u.n_vars = R->n_vars;
     }
-    free(slots); free(entries); free(types);
+    free(slots); free(entries); free(gtypes); free(types);
     free(B.vars); free(B.instrs); free(B.ibb); free(B.irank); free(B.bbcnt); free(B.bblast); free(B.cargs); free(B.lname); free(B.lvar); free(B.lstack);
     free(B.frames); free(B.errs);
 }
