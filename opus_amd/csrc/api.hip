@@ -378,6 +378,8 @@ int opusfe_create(opusfe_ctx** out, int device) {
     opusfe_ctx* ctx = new opusfe_ctx();
     ctx->device = device;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess
+        || hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess
+        || hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess
         || hipMalloc((void**)&ctx->d_status, 64 * sizeof(uint32_t)) != hipSuccess
         || hipHostMalloc((void**)&ctx->h_status, 64 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
         delete ctx;
@@ -403,6 +405,9 @@ void opusfe_destroy(opusfe_ctx* ctx) {
     (void)hipFree(ctx->d_status);
     (void)hipHostFree(ctx->h_status);
     (void)hipStreamDestroy(ctx->stream);
+    if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     delete ctx;
 }
 
@@ -780,7 +785,7 @@ int opusfe_dump(opusfe_unit* u, int what, char** out, uint64_t* out_len) {
                 s = dump_tokens(u, limit);
                 break;
             }
-            case 1: if (!u->parsed || u->status == OPUSFE_SYNTAX || !u->d_nodes) return (int)OPUSFE_ERR_ARG;   // no AST after a syntax error
+            case 1: if (!u->parsed || (u->status != OPUSFE_OK && u->status != OPUSFE_SEMANTIC) || (u->n_nodes && !u->d_nodes)) { u->ctx->msg = "no AST: the unit did not parse"; return (int)OPUSFE_ERR_ARG; }
                     ensure_host_ast(u); s = dump_ast(u); break;
             case 2: ensure_host_ast(u); ensure_host_ir(u); s = dump_ir(u); break;
             case 4: ensure_host_ir(u); s = dump_semantic_errors(u); break;

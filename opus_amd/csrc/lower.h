@@ -1389,25 +1389,27 @@ __global__ MACHINE_ATTR(OPUSFE_LOWER_WAVES) __launch_bounds__(64) void k_lower_f
     if (L.nerrs) atomicAdd(status + 1, L.nerrs);
 }
 
-__global__ void k_ir_counts(const FuncIr* __restrict__ f, uint32_t n, IrCnt* __restrict__ out) {
+// Place of a sequentially lowered function in the dense arrays (same bump allocation as the node-parallel path,
+// lower_par.h bump_allocate) and the global instruction offsets of its blocks.  One lane per function.
+}  // namespace opusfe
+#include "lower_par.h"
+namespace opusfe {
+__global__ void k_fb_bases(FuncIr* __restrict__ f, uint32_t n, LowerBuffers B, par::ParArgs A, const uint32_t* __restrict__ fb_flag, const FbIdx* __restrict__ fbx) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    out[i] = IrCnt{f[i].n_vars, f[i].n_instrs, f[i].n_bbs, f[i].n_types, f[i].n_cargs, f[i].n_errs};
-}
-
-// per function: dense bases + exclusive scan of its bb sizes into bb_offsets (global instruction indices)
-__global__ void k_ir_bb_offsets(FuncIr* __restrict__ f, uint32_t n, const IrCnt* __restrict__ base, LowerBuffers B, uint32_t* __restrict__ bb_offsets, IrCnt totals_hint,
-                                const uint32_t* __restrict__ fb_flag, const FbIdx* __restrict__ fbx) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= n || !fb_flag[i]) return;
     FuncIr r = f[i];
-    r.var_base = base[i].vars; r.instr_base = base[i].instrs; r.bb_base = base[i].bbs; r.type_base = base[i].types; r.carg_base = base[i].cargs; r.err_base = base[i].errs;
+    if (r.n_bbs == 0) return;
+    const par::Bases b = par::bump_allocate(A, r.n_vars, r.n_instrs, r.n_bbs, r.n_types, r.n_cargs);
+    r.var_base = b.var_base; r.instr_base = b.instr_base; r.bb_base = b.bb_base; r.type_base = b.type_base; r.carg_base = b.carg_base;
+    r.err_base = r.n_errs ? atomicAdd(A.err_counter, r.n_errs) : 0u;
+    bool fits = b.fits;
+    if ((uint64_t)r.err_base + r.n_errs > A.cap_errs) { fits = false; atomicMax(A.overflow, 1u); }
+    if (!fits) r.status |= 0x80000000u;              // compaction skips it; the host runs again
     f[i] = r;
-    if (r.n_bbs == 0 || !fb_flag[i]) return;             // the node-parallel path writes its own block offsets
+    if (!fits) return;
     const uint32_t* cnt = B.bbcnt + lower_base(CAP_BBS, fbx[i].nodes, fbx[i].funcs);
     uint32_t run = r.instr_base;
-    for (uint32_t b = 0; b < r.n_bbs; b++) { bb_offsets[r.bb_base + b] = run; run += cnt[b]; }
-    (void)totals_hint;
+    for (uint32_t k = 0; k < r.n_bbs; k++) { A.bb_offsets[r.bb_base + k] = run; run += cnt[k]; }
 }
 
 struct IrOut { opusfe_variable* vars; opusfe_instr* instrs; uint32_t* cargs; TypeRec* types; SemErr* errs; const uint32_t* bb_offsets; uint32_t n_gtypes; };
@@ -1420,7 +1422,7 @@ __global__ __launch_bounds__(256) void k_ir_compact(const FuncIr* __restrict__ f
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     for (uint32_t i = wave; i < n; i += nwaves) {
         const FuncIr r = f[i];
-        if (r.n_bbs == 0 || !fb_flag[i]) continue;
+        if (r.n_bbs == 0 || !fb_flag[i] || (r.status & 0x80000000u)) continue;
         const uint32_t sb_n = fbx[i].nodes, sb_f = fbx[i].funcs;
         const uint32_t tsb = B.type_sparse_base + (uint32_t)lower_base(CAP_TYPES, sb_n, sb_f);   // first sparse local type id
         const uint32_t tdb = O.n_gtypes + r.type_base;                                                   // first dense local type id
@@ -1448,10 +1450,6 @@ __global__ __launch_bounds__(256) void k_ir_compact(const FuncIr* __restrict__ f
 }
 
 
-}  // namespace opusfe
-#include "lower_par.h"
-namespace opusfe {
-
 // which functions the node-parallel path declined, and how much sparse space the sequential machine needs for them
 __global__ void k_fb_mark(const FuncIr* __restrict__ f, uint32_t n_funcs, const uint32_t* __restrict__ def_nodes, uint32_t n_defs, uint32_t n_nodes, const DefCnt* __restrict__ def_excl,
                           const opusfe_node* __restrict__ nodes, uint32_t* __restrict__ fb_flag, FbIdx* __restrict__ fbx) {
@@ -1465,6 +1463,36 @@ __global__ void k_fb_mark(const FuncIr* __restrict__ f, uint32_t n_funcs, const 
     const uint32_t nn = (d + 1 < n_defs ? def_nodes[d + 1] : n_nodes) - dn;
     fb_flag[fidx] = fb ? 1u : 0u;
     fbx[fidx] = FbIdx{fb ? nn : 0u, fb ? 1u : 0u};
+}
+
+// The diagnostics of IR generation in the reference's report order (functions in definition order): the passes place each
+// function's errors by bump allocation; when there are any (rare) they are copied into definition order.
+__global__ void k_err_counts(const FuncIr* __restrict__ f, uint32_t n, uint32_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = f[i].n_errs;
+}
+__global__ void k_err_order(FuncIr* __restrict__ f, uint32_t n, const uint32_t* __restrict__ excl, const SemErr* __restrict__ in, SemErr* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    FuncIr r = f[i];
+    for (uint32_t k = 0; k < r.n_errs; k++) out[excl[i] + k] = in[r.err_base + k];
+    r.err_base = excl[i];
+    f[i] = r;
+}
+
+// functions too large for the node-parallel path (known before it runs): the machine starts on them at once, on a second stream
+__global__ void k_fb_mark_size(const uint32_t* __restrict__ def_nodes, uint32_t n_defs, uint32_t n_nodes, const DefCnt* __restrict__ def_excl,
+                               const opusfe_node* __restrict__ nodes, uint32_t limit, uint32_t* __restrict__ fb_flag, FbIdx* __restrict__ fbx) {
+    const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= n_defs) return;
+    const uint32_t dn = def_nodes[d];
+    const uint8_t k = nodes[dn].kind;
+    if (k != D_Function && k != D_Extern) return;
+    const uint32_t fidx = def_excl[d].funcs;
+    const uint32_t nn = (d + 1 < n_defs ? def_nodes[d + 1] : n_nodes) - dn;
+    const bool big = k == D_Function && nn >= limit;
+    fb_flag[fidx] = big ? 1u : 0u;
+    fbx[fidx] = FbIdx{big ? nn : 0u, big ? 1u : 0u};
 }
 
 // ---- results ------------------------------------------------------------------------------------
@@ -1562,17 +1590,29 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
            ph_def, ph_prev, n_nodes, gtypes, R->d_funcrecs, R->d_globals, ctx->d_status + WL_FINERR);
     // size classes of the definitions (largest first): which workgroup shape lowers a function, and the dispatch order of the machine
     uint32_t* order = tmp.get<uint32_t>(n_defs);
-    uint32_t* order_hist = tmp.get<uint32_t>(33);
-    HIP_TRY(hipMemsetAsync(order_hist, 0, 33 * sizeof(uint32_t), st));
+    uint32_t* order_hist = tmp.get<uint32_t>(ORDER_CLASSES);
+    HIP_TRY(hipMemsetAsync(order_hist, 0, ORDER_CLASSES * sizeof(uint32_t), st));
     LAUNCH(ctx, "order_hist", k_order_hist, grid_for(n_defs, 256), 256, u->d_def_nodes, n_defs, n_nodes, order_hist);
     LAUNCH(ctx, "order_scan", k_order_scan, 1, 64, order_hist);
     LAUNCH(ctx, "order_scatter", k_order_scatter, grid_for(n_defs, 256), 256, u->d_def_nodes, n_defs, n_nodes, order_hist, order);
-    uint32_t class_end[33];
+    // functions of 2048 nodes and more never fit the node-parallel path: flagged now, so that the machine can start on them at once
+    uint32_t* big_flag = tmp.get<uint32_t>(n_funcs + 1);
+    FbIdx* big_idx = tmp.get<FbIdx>(n_funcs + 1);
+    HIP_TRY(hipMemsetAsync(ctx->d_status + WL_FBTOT, 0, 2 * sizeof(uint32_t), st));
+    if (n_funcs) {
+        LAUNCH(ctx, "fb_mark_size", k_fb_mark_size, grid_for(n_defs, 256), 256, u->d_def_nodes, n_defs, n_nodes, def_excl, u->d_nodes, (uint32_t)2048, big_flag, big_idx);
+        prof_begin(ctx, "fb_scan");
+        device_scan<true>(big_idx, big_idx, n_funcs, OpAddFbIdx(), FbIdx{0, 0}, (FbIdx*)scan_tmp, (FbIdx*)(ctx->d_status + WL_FBTOT), st);
+        prof_end(ctx);
+    }
+    uint32_t class_end[ORDER_CLASSES];
     HIP_TRY(hipMemcpyAsync(class_end, order_hist, sizeof class_end, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(ctx->h_status, ctx->d_status, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     prof_collect(ctx);
     R->n_funcs = n_funcs; R->n_globals = n_globals; R->n_gtypes = n_gtypes;
+    static const bool seq_only = getenv("OPUSFE_LOWER_SEQ") != nullptr;     // debugging aid: everything through the sequential machine
+    const uint32_t big_nodes = seq_only ? 0u : ctx->h_status[WL_FBTOT], big_funcs = seq_only ? 0u : ctx->h_status[WL_FBTOT + 1];
     if (ctx->h_status[WL_FINERR] != 0) {   // frontend.rs:145: semantic errors while finalizing -> no IR
         R->n_sem_errors = ctx->h_status[WL_FINERR];
         // the diagnostics themselves, in the reference's report order (definitions in file order)
@@ -1592,136 +1632,175 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
     }
     if (n_funcs == 0) { u->status = OPUSFE_OK; R->have_host = true; return; }
 
-    // E1. node-parallel count pass (lower_par.h): every function it can lower gets its exact result sizes
+    // E. IR generation.  The node-parallel path (lower_par.h) lowers every function it can in ONE pass straight into the dense
+    // result arrays (sizes by counting, places by bump allocation); the functions it declines go through the sequential
+    // machine, into sparse regions sized for them alone, and are compacted into the same arrays.  The arrays are sized from
+    // the node count (ratios of the previous unit on this context, with head-room); if one is too small the pass raises
+    // `overflow`, still counts exactly, and everything runs once more with the exact sizes.
     SemView S{u->d_src, u->d_tokens, u->d_val64, u->d_nodes, R->d_tid_of_node, gtypes, slots, n_slots - 1, entries, R->d_funcrecs, R->d_globals, n_gtypes};
     R->d_funcs = dev_alloc_t<FuncIr>(ctx, n_funcs);
-    HIP_TRY(hipMemsetAsync(R->d_funcs, 0, (size_t)n_funcs * sizeof(FuncIr), st));
     uint64_t* user_syms = tmp.get<uint64_t>(1);
     LAUNCH(ctx, "sem_user_syms", k_sem_user_syms, 1, 64, S, user_syms);
-    LAUNCH(ctx, "par_init", par::k_par_init, grid_for(n_defs, 256), 256, u->d_nodes, u->d_def_nodes, n_defs, def_excl, R->d_funcs);
-    par::ParArgs PA{};
-    PA.def_nodes = u->d_def_nodes; PA.n_defs = n_defs; PA.n_nodes = n_nodes; PA.def_excl = def_excl; PA.undefined_flag = undefined_flag; PA.user_syms = user_syms;
-    PA.pp_base = pp_base; PA.out = R->d_funcs; PA.status = ctx->d_status + WL_STATUS;
-    // class c = definitions whose node count has bit length c; order[] holds them largest class first, class c ends at class_end[c]
-    const uint32_t s_lo = class_end[9], s_hi = n_defs, m_lo = class_end[11], m_hi = class_end[9], l_lo = class_end[12], l_hi = class_end[11];
-    static const bool seq_only = getenv("OPUSFE_LOWER_SEQ") != nullptr;     // debugging aid: everything through the sequential machine
-    auto launch_par = [&](bool emit) {
-        struct Shape { uint32_t lo, hi, nmax, maxdef, threads; const char* name; };
-        const Shape shapes[3] = {{l_lo, l_hi, 2048, 256, 512, emit ? "lower_par_emit_L" : "lower_par_count_L"},
-                                 {m_lo, m_hi, 1024, 128, 256, emit ? "lower_par_emit_M" : "lower_par_count_M"},
-                                 {s_lo, s_hi, 256, 64, 64, emit ? "lower_par_emit_S" : "lower_par_count_S"}};
-        for (const Shape& sh : shapes) {
-            if (sh.hi <= sh.lo || seq_only) continue;
-            par::ParArgs a = PA;
-            a.list = order + sh.lo; a.n_list = sh.hi - sh.lo; a.nmax = sh.nmax; a.maxdef = sh.maxdef;
-            const size_t lds = par::lds_bytes(sh.nmax, sh.maxdef, sh.threads);
-            prof_begin(ctx, sh.name);
-            if (sh.threads == 512) {
-                if (emit) { HIP_TRY(hipFuncSetAttribute((const void*)par::k_lower_par<512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); hipLaunchKernelGGL((par::k_lower_par<512, true>), dim3(a.n_list), dim3(512), lds, st, S, a); }
-                else { HIP_TRY(hipFuncSetAttribute((const void*)par::k_lower_par<512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); hipLaunchKernelGGL((par::k_lower_par<512, false>), dim3(a.n_list), dim3(512), lds, st, S, a); }
-            } else if (sh.threads == 256) {
-                if (emit) { HIP_TRY(hipFuncSetAttribute((const void*)par::k_lower_par<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); hipLaunchKernelGGL((par::k_lower_par<256, true>), dim3(a.n_list), dim3(256), lds, st, S, a); }
-                else { HIP_TRY(hipFuncSetAttribute((const void*)par::k_lower_par<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); hipLaunchKernelGGL((par::k_lower_par<256, false>), dim3(a.n_list), dim3(256), lds, st, S, a); }
-            } else {
-                if (emit) hipLaunchKernelGGL((par::k_lower_par<64, true>), dim3(a.n_list), dim3(64), lds, st, S, a);
-                else hipLaunchKernelGGL((par::k_lower_par<64, false>), dim3(a.n_list), dim3(64), lds, st, S, a);
-            }
-            HIP_TRY(hipGetLastError());
-            prof_end(ctx);
-        }
-    };
-    launch_par(false);
-
-    // E2. the functions it declined go through the sequential machine, into sparse regions sized for them alone
+    // order[] holds the definitions by size class, largest class first; class c ends at class_end[c] and starts where class c + 1 ends
+    unsigned long long* counters = tmp.get<unsigned long long>(par::CTR_COUNT + 2);     // + overflow flag, + error counter
     uint32_t* fb_flag = tmp.get<uint32_t>(n_funcs);
     FbIdx* fbx = tmp.get<FbIdx>(n_funcs);
-    LAUNCH(ctx, "fb_mark", k_fb_mark, grid_for(n_defs, 256), 256, R->d_funcs, n_funcs, u->d_def_nodes, n_defs, n_nodes, def_excl, u->d_nodes, fb_flag, fbx);
-    prof_begin(ctx, "fb_scan");
-    device_scan<true>(fbx, fbx, n_funcs, OpAddFbIdx(), FbIdx{0, 0}, (FbIdx*)scan_tmp, (FbIdx*)(ctx->d_status + WL_FBTOT), st);
-    prof_end(ctx);
-    HIP_TRY(hipMemcpyAsync(ctx->h_status, ctx->d_status, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    prof_collect(ctx);
-    const uint32_t fb_nodes = ctx->h_status[WL_FBTOT], fb_funcs = ctx->h_status[WL_FBTOT + 1];
-    R->n_fallback = fb_funcs;
-    LowerBuffers B{};
-    B.type_sparse_base = n_gtypes;
-    TypeRec* types = gtypes;                 // global records, followed by the machine's sparse per-function regions when there are any
-    if (fb_funcs) {
-        const uint64_t type_cap = (uint64_t)n_gtypes + lower_base(CAP_TYPES, fb_nodes, fb_funcs) + CAP_CONST;
-        if (type_cap >= 0xFFFFFFF0ull) { u->status = OPUSFE_ERR_ARG; ctx->msg = "unit too large for 32-bit type ids: shard it"; return; }
-        types = tmp.get<TypeRec>(type_cap);
-        HIP_TRY(hipMemcpyAsync(types, gtypes, (size_t)n_gtypes * sizeof(TypeRec), hipMemcpyDeviceToDevice, st));
-        S.types = types;
-        B.vars = tmp.get<opusfe_variable>(lower_base(CAP_VARS, fb_nodes, fb_funcs) + CAP_CONST);
-        const uint64_t icap = lower_base(CAP_INSTRS, fb_nodes, fb_funcs) + CAP_CONST;
-        B.instrs = tmp.get<opusfe_instr>(icap); B.ibb = tmp.get<uint32_t>(icap); B.irank = tmp.get<uint32_t>(icap);
-        const uint64_t bcap = lower_base(CAP_BBS, fb_nodes, fb_funcs) + CAP_CONST;
-        B.bbcnt = tmp.get<uint32_t>(bcap); B.bblast = tmp.get<uint32_t>(bcap);
-        B.cargs = tmp.get<uint32_t>(lower_base(CAP_CARGS, fb_nodes, fb_funcs) + CAP_CONST);
-        const uint64_t lcap = lower_base(CAP_LOCALS, fb_nodes, fb_funcs) + CAP_CONST;
-        B.lname = tmp.get<uint32_t>(lcap); B.lvar = tmp.get<uint32_t>(lcap); B.lstack = tmp.get<uint32_t>(lcap);
-        B.frames = tmp.get<LFrame>(lower_base(CAP_FRAMES, fb_nodes, fb_funcs) + CAP_CONST);
-        B.errs = tmp.get<SemErr>(lower_base(CAP_ERRS, fb_nodes, fb_funcs) + CAP_CONST);
-        uint64_t* prof_buf = tmp.get<uint64_t>(LP_COUNT);
-        HIP_TRY(hipMemsetAsync(prof_buf, 0, LP_COUNT * 8, st));
-        LAUNCH(ctx, "lower_functions", k_lower_functions, grid_for((uint64_t)n_defs * UNIT_LANES, 64), 64, S, B, undefined_flag, u->d_def_nodes, n_defs, n_nodes, (uint32_t)u->n_tokens, def_excl, R->d_funcs,
-               ctx->d_status + WL_STATUS, prof_buf, user_syms, (const uint32_t*)order, (const uint32_t*)fb_flag, (const FbIdx*)fbx);
-#ifdef OPUSFE_LOWER_PROF
+    uint64_t cap[6];     // vars, instrs, bbs, types, cargs, diagnostics
+    for (int k = 0; k < 5; k++) cap[k] = (uint64_t)(ctx->ir_ratio[k] * (double)n_nodes) + (1u << 16);
+    cap[5] = (1u << 16) + n_nodes / 64;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        dev_free(ctx, R->d_vars); dev_free(ctx, R->d_instrs); dev_free(ctx, R->d_bb_offsets); dev_free(ctx, R->d_cargs); dev_free(ctx, R->d_types); dev_free(ctx, R->d_errs);
+        R->d_vars = nullptr; R->d_instrs = nullptr; R->d_bb_offsets = nullptr; R->d_cargs = nullptr; R->d_types = nullptr; R->d_errs = nullptr;
+        if (cap[1] >= (1ull << par::CTR_BB_SHIFT) || (uint64_t)n_gtypes + cap[3] >= 0xFFFFFFF0ull || cap[0] >= 0xFFFFFFF0ull) { u->status = OPUSFE_ERR_ARG; ctx->msg = "unit too large for 32-bit IR indices: shard it"; return; }
+        R->d_vars = dev_alloc_t<opusfe_variable>(ctx, cap[0]);
+        R->d_instrs = dev_alloc_t<opusfe_instr>(ctx, cap[1]);
+        R->d_bb_offsets = dev_alloc_t<uint32_t>(ctx, cap[2] + 1);
+        R->d_types = dev_alloc_t<TypeRec>(ctx, (uint64_t)n_gtypes + cap[3]);
+        R->d_cargs = dev_alloc_t<uint32_t>(ctx, cap[4]);
+        R->d_errs = dev_alloc_t<SemErr>(ctx, cap[5]);
+        HIP_TRY(hipMemsetAsync(counters, 0, (par::CTR_COUNT + 2) * sizeof(unsigned long long), st));
+        HIP_TRY(hipMemsetAsync(ctx->d_status + WL_STATUS, 0, 2 * sizeof(uint32_t), st));
+        HIP_TRY(hipMemcpyAsync(R->d_types, gtypes, (size_t)n_gtypes * sizeof(TypeRec), hipMemcpyDeviceToDevice, st));
+        LAUNCH(ctx, "par_init", par::k_par_init, grid_for(n_defs, 256), 256, u->d_nodes, u->d_def_nodes, n_defs, def_excl, R->d_funcs);
+        par::ParArgs PA{};
+        PA.def_nodes = u->d_def_nodes; PA.n_defs = n_defs; PA.n_nodes = n_nodes; PA.def_excl = def_excl; PA.undefined_flag = undefined_flag; PA.user_syms = user_syms;
+        PA.pp_base = pp_base; PA.out = R->d_funcs; PA.status = ctx->d_status + WL_STATUS;
+        { static const char* sp = getenv("OPUSFE_PAR_STOP"); PA.stop_phase = sp ? (uint32_t)atoi(sp) : 0u; }
+        PA.counters = counters; PA.overflow = (uint32_t*)(counters + par::CTR_COUNT); PA.err_counter = (uint32_t*)(counters + par::CTR_COUNT + 1);
+        PA.cap_vars = cap[0]; PA.cap_instrs = cap[1]; PA.cap_bbs = cap[2]; PA.cap_types = cap[3]; PA.cap_cargs = cap[4]; PA.cap_errs = cap[5];
+        PA.vars = R->d_vars; PA.instrs = R->d_instrs; PA.bb_offsets = R->d_bb_offsets; PA.cargs = R->d_cargs; PA.types_out = R->d_types;
+        S.types = gtypes;
+        // The sequential machine on the functions flagged in `flag` (sparse regions laid out by `idx`), then their places in the
+        // dense arrays and the compaction into them; all on stream `ms`.
+        TempList tmp2(ctx);       // the machine's sparse regions live for one attempt
+        auto machine_pass = [&](hipStream_t ms, const uint32_t* flag, const FbIdx* idx, uint32_t nodes_total, uint32_t funcs_total, bool timed) -> bool {
+            LowerBuffers B{};
+            B.type_sparse_base = n_gtypes;
+            const uint64_t type_cap = (uint64_t)n_gtypes + lower_base(CAP_TYPES, nodes_total, funcs_total) + CAP_CONST;
+            if (type_cap >= 0xFFFFFFF0ull) { u->status = OPUSFE_ERR_ARG; ctx->msg = "unit too large for 32-bit type ids: shard it"; return false; }
+            TypeRec* types = tmp2.get<TypeRec>(type_cap);     // global records followed by the machine's sparse per-function regions
+            HIP_TRY(hipMemcpyAsync(types, gtypes, (size_t)n_gtypes * sizeof(TypeRec), hipMemcpyDeviceToDevice, ms));
+            SemView S2 = S; S2.types = types;
+            B.vars = tmp2.get<opusfe_variable>(lower_base(CAP_VARS, nodes_total, funcs_total) + CAP_CONST);
+            const uint64_t icap = lower_base(CAP_INSTRS, nodes_total, funcs_total) + CAP_CONST;
+            B.instrs = tmp2.get<opusfe_instr>(icap); B.ibb = tmp2.get<uint32_t>(icap); B.irank = tmp2.get<uint32_t>(icap);
+            const uint64_t bcap = lower_base(CAP_BBS, nodes_total, funcs_total) + CAP_CONST;
+            B.bbcnt = tmp2.get<uint32_t>(bcap); B.bblast = tmp2.get<uint32_t>(bcap);
+            B.cargs = tmp2.get<uint32_t>(lower_base(CAP_CARGS, nodes_total, funcs_total) + CAP_CONST);
+            const uint64_t lcap = lower_base(CAP_LOCALS, nodes_total, funcs_total) + CAP_CONST;
+            B.lname = tmp2.get<uint32_t>(lcap); B.lvar = tmp2.get<uint32_t>(lcap); B.lstack = tmp2.get<uint32_t>(lcap);
+            B.frames = tmp2.get<LFrame>(lower_base(CAP_FRAMES, nodes_total, funcs_total) + CAP_CONST);
+            const uint64_t ecap = lower_base(CAP_ERRS, nodes_total, funcs_total) + CAP_CONST;
+            B.errs = tmp2.get<SemErr>(ecap);
+            uint64_t* prof_buf = tmp2.get<uint64_t>(LP_COUNT);
+            HIP_TRY(hipMemsetAsync(prof_buf, 0, LP_COUNT * 8, ms));
+            par::ParArgs PB = PA;
+            if (timed) prof_begin(ctx, "lower_functions");
+            hipLaunchKernelGGL(k_lower_functions, dim3(grid_for((uint64_t)n_defs * UNIT_LANES, 64)), dim3(64), 0, ms, S2, B, (const uint8_t*)undefined_flag, (const uint32_t*)u->d_def_nodes, n_defs, n_nodes,
+                               (uint32_t)u->n_tokens, (const DefCnt*)def_excl, R->d_funcs, ctx->d_status + WL_STATUS, prof_buf, (const uint64_t*)user_syms, (const uint32_t*)order, flag, idx);
+            HIP_TRY(hipGetLastError());
+            if (timed) prof_end(ctx);
+            hipLaunchKernelGGL(k_fb_bases, dim3(grid_for(n_funcs, 64)), dim3(64), 0, ms, R->d_funcs, n_funcs, B, PB, flag, idx);
+            HIP_TRY(hipGetLastError());
+            IrOut O{R->d_vars, R->d_instrs, R->d_cargs, R->d_types, R->d_errs, R->d_bb_offsets, n_gtypes};
+            unsigned grid = (unsigned)((n_funcs + 3) / 4);
+            if (grid > 8192) grid = 8192;
+            hipLaunchKernelGGL(k_ir_compact, dim3(grid), dim3(256), 0, ms, (const FuncIr*)R->d_funcs, n_funcs, B, (const TypeRec*)types, O, flag, idx);
+            HIP_TRY(hipGetLastError());
+            return true;
+        };
+        // the functions that are too large for the node-parallel path start at once, next to it
+        HIP_TRY(hipEventRecord(ctx->ev_fork, st));
+        HIP_TRY(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+        if (big_funcs) { if (!machine_pass(ctx->stream2, big_flag, big_idx, big_nodes, big_funcs, false)) { HIP_TRY(hipStreamSynchronize(ctx->stream2)); return; } }
         {
-            uint64_t h[LP_COUNT];
-            HIP_TRY(hipMemcpyAsync(h, prof_buf, sizeof h, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            static const char* const NAMES[LP_NAMED] = {"total", "node loads", "local_find", "call_variables", "autocast", "try_cast_pointer", "lookup_name", "field_access",
-                                                        "push", "new_var", "frames", "compiler_lookup_function"};
-            fprintf(stderr, "lowering cycle accounting (inclusive, summed over functions):\n");
-            for (int i = 0; i < LP_NAMED; i++) fprintf(stderr, "  %-26s %14llu  %5.1f%%\n", NAMES[i], (unsigned long long)h[i], 100.0 * h[i] / (double)h[0]);
-            fprintf(stderr, "per machine state (index into enum LState): share of cycles, steps, cycles per step\n");
-            for (int i = 0; i < 48; i++) if (h[LP_STATE_STEPS + i]) fprintf(stderr, "  state %2d  %5.1f%%  %12llu steps  %8.0f cycles/step\n", i, 100.0 * h[LP_STATE_CYCLES + i] / (double)h[0],
-                                                                           (unsigned long long)h[LP_STATE_STEPS + i], (double)h[LP_STATE_CYCLES + i] / (double)h[LP_STATE_STEPS + i]);
+            // One launch per half-octave size class (scan.h order_class_of_size): the LDS a workgroup reserves is sized for the largest
+            // function of its class, so at most a third of it is unused.  Functions of 2048 nodes and more, and the ones the fast path
+            // declines, go through the sequential machine.  OPUSFE_PAR_SHAPE=a,b,c overrides the thread counts of the three shapes.
+            static const char* shape_env = getenv("OPUSFE_PAR_SHAPE");
+            uint32_t ts = 64, tm = 256, tl = 512;      // (only with OPUSFE_PAR_SHAPE)
+            if (shape_env) sscanf(shape_env, "%u,%u,%u", &ts, &tm, &tl);
+            static const char* const NAMES[12] = {"lower_par_64", "lower_par_96", "lower_par_128", "lower_par_192", "lower_par_256", "lower_par_384", "lower_par_512",
+                                                  "lower_par_768", "lower_par_1024", "lower_par_1536", "lower_par_2048", "lower_par"};
+            const uint32_t c_top = order_class_of_size(2047), c_small = order_class_of_size(63);     // classes above c_top: sequential machine
+            int name_i = 10;
+            for (uint32_t c = c_top; c >= c_small && !seq_only; c--, name_i--) {
+                // the smallest launch takes every class up to c_small
+                const uint32_t lo = class_end[c + 1], hi = c == c_small ? n_defs : class_end[c];
+                if (hi <= lo) continue;
+                par::ParArgs a = PA;
+                a.list = order + lo; a.n_list = hi - lo;
+                a.nmax = (uint32_t)order_class_lo(c + 1) - 1u; if (a.nmax < 63) a.nmax = 63;
+                a.maxdef = a.nmax / 8 < 32 ? 32 : a.nmax / 8;
+                // threads: as many waves per workgroup as it takes to reach 16 waves per CU (the register limit) with the workgroups
+                // that fit the 160 KB of LDS
+                uint32_t threads;
+                if (shape_env) threads = a.nmax <= 256 ? ts : a.nmax <= 1024 ? tm : tl;
+                else {
+                    const size_t blocks = std::max<size_t>(1, (160u << 10) / par::lds_bytes(a.nmax, a.maxdef, 256));
+                    const size_t want = (16 + blocks - 1) / blocks;
+                    threads = want <= 1 ? 64 : want <= 2 ? 128 : want <= 4 ? 256 : want <= 8 ? 512 : 1024;
+                }
+                const size_t lds = par::lds_bytes(a.nmax, a.maxdef, threads);
+                prof_begin(ctx, NAMES[name_i < 0 ? 11 : name_i]);
+#define OPUSFE_PAR_LAUNCH(T) do { HIP_TRY(hipFuncSetAttribute((const void*)par::k_lower_par<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                                  hipLaunchKernelGGL((par::k_lower_par<T>), dim3(a.n_list), dim3(T), lds, st, S, a); } while (0)
+                switch (threads) {
+                    case 64: OPUSFE_PAR_LAUNCH(64); break; case 128: OPUSFE_PAR_LAUNCH(128); break; case 256: OPUSFE_PAR_LAUNCH(256); break;
+                    case 512: OPUSFE_PAR_LAUNCH(512); break; default: OPUSFE_PAR_LAUNCH(1024); break;
+                }
+#undef OPUSFE_PAR_LAUNCH
+                HIP_TRY(hipGetLastError());
+                prof_end(ctx);
+            }
         }
-#endif
+        HIP_TRY(hipEventRecord(ctx->ev_join, ctx->stream2));
+        HIP_TRY(hipStreamWaitEvent(st, ctx->ev_join, 0));
+        // the functions it declined
+        LAUNCH(ctx, "fb_mark", k_fb_mark, grid_for(n_defs, 256), 256, R->d_funcs, n_funcs, u->d_def_nodes, n_defs, n_nodes, def_excl, u->d_nodes, fb_flag, fbx);
+        prof_begin(ctx, "fb_scan");
+        device_scan<true>(fbx, fbx, n_funcs, OpAddFbIdx(), FbIdx{0, 0}, (FbIdx*)scan_tmp, (FbIdx*)(ctx->d_status + WL_FBTOT), st);
+        prof_end(ctx);
+        HIP_TRY(hipMemcpyAsync(ctx->h_status, ctx->d_status, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        prof_collect(ctx);
+        const uint32_t fb_nodes = ctx->h_status[WL_FBTOT], fb_funcs = ctx->h_status[WL_FBTOT + 1];
+        R->n_fallback = fb_funcs + big_funcs;
+        if (fb_funcs) { if (!machine_pass(st, fb_flag, fbx, fb_nodes, fb_funcs, true)) return; }
+        unsigned long long hc[par::CTR_COUNT + 2];
+        HIP_TRY(hipMemcpyAsync(hc, counters, sizeof hc, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(ctx->h_status, ctx->d_status, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        prof_collect(ctx);
+        const uint32_t lst = ctx->h_status[WL_STATUS];
+        if (lst >= DS_INTERNAL_CAPACITY) { u->status = OPUSFE_ERR_INTERNAL; ctx->msg = "lowering: internal capacity / consistency check failed"; return; }
+        if (lst != DS_OK) { u->status = OPUSFE_UNSUPPORTED; u->dev_status = lst; ctx->msg = "construct on which the reference panics (unreachable!/unwrap) or overflows its stack"; return; }
+        const uint64_t tot[5] = {hc[par::CTR_VARS], hc[par::CTR_INSTR_BB] & ((1ull << par::CTR_BB_SHIFT) - 1), hc[par::CTR_INSTR_BB] >> par::CTR_BB_SHIFT, hc[par::CTR_TYPES], hc[par::CTR_CARGS]};
+        const bool overflow = (uint32_t)hc[par::CTR_COUNT] != 0;
+        if (overflow) {
+            if (attempt == 1) { u->status = OPUSFE_ERR_INTERNAL; ctx->msg = "lowering: the exact-size pass overflowed"; return; }
+            for (int k = 0; k < 5; k++) cap[k] = tot[k] + 16;      // the counters are exact whether or not everything fitted
+            cap[5] = (uint32_t)hc[par::CTR_COUNT + 1] + 16;
+            continue;
+        }
+        R->n_sem_errors = ctx->h_status[WL_ERRS];
+        R->n_vars = tot[0]; R->n_instrs = tot[1]; R->n_bbs = tot[2]; R->n_types = (uint64_t)n_gtypes + tot[3]; R->n_cargs = tot[4]; R->n_errs = (uint32_t)hc[par::CTR_COUNT + 1];
+        for (int k = 0; k < 5; k++) ctx->ir_ratio[k] = std::max(0.01, 1.04 * (double)tot[k] / (double)n_nodes);      // sizes of the next unit: this one's, plus head-room
+        if (R->n_errs) {       // report order = definition order
+            uint32_t* ecnt = tmp.get<uint32_t>(n_funcs);
+            SemErr* ordered = dev_alloc_t<SemErr>(ctx, R->n_errs);
+            LAUNCH(ctx, "err_counts", k_err_counts, grid_for(n_funcs, 256), 256, R->d_funcs, n_funcs, ecnt);
+            device_scan<true>(ecnt, ecnt, n_funcs, OpAddU32(), (uint32_t)0, scan_tmp, (uint32_t*)nullptr, st);
+            LAUNCH(ctx, "err_order", k_err_order, grid_for(n_funcs, 256), 256, R->d_funcs, n_funcs, ecnt, R->d_errs, ordered);
+            HIP_TRY(hipStreamSynchronize(st));
+            dev_free(ctx, R->d_errs);
+            R->d_errs = ordered;
+        }
+        const uint32_t n_instrs32 = (uint32_t)R->n_instrs;
+        HIP_TRY(hipMemcpyAsync(R->d_bb_offsets + R->n_bbs, &n_instrs32, 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        break;
     }
-    // E3. dense bases of every function
-    IrCnt* cnt = tmp.get<IrCnt>(n_funcs);
-    LAUNCH(ctx, "ir_counts", k_ir_counts, grid_for(n_funcs, 256), 256, R->d_funcs, n_funcs, cnt);
-    prof_begin(ctx, "ir_scan");
-    device_scan<true>(cnt, cnt, n_funcs, OpAddIrCnt(), IrCnt{0, 0, 0, 0, 0, 0}, (IrCnt*)scan_tmp, (IrCnt*)(ctx->d_status + WL_IRTOT), st);
-    prof_end(ctx);
-    HIP_TRY(hipMemcpyAsync(ctx->h_status, ctx->d_status, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    prof_collect(ctx);
-    const uint32_t lst = ctx->h_status[WL_STATUS];
-    if (lst >= DS_INTERNAL_CAPACITY) { u->status = OPUSFE_ERR_INTERNAL; ctx->msg = "lowering: internal capacity check failed"; return; }
-    if (lst != DS_OK) { u->status = OPUSFE_UNSUPPORTED; u->dev_status = lst; ctx->msg = "construct on which the reference panics (unreachable!/unwrap) or overflows its stack"; return; }
-    R->n_sem_errors = ctx->h_status[WL_ERRS];
-    const uint32_t* tot = ctx->h_status + WL_IRTOT;
-    R->n_vars = tot[0]; R->n_instrs = tot[1]; R->n_bbs = tot[2]; R->n_types = (uint64_t)n_gtypes + tot[3]; R->n_cargs = tot[4]; R->n_errs = tot[5];
-    if (R->n_types >= 0xFFFFFFF0ull) { u->status = OPUSFE_ERR_ARG; ctx->msg = "unit too large for 32-bit type ids: shard it"; return; }
-    // F. dense output: the node-parallel emit pass writes it directly; the machine's functions are compacted into it
-    R->d_vars = dev_alloc_t<opusfe_variable>(ctx, R->n_vars);
-    R->d_instrs = dev_alloc_t<opusfe_instr>(ctx, R->n_instrs);
-    R->d_bb_offsets = dev_alloc_t<uint32_t>(ctx, R->n_bbs + 1);
-    R->d_cargs = dev_alloc_t<uint32_t>(ctx, R->n_cargs);
-    R->d_types = dev_alloc_t<TypeRec>(ctx, R->n_types);
-    R->d_errs = dev_alloc_t<SemErr>(ctx, R->n_errs);
-    HIP_TRY(hipMemcpyAsync(R->d_types, gtypes, (size_t)n_gtypes * sizeof(TypeRec), hipMemcpyDeviceToDevice, st));
-    const uint32_t n_instrs32 = (uint32_t)R->n_instrs;
-    HIP_TRY(hipMemcpyAsync(R->d_bb_offsets + R->n_bbs, &n_instrs32, 4, hipMemcpyHostToDevice, st));
-    LAUNCH(ctx, "ir_bb_offsets", k_ir_bb_offsets, grid_for(n_funcs, 64), 64, R->d_funcs, n_funcs, cnt, B, R->d_bb_offsets, IrCnt{}, (const uint32_t*)fb_flag, (const FbIdx*)fbx);
-    if (fb_funcs) {
-        IrOut O{R->d_vars, R->d_instrs, R->d_cargs, R->d_types, R->d_errs, R->d_bb_offsets, n_gtypes};
-        unsigned grid = (unsigned)((n_funcs + 3) / 4);
-        if (grid > 8192) grid = 8192;
-        LAUNCH(ctx, "ir_compact", k_ir_compact, grid, 256, R->d_funcs, n_funcs, B, types, O, (const uint32_t*)fb_flag, (const FbIdx*)fbx);
-    }
-    PA.fb_flag = fb_flag; PA.vars = R->d_vars; PA.instrs = R->d_instrs; PA.bb_offsets = R->d_bb_offsets; PA.cargs = R->d_cargs; PA.types_out = R->d_types;
-    S.types = gtypes;
-    launch_par(true);
-    HIP_TRY(hipMemcpyAsync(ctx->h_status, ctx->d_status, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    prof_collect(ctx);
-    if (ctx->h_status[WL_STATUS] >= DS_INTERNAL_CAPACITY) { u->status = OPUSFE_ERR_INTERNAL; ctx->msg = "lowering: the count and emit passes of the node-parallel path disagree"; return; }
     u->n_funcs = n_funcs; u->n_instrs = R->n_instrs; u->n_vars = R->n_vars; u->n_bbs = R->n_bbs; u->n_types = R->n_types;
     u->status = OPUSFE_OK;
 }

@@ -72,10 +72,32 @@ __host__ __device__ __forceinline__ Desc d_inner(Desc d) {      // nw > 0: the p
 struct ParArgs {
     const uint32_t* def_nodes; uint32_t n_defs, n_nodes; const DefCnt* def_excl; const uint8_t* undefined_flag; const uint64_t* user_syms;
     const uint32_t* list; uint32_t n_list; uint32_t nmax, maxdef; uint32_t pp_base;
-    FuncIr* out; uint32_t* status; const uint32_t* fb_flag;   // emit pass: functions the sequential machine lowered
-    // emit pass: the dense result arrays
+    FuncIr* out; uint32_t* status;
+    // The dense result arrays, filled in ONE pass: a function that knows its sizes takes its place in each array with an
+    // atomic add on `counters` (bump allocation: the layout is dense, its order is the order in which functions finish).
+    // counters[0] = instructions | blocks << 36 (one atomic, so that block order and instruction order agree: the end of a
+    // function's last block is the start of the next function's first), [1] variables, [2] local types, [3] call arguments.
+    // When an array is too small nothing is written, `overflow` is raised and the host runs again with the exact totals.
+    uint32_t stop_phase;      // diagnostics (OPUSFE_PAR_STOP): leave after phase n, 0 = run everything
+    unsigned long long* counters; uint32_t* overflow; uint32_t* err_counter;   // (semantic errors: sequential machine only)
+    uint64_t cap_vars, cap_instrs, cap_bbs, cap_types, cap_cargs, cap_errs;
     opusfe_variable* vars; opusfe_instr* instrs; uint32_t* bb_offsets; uint32_t* cargs; TypeRec* types_out;
 };
+enum { CTR_INSTR_BB = 0, CTR_VARS = 1, CTR_TYPES = 2, CTR_CARGS = 3, CTR_COUNT = 4, CTR_BB_SHIFT = 36 };
+struct Bases { uint32_t var_base, instr_base, bb_base, type_base, carg_base; bool fits; };
+// a function's place in the dense arrays (one lane)
+__device__ __forceinline__ Bases bump_allocate(const ParArgs& A, uint32_t n_vars, uint32_t n_instrs, uint32_t n_bbs, uint32_t n_types, uint32_t n_cargs) {
+    Bases b;
+    const unsigned long long ib = atomicAdd(A.counters + CTR_INSTR_BB, (unsigned long long)n_instrs | ((unsigned long long)n_bbs << CTR_BB_SHIFT));
+    const uint64_t i0 = ib & ((1ull << CTR_BB_SHIFT) - 1), b0 = ib >> CTR_BB_SHIFT;
+    const uint64_t v0 = atomicAdd(A.counters + CTR_VARS, (unsigned long long)n_vars);
+    const uint64_t t0 = n_types ? atomicAdd(A.counters + CTR_TYPES, (unsigned long long)n_types) : 0ull;
+    const uint64_t c0 = n_cargs ? atomicAdd(A.counters + CTR_CARGS, (unsigned long long)n_cargs) : 0ull;
+    b.fits = i0 + n_instrs <= A.cap_instrs && b0 + n_bbs <= A.cap_bbs && v0 + n_vars <= A.cap_vars && t0 + n_types <= A.cap_types && c0 + n_cargs <= A.cap_cargs;
+    b.instr_base = (uint32_t)i0; b.bb_base = (uint32_t)b0; b.var_base = (uint32_t)v0; b.type_base = (uint32_t)t0; b.carg_base = (uint32_t)c0;
+    if (!b.fits) atomicMax(A.overflow, 1u);
+    return b;
+}
 
 struct DefEnt { uint32_t hash, low, len, node, dpoint, send, var; uint32_t pad; Desc vt; };   // a local definition, visible to nodes of pre-order rank [dpoint, send); vt = type of its variable
 struct ArgEnt { uint32_t hash, low, len, pad; Desc vt; };
@@ -87,7 +109,7 @@ enum : uint32_t { ST_DONE = 1u, ST_STAGE1 = 2u /* for: the loop variable has its
                   ST_EXP_SHIFT = 16, ST_EXP_MASK = 15u << 16 };
 enum : uint32_t { EXP_NONE = 0, EXP_GENINT, EXP_BOOL, EXP_RET, EXP_SIZE, EXP_ASSIGN, EXP_FIELD, EXP_ARG };
 // name resolution results (ref[]): tag in the top 3 bits
-enum : uint32_t { RF_NONE = 0u, RF_LOCAL = 1u << 29, RF_ARG = 2u << 29, RF_GLOBAL = 3u << 29, RF_CONST = 4u << 29, RF_FUNC = 5u << 29, RF_CALL = 6u << 29, RF_TAG = 7u << 29, RF_VAL = ~(7u << 29) };
+enum : uint32_t { RF_NONE = 0u, RF_LOCAL = 1u << 29, RF_ARG = 2u << 29, RF_GLOBAL = 3u << 29, RF_CONST = 4u << 29, RF_FUNC = 5u << 29, RF_CALL = 6u << 29, RF_CALL1 = 7u << 29 /* exactly one function of that name: its index */, RF_TAG = 7u << 29, RF_VAL = ~(7u << 29) };
 // result-variable info (rvi[]): who created the variable that holds a node's result
 enum : uint32_t { RV_OWN = 0u, RV_PASS = 1u << 29, RV_LOCAL = 2u << 29, RV_ARG = 3u << 29, RV_RESOLVED = 7u << 29, RV_TAG = 7u << 29, RV_VAL = ~(7u << 29) };
 enum : uint8_t { TAIL_NONE = 0, TAIL_INSTR = 1, TAIL_TERM = 2, TAIL_NEWBB = 3 };
@@ -101,20 +123,20 @@ struct Fn {
     SemView S; ParArgs A;
     uint32_t dn, nn, fidx, nargs; FuncRec F; uint64_t user_syms;
     // LDS
-    uint64_t* rt; uint64_t* cnt; uint32_t* kn; uint32_t* st; uint32_t* ref; uint32_t* rvi;
+    uint64_t* rt; uint64_t* cnt; uint32_t* kn; uint32_t* st; uint32_t* ref; uint32_t* rvi; uint32_t* pay;
     uint16_t* fc; uint16_t* nx; uint16_t* pa; uint16_t* rk; uint16_t* sz; uint16_t* pe; uint16_t* cg; uint8_t* tail;
     DefEnt* defs; ArgEnt* args; uint32_t* misc; uint64_t* scratch;
     // emit bases
     uint32_t var_base, instr_base, bb_base, type_base, carg_base, n_vars_tot, n_instrs_tot, n_bbs_tot, n_types_tot, n_cargs_tot;
     uint32_t tid, nthreads;
 };
-enum { MI_FB = 0, MI_NDEFS = 1, MI_SUM_V = 2, MI_SUM_T = 3, MI_SUM_I = 4, MI_SUM_B = 5, MI_BAD = 6, MI_WHY = 7, MI_WORDS = 8 };
+enum { MI_FB = 0, MI_NDEFS = 1, MI_SUM_V = 2, MI_SUM_T = 3, MI_SUM_I = 4, MI_SUM_B = 5, MI_BAD = 6, MI_WHY = 7, MI_VBASE = 8, MI_IBASE = 9, MI_BBASE = 10, MI_TBASE = 11, MI_CBASE = 12, MI_FITS = 13, MI_WORDS = 16 };
 
 __host__ __device__ inline size_t lds_bytes(uint32_t nmax, uint32_t maxdef, uint32_t nthreads) {
     size_t b = 0;
     b += 8ull * nmax;            // rt
     b += 8ull * 2 * nmax;        // cnt
-    b += 4ull * 4 * nmax;        // kn st ref rvi
+    b += 4ull * 5 * nmax;        // kn st ref rvi pay
     b += 2ull * 7 * nmax;        // fc nx pa rk sz pe cg
     b += 2ull * nmax;            // tail (2 per node)
     b = (b + 7) & ~(size_t)7;
@@ -141,7 +163,7 @@ __device__ __forceinline__ uint32_t RANK_END(const Fn& f, uint32_t i) { return (
 __device__ __forceinline__ uint32_t child_at(const Fn& f, uint32_t i, uint32_t k) { uint32_t c = f.fc[i]; while (k-- && c != NONE16) c = f.nx[c]; return c; }
 __device__ __forceinline__ uint32_t last_child(const Fn& f, uint32_t i) { uint32_t c = f.fc[i], l = NONE16; while (c != NONE16) { l = c; c = f.nx[c]; } return l; }
 // global type id of a parse-tree type node of this function
-__device__ __forceinline__ uint32_t TID(const Fn& f, uint32_t local_node) { return f.S.tid_of_node[f.dn + local_node]; }
+__device__ __forceinline__ uint32_t TID(const Fn& f, uint32_t local_node) { return f.ref[local_node]; }      // (type nodes keep their resolved id in ref[], loaded with the node)
 
 // ---- views of a type ------------------------------------------------------------------------------------------------
 struct TView { uint8_t kind, ptr; bool plain; Desc sub; TypeRec rec; };
@@ -441,7 +463,8 @@ template <bool EMIT> __device__ __forceinline__ Val<EMIT> autocast(Fn& f, Em<EMI
         if (!EMIT) {
             const uint32_t x = creator_of(f, src_node);
             if (KIND(f, x) != E_Integer || !d_plain(want)) { fallback(f); return val; }
-            f.ref[x] = d_base(want);
+            if (d_base(want) >= TP_COUNT) { fallback(f); return val; }
+            f.ref[x] = (f.ref[x] & 0xFFFFFFu) | ((d_base(want) + 1u) << 24);
         }
         val.t = want;
         return val;
@@ -553,7 +576,7 @@ __device__ __forceinline__ Desc expected_of(Fn& f, uint32_t i, bool* ready) {
             uint32_t a = f.pa[i];
             while (a != NONE16 && (KIND(f, a) == E_Parentheses || KIND(f, a) == E_Negate)) a = f.pa[a];
             if (a == NONE16) { fallback(f); return DESC_NONE; }
-            if (exp == EXP_ARG) return d_id((f.ref[a] & RF_TAG) == RF_CALL ? (uint32_t)TP_GenericInteger : (uint32_t)TP_Size);   // call argument / index
+            if (exp == EXP_ARG) return d_id(((f.ref[a] & RF_TAG) == RF_CALL || (f.ref[a] & RF_TAG) == RF_CALL1) ? (uint32_t)TP_GenericInteger : (uint32_t)TP_Size);   // call argument / index
             if (exp == EXP_ASSIGN) {
                 const uint32_t lhs = f.fc[a];
                 if (!(f.st[lhs] & ST_DONE)) { *ready = false; return DESC_NONE; }
@@ -563,7 +586,7 @@ __device__ __forceinline__ Desc expected_of(Fn& f, uint32_t i, bool* ready) {
             const uint32_t recnode = f.pa[a];
             const TView r = view(f, d_id(TID(f, f.fc[recnode])));
             if (r.kind != TY_Record) return DESC_NONE;
-            const uint32_t ft = record_field(f, r.rec, f.S.tok[ND(f, a).payload]);
+            const uint32_t ft = record_field(f, r.rec, f.S.tok[f.pay[a]]);
             return ft == OPUSFE_NONE ? DESC_NONE : d_id(ft);
         }
         default: return DESC_NONE;
@@ -623,7 +646,7 @@ __device__ __forceinline__ bool operands_done(const Fn& f, uint32_t i) {
 }
 
 // Lowers node i: all events it owns.  Returns false when an input is not ready yet (count pass only).
-template <bool EMIT> __device__ bool visit(Fn& f, uint32_t i) {
+template <bool EMIT> __device__ __forceinline__ bool visit(Fn& f, uint32_t i) {
     const uint32_t st = f.st[i];
     const uint8_t kind = KIND(f, i);
     const uint32_t mode = st & ST_MODE_MASK;
@@ -801,10 +824,11 @@ template <bool EMIT> __device__ bool visit(Fn& f, uint32_t i) {
     if (mode == ST_MODE_E) {
         switch (kind) {
             case E_Integer: {
-                const opusfe_token t = f.S.tok[ND(f, i).payload];
+                // ref[i] = the token's aux word (suffix) | the final type + 1 of the variable << 24 once an autocast retyped it
+                const uint32_t aux = f.ref[i] & 0xFFFF;
                 Desc typ;
-                if (t.aux & 0x8000) {
-                    const uint32_t size = t.aux & 0xFF; const bool sg = (t.aux & 0x100) != 0;
+                if (aux & 0x8000) {
+                    const uint32_t size = aux & 0xFF; const bool sg = (aux & 0x100) != 0;
                     uint32_t p;
                     if (!sg) p = size == 8 ? TP_Natural8 : size == 16 ? TP_Natural16 : size == 32 ? TP_Natural32 : size == 64 ? TP_Natural64 : TP_Size;
                     else p = size == 8 ? TP_Integer8 : size == 16 ? TP_Integer16 : size == 32 ? TP_Integer32 : size == 64 ? TP_Integer64 : TP_Offset;
@@ -818,17 +842,21 @@ template <bool EMIT> __device__ bool visit(Fn& f, uint32_t i) {
                     if (exp != DESC_NONE) k = view(f, exp).kind;
                     typ = (exp != DESC_NONE && (kind_is_integral(k) || k == TY_GenericInteger)) ? exp : d_id(TP_Integer32);
                 }
-                uint64_t val = (t.flags & OPUSFE_TF_INLINE) ? (uint64_t)t.payload : f.S.val64[t.payload];
-                // a <integer> literal under unary minus is negated in place (generate_ir.rs:766-780): one sign flip per Negate above it
-                if (view(f, typ).kind == TY_GenericInteger) {
-                    uint32_t a = f.pa[i]; bool neg = false;
-                    while (a != NONE16 && (KIND(f, a) == E_Parentheses || KIND(f, a) == E_Negate)) { if (KIND(f, a) == E_Negate) neg = !neg; a = f.pa[a]; }
-                    if (neg) val = 0 - val;
+                uint64_t val = 0;
+                if (EMIT) {
+                    const opusfe_token t = f.S.tok[f.pay[i]];
+                    val = (t.flags & OPUSFE_TF_INLINE) ? (uint64_t)t.payload : f.S.val64[t.payload];
+                    // a <integer> literal under unary minus is negated in place (generate_ir.rs:766-780): one sign flip per Negate above it
+                    if (view(f, typ).kind == TY_GenericInteger) {
+                        uint32_t a = f.pa[i]; bool neg = false;
+                        while (a != NONE16 && (KIND(f, a) == E_Parentheses || KIND(f, a) == E_Negate)) { if (KIND(f, a) == E_Negate) neg = !neg; a = f.pa[a]; }
+                        if (neg) val = 0 - val;
+                    }
                 }
                 Em<EMIT> e = open_slot<EMIT>(f, POS_ENTER(f, i));
                 Val<EMIT> o; o.t = typ; o.info = own_rv(e.pos, e.v);
-                if (!EMIT) f.ref[i] = OPUSFE_NONE;
-                const Desc final_t = (EMIT && f.ref[i] != OPUSFE_NONE) ? d_id(f.ref[i]) : typ;
+                const uint32_t fin = f.ref[i] >> 24;
+                const Desc final_t = (EMIT && fin) ? d_id(fin - 1) : typ;
                 o.var = e.newvar(f, final_t, true);
                 e.ins(f, I_Integer, o.var, 0, 0, (uint32_t)val, (uint32_t)(val >> 32));
                 close_slot(f, e);
@@ -836,18 +864,17 @@ template <bool EMIT> __device__ bool visit(Fn& f, uint32_t i) {
                 return true;
             }
             case E_Float: case E_Null: case E_Bool: case E_String: {
-                const opusfe_node nd = ND(f, i);
                 Em<EMIT> e = open_slot<EMIT>(f, POS_ENTER(f, i));
                 Val<EMIT> o; o.info = own_rv(e.pos, e.v);
                 if (kind == E_Float) {
-                    const opusfe_token t = f.S.tok[nd.payload];
-                    const uint64_t bits = f.S.val64[t.payload];
-                    o.t = d_id(t.aux == 32 ? TP_Float32 : TP_Float64);
+                    uint64_t bits = 0;
+                    if (EMIT) bits = f.S.val64[f.S.tok[f.pay[i]].payload];
+                    o.t = d_id((f.ref[i] & 0xFFFF) == 32 ? TP_Float32 : TP_Float64);      // (the token's aux word, fetched with the names)
                     o.var = e.newvar(f, o.t, true);
                     e.ins(f, I_Float, o.var, 0, 0, (uint32_t)bits, (uint32_t)(bits >> 32));
                 } else if (kind == E_Null) { o.t = d_id(TP_Null); o.var = e.newvar(f, o.t, true); e.ins(f, I_Null, o.var); }
-                else if (kind == E_Bool) { o.t = d_id(TP_Bool); o.var = e.newvar(f, o.t, true); e.ins(f, I_Bool, o.var, 0, 0, 0, 0, nd.sub); }
-                else { o.t = d_id(TP_String); o.var = e.newvar(f, o.t, true); e.ins(f, I_String, o.var, 0, 0, nd.payload); }
+                else if (kind == E_Bool) { o.t = d_id(TP_Bool); o.var = e.newvar(f, o.t, true); e.ins(f, I_Bool, o.var, 0, 0, 0, 0, SUB(f, i)); }
+                else { o.t = d_id(TP_String); o.var = e.newvar(f, o.t, true); e.ins(f, I_String, o.var, 0, 0, f.pay[i]); }
                 close_slot(f, e);
                 set_result<EMIT>(f, i, o);
                 return true;
@@ -980,13 +1007,13 @@ template <bool EMIT> __device__ bool visit(Fn& f, uint32_t i) {
                 v.t = f.args[idx].vt; v.info = RV_ARG | idx; v.var = f.nargs + idx;
                 v = try_cast_pointer<EMIT>(f, e, v, pt);
             } else if (tag == RF_GLOBAL) {
-                v.t = d_ptr(f, PT_Mutable, d_id(f.S.globals[idx].type_id));
+                v.t = d_ptr(f, PT_Mutable, EMIT ? d_id(f.S.globals[idx].type_id) : f.rt[i]);
                 v.info = own_rv(e.pos, e.v);
                 v.var = e.newvar(f, v.t, true);
                 e.ins(f, I_GlobalVariable, v.var, 0, 0, idx);
                 v = try_cast_pointer<EMIT>(f, e, v, pt);
             } else if (tag == RF_CONST) {
-                v.t = d_id(f.S.globals[idx].type_id);
+                v.t = EMIT ? d_id(f.S.globals[idx].type_id) : f.rt[i];
                 v.info = own_rv(e.pos, e.v);
                 v.var = e.newvar(f, v.t, true);
                 e.ins(f, I_GlobalConstant, v.var, 0, 0, idx);
@@ -1030,7 +1057,7 @@ template <bool EMIT> __device__ bool visit(Fn& f, uint32_t i) {
         case E_Field: {                      // :1027-1030
             const uint32_t c = f.fc[i];
             Em<EMIT> e = open_slot<EMIT>(f, POS_EXIT(f, c));
-            Val<EMIT> v = field_access<EMIT>(f, e, child_val<EMIT>(f, c), ND(f, i).payload, pt);
+            Val<EMIT> v = field_access<EMIT>(f, e, child_val<EMIT>(f, c), f.pay[i], pt);
             if (failed(f)) return true;
             v = p_result<EMIT>(f, e, v, true, st);
             close_slot(f, e);
@@ -1041,23 +1068,41 @@ template <bool EMIT> __device__ bool visit(Fn& f, uint32_t i) {
             const uint32_t r = f.ref[i], tag = r & RF_TAG, idx = r & RF_VAL;
             const uint32_t n = NCH(f, i);
             const uint32_t lastc = last_child(f, i);
-            if (tag == RF_CALL) {              // :1031-1045 + get_function_call_variables :1181-1198
+            if (tag == RF_CALL || tag == RF_CALL1) {   // :1031-1045 + get_function_call_variables :1181-1198
                 if (n > MAX_CALL_ARGS) { fallback(f); return true; }
                 Em<EMIT> e = open_slot<EMIT>(f, n ? POS_EXIT(f, lastc) : POS_ENTER(f, i));
-                Desc at[MAX_CALL_ARGS]; uint32_t an[MAX_CALL_ARGS];
+                Desc at[MAX_CALL_ARGS]; uint32_t an[MAX_CALL_ARGS], want[MAX_CALL_ARGS];
                 uint32_t k = 0;
                 for (uint32_t c = f.fc[i]; c != NONE16 && k < MAX_CALL_ARGS; c = f.nx[c], k++) { at[k] = f.rt[c]; an[k] = c; if (at[k] == DESC_NONE || view(f, at[k]).kind == TY_Error) { fallback(f); return true; } }
-                const uint32_t fn = lookup_function(f, key_tok(ND(f, i).payload), at, n);
-                if (failed(f) || fn == FN_NONE || fn_builtin(fn)) { fallback(f); return true; }
+                uint32_t fn; Desc ret_t;
+                if (tag == RF_CALL1) {
+                    // the only candidate: it is the callee iff every argument autocasts to its parameter (compile.rs:1085-1139 with one function)
+                    fn = idx;
+                    if (EMIT) { for (k = 0; k < n; k++) want[k] = fn_arg_type(f, fn, k); ret_t = d_id(fn_ret(f, fn)); }
+                    else {
+                        for (k = 0; k < n; k++) {
+                            want[k] = (uint32_t)f.cnt[POS_EXIT(f, an[k])];
+                            f.cnt[POS_EXIT(f, an[k])] = 0;                     // back to an empty event
+                            const int c = can_autocast3(f, at[k], d_id(want[k]));
+                            if (c < 0) { fallback(f); return true; }
+                        }
+                        ret_t = f.rt[i];
+                    }
+                } else {
+                    fn = lookup_function(f, key_tok(f.pay[i]), at, n);
+                    if (failed(f) || fn == FN_NONE || fn_builtin(fn)) { fallback(f); return true; }
+                    for (k = 0; k < n; k++) want[k] = fn_arg_type(f, fn, k);
+                    ret_t = d_id(fn_ret(f, fn));
+                }
                 const uint32_t fv = e.newvar(f, d_func(fn), true);
                 e.ins(f, I_Function, fv, 0, 0, fn);
                 const uint32_t cg = EMIT ? f.carg_base + f.cg[i] : 0u;
                 for (k = 0; k < n; k++) {
-                    Val<EMIT> a = autocast<EMIT>(f, e, child_val<EMIT>(f, an[k]), an[k], d_id(fn_arg_type(f, fn, k)));
+                    Val<EMIT> a = autocast<EMIT>(f, e, child_val<EMIT>(f, an[k]), an[k], d_id(want[k]));
                     if (EMIT) gst(f.A.cargs + cg + k, a.var);
                 }
                 if (failed(f)) return true;
-                Val<EMIT> o; o.t = d_id(fn_ret(f, fn)); o.info = own_rv(e.pos, e.v);
+                Val<EMIT> o; o.t = ret_t; o.info = own_rv(e.pos, e.v);
                 o.var = e.newvar(f, o.t, true);
                 e.ins(f, I_Call, o.var, fv, 0, cg, 0, (uint16_t)n);
                 o = p_result<EMIT>(f, e, o, false, st);
@@ -1075,7 +1120,7 @@ template <bool EMIT> __device__ bool visit(Fn& f, uint32_t i) {
                 if (!EMIT && d.vt == DESC_NONE) return false;
                 v.t = d.vt; v.var = EMIT ? d.var : 0u;
             } else if (tag == RF_ARG) { v.t = f.args[idx].vt; v.var = f.nargs + idx; }
-            else if (tag == RF_GLOBAL) { v.t = d_ptr(f, PT_Mutable, d_id(f.S.globals[idx].type_id)); v.var = e.newvar(f, v.t, true); e.ins(f, I_GlobalVariable, v.var, 0, 0, idx); }
+            else if (tag == RF_GLOBAL) { v.t = d_ptr(f, PT_Mutable, EMIT ? d_id(f.S.globals[idx].type_id) : f.rt[i]); v.var = e.newvar(f, v.t, true); e.ins(f, I_GlobalVariable, v.var, 0, 0, idx); }
             else { fallback(f); return true; }
             v = try_cast_pointer<EMIT>(f, e, v, pt);
             if (failed(f)) return true;
@@ -1120,7 +1165,7 @@ template <bool EMIT> __device__ bool visit(Fn& f, uint32_t i) {
             for (; fi != NONE16; fi = f.nx[fi]) {
                 Em<EMIT> e2 = open_slot<EMIT>(f, POS_EXIT(f, fi));
                 const uint32_t val = f.fc[fi];
-                Val<EMIT> fv = field_access<EMIT>(f, e2, out, ND(f, fi).payload, PT_Mutable);
+                Val<EMIT> fv = field_access<EMIT>(f, e2, out, f.pay[fi], PT_Mutable);
                 if (failed(f)) return true;
                 e2.ins(f, I_Store, 0, fv.var, RV<EMIT>(f, val));
                 if (f.nx[fi] == NONE16) res = p_result<EMIT>(f, e2, out, true, st);
@@ -1144,7 +1189,19 @@ template <class E> __device__ __forceinline__ uint64_t block_scan(Fn& f, E* a, u
     PAR_SYNC();
     f.scratch[f.tid] = sum;
     PAR_SYNC();
+#ifdef OPUSFE_EMU
     if (f.tid == 0) { uint64_t run = 0; for (uint32_t k = 0; k < T; k++) { const uint64_t v = f.scratch[k]; f.scratch[k] = run; run += v; } f.scratch[T] = run; }
+#else
+    if (f.tid < 64) {      // the first wave scans the per-thread sums: T / 64 each, a shuffle scan across the lanes
+        const uint32_t per2 = T / 64, b2 = f.tid * per2;
+        uint64_t s2 = 0;
+        for (uint32_t k = 0; k < per2; k++) s2 += f.scratch[b2 + k];
+        const uint64_t incl = wave_inclusive_scan(s2, OpAddU64());
+        uint64_t run2 = incl - s2;
+        for (uint32_t k = 0; k < per2; k++) { const uint64_t v = f.scratch[b2 + k]; f.scratch[b2 + k] = run2; run2 += v; }
+        if (f.tid == 63) f.scratch[T] = incl;
+    }
+#endif
     PAR_SYNC();
     uint64_t run = f.scratch[f.tid];
     for (uint32_t k = lo; k < hi; k++) { const uint64_t v = a[k]; a[k] = (E)run; run += v; }
@@ -1154,7 +1211,7 @@ template <class E> __device__ __forceinline__ uint64_t block_scan(Fn& f, E* a, u
 }
 
 // One function per workgroup.
-template <bool EMIT> __device__ void lower_function(Fn& f) {
+__device__ __forceinline__ void lower_function(Fn& f) {
     const uint32_t nn = f.nn, tid = f.tid, T = f.nthreads;
     if (tid == 0) { for (uint32_t k = 0; k < MI_WORDS; k++) f.misc[k] = 0; }
     PAR_SYNC();
@@ -1165,7 +1222,8 @@ template <bool EMIT> __device__ void lower_function(Fn& f) {
         const uint32_t fc = n.first_child == OPUSFE_NONE ? NONE16 : n.first_child - f.dn, nx = n.next == OPUSFE_NONE ? NONE16 : n.next - f.dn;
         if ((fc != NONE16 && fc >= nn) || (nx != NONE16 && nx >= nn)) fallback(f);      // links must stay inside the function
         f.fc[i] = (uint16_t)fc; f.nx[i] = (uint16_t)nx;
-        f.pa[i] = NONE16; f.st[i] = 0; f.ref[i] = 0; f.rvi[i] = 0; f.rt[i] = DESC_NONE; f.cg[i] = 0; f.rk[i] = 0; f.sz[i] = 0; f.pe[i] = 0;
+        f.pay[i] = n.payload;
+        f.pa[i] = NONE16; f.st[i] = 0; f.ref[i] = (n.kind >= Y_Name && n.kind <= Y_Array) ? f.S.tid_of_node[f.dn + i] : 0u; f.rvi[i] = 0; f.rt[i] = DESC_NONE; f.cg[i] = 0; f.rk[i] = 0; f.sz[i] = 0; f.pe[i] = 0;
         f.cnt[2 * i] = 0; f.cnt[2 * i + 1] = 0; f.tail[2 * i] = TAIL_NONE; f.tail[2 * i + 1] = TAIL_NONE;
         if (f.A.undefined_flag[f.dn + i]) fallback(f);                                // UndefinedType somewhere in the function
     }
@@ -1174,6 +1232,7 @@ template <bool EMIT> __device__ void lower_function(Fn& f) {
     for (uint32_t i = tid; i < nn; i += T) { uint32_t guard = 0; for (uint32_t c = f.fc[i]; c != NONE16 && guard <= nn; c = f.nx[c], guard++) f.pa[c] = (uint16_t)i; if (guard > nn) fallback(f); }
     PAR_SYNC();
     if (failed(f)) return;
+    if (f.A.stop_phase == 1) { fallback(f); return; }
     // subtree sizes, bottom-up
     for (uint32_t round = 0; round <= nn; round++) {
         bool progress = false;
@@ -1191,6 +1250,7 @@ template <bool EMIT> __device__ void lower_function(Fn& f) {
     if (!(f.st[0] & ST_SIZED) || f.sz[0] != nn) { fallback(f); }                       // every node must hang under the root (no cycles, no strays)
     PAR_SYNC();
     if (failed(f)) return;
+    if (f.A.stop_phase == 2) { fallback(f); return; }
     // pre-order rank, depth and evaluation context, top-down: a node that has its own hands them to its children
     if (tid == 0) { f.rk[0] = 0; f.pe[0] = 0; f.st[0] |= ST_CTX; }
     PAR_SYNC();
@@ -1253,12 +1313,13 @@ template <bool EMIT> __device__ void lower_function(Fn& f) {
         if (!par_sync_or(progress)) break;
     }
     if (failed(f)) return;
+    if (f.A.stop_phase == 3) { fallback(f); return; }
     // ---- arguments and local definitions ----
     if (tid == 0) {
         uint32_t a = f.fc[0], k = 0;
         while (a != NONE16 && KIND(f, a) == X_NamedType) {
             if (k >= MAX_ARGS) { fallback(f); break; }
-            const opusfe_token t = f.S.tok[ND(f, a).payload];
+            const opusfe_token t = f.S.tok[f.pay[a]];
             if (t.kind != T_Identifier) { fallback(f); break; }                         // a symbol as a variable name (sym_locals)
             ArgEnt e; e.hash = t.payload; e.low = t.low; e.len = t.len; e.pad = 0; e.vt = d_ptr(f, PT_Mutable, d_id(TID(f, f.fc[a])));
             f.args[k++] = e;
@@ -1273,7 +1334,7 @@ template <bool EMIT> __device__ void lower_function(Fn& f) {
             if (f.st[i] & ST_DEAD) { fallback(f); continue; }                           // a definition in code that is never evaluated
             const uint32_t slot = atomicAdd(&f.misc[MI_NDEFS], 1u);
             if (slot >= f.A.maxdef) { fallback(f); continue; }
-            const opusfe_token t = f.S.tok[ND(f, i).payload];
+            const opusfe_token t = f.S.tok[f.pay[i]];
             if (t.kind != T_Identifier) { fallback(f); continue; }
             DefEnt d; d.hash = t.payload; d.low = t.low; d.len = t.len; d.node = i; d.var = 0; d.pad = 0; d.vt = DESC_NONE;
             if (k == S_For) { uint32_t cond, tb, eb; blocks_of(f, i, &cond, &tb, &eb); if (tb == NONE16) { fallback(f); continue; } d.dpoint = RANK(f, tb); d.send = RANK_END(f, tb); }
@@ -1316,11 +1377,15 @@ template <bool EMIT> __device__ void lower_function(Fn& f) {
         }
         for (uint32_t a = tid; a < f.nargs; a += T) for (uint32_t b = 0; b < a; b++) { const ArgEnt& x = f.args[a]; const ArgEnt& y = f.args[b]; if (x.hash == y.hash && x.len == y.len && bytes_eq(f, x.low, y.low, x.len)) fallback(f); }
     }
+    PAR_SYNC();
+    if (f.A.stop_phase == 4) { fallback(f); return; }
     // ---- names ----
     for (uint32_t i = tid; i < nn; i += T) {
         const uint8_t k = KIND(f, i);
-        if ((k != E_Variable && k != E_NamedCall) || (f.st[i] & ST_DEAD)) continue;
-        const uint32_t name_tok = ND(f, i).payload;
+        if (f.st[i] & ST_DEAD) continue;
+        if (k == E_Integer || k == E_Float) { f.ref[i] = f.S.tok[f.pay[i]].aux; continue; }     // the literal's suffix decides its type
+        if (k != E_Variable && k != E_NamedCall) continue;
+        const uint32_t name_tok = f.pay[i];
         const opusfe_token t = f.S.tok[name_tok];
         if (t.kind != T_Identifier) { fallback(f); continue; }
         const uint32_t local = find_local(f, t, i);
@@ -1329,6 +1394,20 @@ template <bool EMIT> __device__ void lower_function(Fn& f) {
             if (local != RF_NONE) { fallback(f); continue; }      // a local shadows the functions of that name (:1152-1158)
             f.ref[i] = RF_CALL | (slot & RF_VAL);
             f.cg[i] = (uint16_t)NCH(f, i);
+            // One function of that name (the common case): everything the visit needs from the tables is fetched HERE, where all
+            // call nodes do it at once, instead of inside the type fixpoint: the return type goes to rt[i], the parameter types to
+            // the EXIT slots of the arguments (this node owns them; they are read before it counts into the last one).
+            const NameSlot sl = f.S.slots[slot];
+            uint32_t nfn = 0, only = 0;
+            for (uint32_t j = 0; j < sl.count; j++) { const NameEntry e = f.S.entries[sl.offset + j]; if ((e.kind_index >> 30) == NK_FUNCTION) { nfn++; only = e.kind_index & 0x3FFFFFFFu; } }
+            if (nfn == 1 && NCH(f, i) <= MAX_CALL_ARGS) {
+                const FuncRec fr = f.S.funcs[only];
+                if (fr.nargs != NCH(f, i)) { fallback(f); continue; }                      // NoOverloadForFunction
+                uint32_t c = f.fc[i], a = fr.first_arg;
+                for (uint32_t q = 0; q < fr.nargs && c != NONE16; q++) { f.cnt[POS_EXIT(f, c)] = f.S.tid_of_node[f.S.nodes[a].first_child]; a = f.S.nodes[a].next; c = f.nx[c]; }
+                f.rt[i] = d_id(fr.ret);
+                f.ref[i] = RF_CALL1 | only;
+            }
             continue;
         }
         if (local != RF_NONE) { f.ref[i] = local; continue; }
@@ -1345,6 +1424,7 @@ template <bool EMIT> __device__ void lower_function(Fn& f) {
             if (r == RF_NONE && nfn == 1) r = RF_FUNC | only;
         }
         if (r == RF_NONE || (k == E_NamedCall && ((r & RF_TAG) == RF_CONST || (r & RF_TAG) == RF_FUNC))) { fallback(f); continue; }
+        if ((r & RF_TAG) == RF_GLOBAL || (r & RF_TAG) == RF_CONST) f.rt[i] = d_id(f.S.globals[r & RF_VAL].type_id);    // fetched here, read by the visit
         f.ref[i] = r;
     }
     // operator calls and `for` reserve their call arguments too (user overloads only use them; sized for the worst case)
@@ -1355,6 +1435,7 @@ template <bool EMIT> __device__ void lower_function(Fn& f) {
     }
     PAR_SYNC();
     if (failed(f)) return;
+    if (f.A.stop_phase == 5) { fallback(f); return; }
     // ---- types, counts (bottom-up fixpoint) ----
     for (uint32_t round = 0; round <= nn + 1; round++) {
         bool progress = false;
@@ -1375,6 +1456,7 @@ template <bool EMIT> __device__ void lower_function(Fn& f) {
     }
     if (failed(f)) return;
     if (!(f.st[0] & ST_DONE)) { fallback(f); return; }
+    if (f.A.stop_phase == 6) { fallback(f); return; }
     // ---- scans: Euler-order exclusive prefix of the event counters; call-argument slots in node order ----
     {   // the packed 16-bit fields must not carry into each other: check the four sums first
         uint32_t sv = 0, stt = 0, si = 0, sb = 0;
@@ -1389,15 +1471,21 @@ template <bool EMIT> __device__ void lower_function(Fn& f) {
     const Cnt4 tot = unpack4(block_scan(f, f.cnt, 2 * nn));
     const uint32_t tot_cargs = (uint32_t)block_scan(f, f.cg, nn);
     if (tot_cargs > 0xFFF0u) { fallback(f); return; }
-    if (!EMIT) {
-        if (tid == 0) {
-            FuncIr r{};
-            r.def_node = f.dn; r.func = f.fidx; r.n_vars = tot.v; r.n_instrs = tot.i; r.n_bbs = tot.b; r.n_types = tot.t; r.n_cargs = tot_cargs; r.n_errs = 0; r.status = DS_OK;
-            f.A.out[f.fidx] = r;
-        }
-        return;
+    if (f.A.stop_phase == 7) { fallback(f); return; }
+    // ---- the function's place in the dense arrays ----
+    if (tid == 0) {
+        const Bases b = bump_allocate(f.A, tot.v, tot.i, tot.b, tot.t, tot_cargs);
+        FuncIr r{};
+        r.def_node = f.dn; r.func = f.fidx; r.n_vars = tot.v; r.n_instrs = tot.i; r.n_bbs = tot.b; r.n_types = tot.t; r.n_cargs = tot_cargs; r.n_errs = 0; r.status = DS_OK;
+        r.var_base = b.var_base; r.instr_base = b.instr_base; r.bb_base = b.bb_base; r.type_base = b.type_base; r.carg_base = b.carg_base;
+        f.A.out[f.fidx] = r;
+        f.misc[MI_VBASE] = b.var_base; f.misc[MI_IBASE] = b.instr_base; f.misc[MI_BBASE] = b.bb_base; f.misc[MI_TBASE] = b.type_base; f.misc[MI_CBASE] = b.carg_base;
+        f.misc[MI_FITS] = b.fits ? 1u : 0u;
     }
-    if (tot.v != f.n_vars_tot || tot.i != f.n_instrs_tot || tot.b != f.n_bbs_tot || tot.t != f.n_types_tot || tot_cargs != f.n_cargs_tot) { f.misc[MI_BAD] = 1; return; }
+    PAR_SYNC();
+    if (!f.misc[MI_FITS]) return;                         // the host runs again with arrays of the exact size
+    f.var_base = f.misc[MI_VBASE]; f.instr_base = f.misc[MI_IBASE]; f.bb_base = f.misc[MI_BBASE]; f.type_base = f.misc[MI_TBASE]; f.carg_base = f.misc[MI_CBASE];
+    f.n_vars_tot = tot.v; f.n_instrs_tot = tot.i; f.n_bbs_tot = tot.b; f.n_types_tot = tot.t; f.n_cargs_tot = tot_cargs;
     // ---- result variables: every node learns the id of the variable that holds its result ----
     {
         const uint32_t nd = f.misc[MI_NDEFS];
@@ -1419,14 +1507,18 @@ template <bool EMIT> __device__ void lower_function(Fn& f) {
         f.rvi[i] = r;
     }
     PAR_SYNC();
+    if (f.A.stop_phase == 8) return;
     // ---- emit ----
     for (uint32_t i = tid; i < nn; i += T) if (!(f.st[i] & ST_DEAD)) visit<true>(f, i);
     PAR_SYNC();
 }
 
-// One workgroup per function of `list` (definition indices).  COUNT: FuncIr counts (or DS_FALLBACK).  EMIT: dense results.
-template <int THREADS, bool EMIT>
-__global__ __launch_bounds__(THREADS) void k_lower_par(SemView S, ParArgs A) {
+// One workgroup per function of `list` (definition indices): sizes, then the dense results (or DS_FALLBACK).
+#ifndef OPUSFE_PAR_WAVES
+#define OPUSFE_PAR_WAVES 4
+#endif
+template <int THREADS>
+__global__ MACHINE_ATTR(OPUSFE_PAR_WAVES) __launch_bounds__(THREADS) void k_lower_par(SemView S, ParArgs A) {
     const uint32_t slot = blockIdx.x;
     if (slot >= A.n_list) return;
     const uint32_t d = A.list ? A.list[slot] : slot;
@@ -1441,12 +1533,6 @@ __global__ __launch_bounds__(THREADS) void k_lower_par(SemView S, ParArgs A) {
     f.tid = threadIdx.x; f.nthreads = blockDim.x;
     f.var_base = f.instr_base = f.bb_base = f.type_base = f.carg_base = 0;
     f.n_vars_tot = f.n_instrs_tot = f.n_bbs_tot = f.n_types_tot = f.n_cargs_tot = 0;
-    if (EMIT) {
-        const FuncIr r = A.out[fidx];
-        if (A.fb_flag[fidx]) return;                         // lowered by the sequential machine
-        f.var_base = r.var_base; f.instr_base = r.instr_base; f.bb_base = r.bb_base; f.type_base = r.type_base; f.carg_base = r.carg_base;
-        f.n_vars_tot = r.n_vars; f.n_instrs_tot = r.n_instrs; f.n_bbs_tot = r.n_bbs; f.n_types_tot = r.n_types; f.n_cargs_tot = r.n_cargs;
-    }
     // carve the dynamic LDS block (same order as lds_bytes)
     uint8_t* base = (uint8_t*)PAR_LDS_BASE();
     const uint32_t nmax = A.nmax;
@@ -1456,6 +1542,7 @@ __global__ __launch_bounds__(THREADS) void k_lower_par(SemView S, ParArgs A) {
     f.st = (uint32_t*)base; base += 4ull * nmax;
     f.ref = (uint32_t*)base; base += 4ull * nmax;
     f.rvi = (uint32_t*)base; base += 4ull * nmax;
+    f.pay = (uint32_t*)base; base += 4ull * nmax;
     f.fc = (uint16_t*)base; base += 2ull * nmax;
     f.nx = (uint16_t*)base; base += 2ull * nmax;
     f.pa = (uint16_t*)base; base += 2ull * nmax;
@@ -1470,10 +1557,10 @@ __global__ __launch_bounds__(THREADS) void k_lower_par(SemView S, ParArgs A) {
     f.misc = (uint32_t*)base; base += 4 * MI_WORDS;
     base = (uint8_t*)(((uintptr_t)base + 7) & ~(uintptr_t)7);
     f.scratch = (uint64_t*)base;
-    lower_function<EMIT>(f);
+    lower_function(f);
     PAR_SYNC();
     if (f.tid == 0) {
-        if (EMIT) { if (f.misc[MI_BAD] || f.misc[MI_FB]) atomicMax(A.status, (uint32_t)DS_INTERNAL_CAPACITY); }   // the two passes must agree
+        if (f.misc[MI_BAD] || (f.misc[MI_FB] && f.misc[MI_FITS])) atomicMax(A.status, (uint32_t)DS_INTERNAL_CAPACITY);   // the count and emit visits must agree
         else if (f.misc[MI_FB]) { FuncIr r{}; r.def_node = dn; r.func = fidx; r.status = DS_FALLBACK; r.pad = f.misc[MI_WHY]; A.out[fidx] = r; }
     }
 }

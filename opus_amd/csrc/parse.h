@@ -818,8 +818,8 @@ inline void run_parser(opusfe_ctx* ctx, opusfe_unit* u) {
     uint32_t init[4] = {0xFFFFFFFFu, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(ctx->d_status + WP_FIRST_ERR, init, sizeof init, hipMemcpyHostToDevice, st));
     uint32_t* order = tmp.get<uint32_t>(n_segs);
-    uint32_t* order_hist = tmp.get<uint32_t>(33);
-    HIP_TRY(hipMemsetAsync(order_hist, 0, 33 * sizeof(uint32_t), st));
+    uint32_t* order_hist = tmp.get<uint32_t>(ORDER_CLASSES);
+    HIP_TRY(hipMemsetAsync(order_hist, 0, ORDER_CLASSES * sizeof(uint32_t), st));
     LAUNCH(ctx, "order_hist", k_order_hist, grid_for(n_segs, 256), 256, u->d_seg_start, n_segs, n_tok, order_hist);
     LAUNCH(ctx, "order_scan", k_order_scan, 1, 64, order_hist);
     LAUNCH(ctx, "order_scatter", k_order_scatter, grid_for(n_segs, 256), 256, u->d_seg_start, n_segs, n_tok, order_hist, order);

@@ -18,6 +18,8 @@ struct opusfe_ctx { int device = 0; };
 struct opusfe_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    // second stream: the sequential lowering machine works through the few huge functions while the node-parallel kernels run
+    hipStream_t stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string msg;
     // caching allocator: freed blocks are kept and reused so that steady-state calls never hipMalloc
     std::multimap<size_t, void*> free_blocks;
@@ -32,6 +34,9 @@ struct opusfe_ctx {
     std::vector<hipEvent_t> event_pool;
     uint32_t* d_status = nullptr;   // DevStatus word + scratch totals (64 words)
     uint32_t* h_status = nullptr;   // pinned mirror
+    // IR result sizes per AST node (variables, instructions, blocks, local types, call arguments) that lower.h run_lower sizes
+    // its arrays with: generous defaults, then what the previous unit on this context needed (+4 %)
+    double ir_ratio[5] = {1.35, 1.65, 0.40, 0.30, 0.25};
     uint32_t* d_static_scratch = nullptr;   // this device's address of api.hip `scratch` (hipGetSymbolAddress at opusfe_create)
     // opusfe_parse_batch: worker contexts (own stream and allocator each) owned by this context; units they created
     // are released before the context is destroyed

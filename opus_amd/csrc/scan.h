@@ -160,35 +160,49 @@ struct OpLast { __host__ __device__ uint32_t operator()(uint32_t a, uint32_t b) 
 // ---- largest units first ---------------------------------------------------------------------------
 // One wave works through one unit (parser: segment, lowering: function) from start to end, so a long unit that is
 // dispatched late finishes long after everything else.  Units are therefore dispatched by size class (bit length of
-// their token / node count, largest class first): a counting sort over 33 classes.  The order only decides WHEN a function runs, never what it produces.
+// their token / node count, largest class first): a counting sort over 66 half-octave classes.  The order only decides WHEN a function runs, never what it produces.
 // (class counters are kept in LDS per workgroup: one global atomic per class and workgroup instead of one per unit)
+// class = 2 * bit length + the bit below the leading one: half-octave size classes ([512,768), [768,1024), ...), so that a
+// consumer that sizes its workgroups by class (lower.h) wastes at most a third of what it reserves
+enum { ORDER_CLASSES = 66 };
+__host__ __device__ __forceinline__ uint32_t order_class_of_size(uint32_t size) {
+    if (size == 0) return 0;
+    const uint32_t bl = 32u - (uint32_t)__builtin_clz(size);
+    return 2u * bl + (bl >= 2 ? (size >> (bl - 2)) & 1u : 0u);
+}
+// sizes of class c are [order_class_lo(c), order_class_lo(c + 1))
+__host__ __device__ __forceinline__ uint64_t order_class_lo(uint32_t c) {
+    const uint32_t bl = c / 2, half = c & 1u;
+    if (bl == 0) return 0;
+    if (bl == 1) return half ? 2 : 1;      // (class 3 is empty: size 1 has no bit below the leading one)
+    return (uint64_t)(2 + half) << (bl - 2);
+}
 __device__ __forceinline__ uint32_t order_class(const uint32_t* __restrict__ start, uint32_t n, uint32_t end_all, uint32_t i) {
-    const uint32_t size = (i + 1 < n ? start[i + 1] : end_all) - start[i];
-    return 32u - (size ? (uint32_t)__builtin_clz(size) : 32u);
+    return order_class_of_size((i + 1 < n ? start[i + 1] : end_all) - start[i]);
 }
 __global__ __launch_bounds__(256) void k_order_hist(const uint32_t* __restrict__ start, uint32_t n, uint32_t end_all, uint32_t* __restrict__ hist) {
-    __shared__ uint32_t h[33];
-    if (threadIdx.x < 33) h[threadIdx.x] = 0;
+    __shared__ uint32_t h[ORDER_CLASSES];
+    if (threadIdx.x < ORDER_CLASSES) h[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) atomicAdd(&h[order_class(start, n, end_all, i)], 1u);
     __syncthreads();
-    if (threadIdx.x < 33 && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+    if (threadIdx.x < ORDER_CLASSES && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
 }
 __global__ void k_order_scan(uint32_t* __restrict__ hist) {          // in place: count -> first output slot, largest class first
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     uint32_t acc = 0;
-    for (int c = 32; c >= 0; c--) { uint32_t v = hist[c]; hist[c] = acc; acc += v; }
+    for (int c = ORDER_CLASSES - 1; c >= 0; c--) { uint32_t v = hist[c]; hist[c] = acc; acc += v; }
 }
 __global__ __launch_bounds__(256) void k_order_scatter(const uint32_t* __restrict__ start, uint32_t n, uint32_t end_all, uint32_t* __restrict__ hist, uint32_t* __restrict__ order) {
-    __shared__ uint32_t h[33], base[33];
-    if (threadIdx.x < 33) h[threadIdx.x] = 0;
+    __shared__ uint32_t h[ORDER_CLASSES], base[ORDER_CLASSES];
+    if (threadIdx.x < ORDER_CLASSES) h[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t c = 0, mine = 0;
     if (i < n) { c = order_class(start, n, end_all, i); mine = atomicAdd(&h[c], 1u); }
     __syncthreads();
-    if (threadIdx.x < 33 && h[threadIdx.x]) base[threadIdx.x] = atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+    if (threadIdx.x < ORDER_CLASSES && h[threadIdx.x]) base[threadIdx.x] = atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
     __syncthreads();
     if (i < n) order[base[c] + mine] = i;
 }

@@ -214,92 +214,96 @@ void emu_lower(EmuUnit& E) {
         R->n_sem_errors = finerr; u.status = OPUSFE_SEMANTIC; free(slots); free(entries); free(gtypes); return;
     }
     if (n_funcs == 0) { free(slots); free(entries); free(gtypes); return; }
-    // node-parallel count pass (lower_par.h), one emulated lane per function; EMU_PAR_NMAX / EMU_LOWER_SEQ steer what falls back
+    // node-parallel path (lower_par.h), one emulated lane per function; EMU_PAR_NMAX / EMU_LOWER_SEQ steer what falls back,
+    // EMU_PAR_TINYCAP makes the first attempt overflow so that the exact-size second attempt is exercised
     SemView S{E.src.data(), tok, u.h_val64.data(), nodes, R->tid_of_node.data(), gtypes, slots, n_slots - 1, entries, R->funcrecs.data(), R->globals.data(), n_gtypes};
     R->funcs.assign(n_funcs, FuncIr{});
     uint32_t lstatus[2] = {0, 0};
     uint64_t user_syms = 0;
     emu_launch(k_sem_user_syms, 1, 1, S, &user_syms);
-    emu_launch(par::k_par_init, grid_for(n_defs, 256), 256, nodes, def_nodes, n_defs, (const DefCnt*)def_excl.data(), R->funcs.data());
-    par::ParArgs PA{};
-    PA.def_nodes = def_nodes; PA.n_defs = n_defs; PA.n_nodes = n_nodes; PA.def_excl = def_excl.data(); PA.undefined_flag = undefined_flag.data(); PA.user_syms = &user_syms;
-    PA.pp_base = pp_base; PA.out = R->funcs.data(); PA.status = lstatus;
-    PA.list = nullptr; PA.n_list = n_defs; PA.nmax = getenv("EMU_PAR_NMAX") ? (uint32_t)atoi(getenv("EMU_PAR_NMAX")) : 2048u; PA.maxdef = getenv("EMU_PAR_MAXDEF") ? (uint32_t)atoi(getenv("EMU_PAR_MAXDEF")) : 256u;
     const bool seq_only = getenv("EMU_LOWER_SEQ") != nullptr;
-    const size_t lds = par::lds_bytes(PA.nmax, PA.maxdef, 1);
-    if (!seq_only) {
-        par::g_emu_lds = (uint32_t*)malloc(lds);
-        memset(par::g_emu_lds, 0xA5, lds);
-        emu_launch((par::k_lower_par<64, false>), n_defs, 1, S, PA);
-        free(par::g_emu_lds); par::g_emu_lds = nullptr;
-    }
+    uint64_t cap[5];
+    for (int k = 0; k < 5; k++) cap[k] = getenv("EMU_PAR_TINYCAP") ? 3 : 8ull * n_nodes + 64;
     std::vector<uint32_t> fb_flag(n_funcs);
     std::vector<FbIdx> fbx(n_funcs);
-    emu_launch(k_fb_mark, grid_for(n_defs, 256), 256, (const FuncIr*)R->funcs.data(), n_funcs, def_nodes, n_defs, n_nodes, (const DefCnt*)def_excl.data(), nodes, fb_flag.data(), fbx.data());
-    FbIdx fbt{0, 0};
-    for (uint32_t i = 0; i < n_funcs; i++) { FbIdx c = fbx[i]; fbx[i] = fbt; fbt = OpAddFbIdx()(fbt, c); }
-    const uint32_t fb_nodes = fbt.nodes, fb_funcs = fbt.funcs;
-    R->n_fallback = fb_funcs;
-    if (getenv("EMU_VERBOSE")) { fprintf(stderr, "functions lowered by the sequential machine: %u of %u\n", fb_funcs, n_funcs); for (auto& fr : R->funcs) if (fr.status == par::DS_FALLBACK) fprintf(stderr, "  function %u (node %u): declined at lower_par.h:%u\n", fr.func, fr.def_node, fr.pad); }
-    if (getenv("EMU_REQUIRE_PAR") && fb_funcs) { fprintf(stderr, "emu: %u functions fell back\n", fb_funcs); u.status = OPUSFE_ERR_INTERNAL; free(slots); free(entries); free(gtypes); return; }
-    LowerBuffers B{};
-    B.type_sparse_base = n_gtypes;
-    TypeRec* types = nullptr;
-    if (fb_funcs) {
-        const uint64_t type_cap = (uint64_t)n_gtypes + lower_base(CAP_TYPES, fb_nodes, fb_funcs) + CAP_CONST;
-        types = exact<TypeRec>(type_cap);
-        memcpy(types, gtypes, (size_t)n_gtypes * sizeof(TypeRec));
-        S.types = types;
-        B.vars = exact<opusfe_variable>(lower_base(CAP_VARS, fb_nodes, fb_funcs) + CAP_CONST);
-        const uint64_t icap = lower_base(CAP_INSTRS, fb_nodes, fb_funcs) + CAP_CONST;
-        B.instrs = exact<opusfe_instr>(icap); B.ibb = exact<uint32_t>(icap); B.irank = exact<uint32_t>(icap);
-        const uint64_t bcap = lower_base(CAP_BBS, fb_nodes, fb_funcs) + CAP_CONST;
-        B.bbcnt = exact<uint32_t>(bcap); B.bblast = exact<uint32_t>(bcap);
-        B.cargs = exact<uint32_t>(lower_base(CAP_CARGS, fb_nodes, fb_funcs) + CAP_CONST);
-        const uint64_t lcap = lower_base(CAP_LOCALS, fb_nodes, fb_funcs) + CAP_CONST;
-        B.lname = exact<uint32_t>(lcap); B.lvar = exact<uint32_t>(lcap); B.lstack = exact<uint32_t>(lcap);
-        B.frames = exact<LFrame>(lower_base(CAP_FRAMES, fb_nodes, fb_funcs) + CAP_CONST);
-        B.errs = exact<SemErr>(lower_base(CAP_ERRS, fb_nodes, fb_funcs) + CAP_CONST);
-        emu_launch(k_lower_functions, grid_for(n_defs, 64), 64, S, B, (const uint8_t*)undefined_flag.data(), def_nodes, n_defs, n_nodes, (uint32_t)u.n_tokens, (const DefCnt*)def_excl.data(),
-                   R->funcs.data(), lstatus, (uint64_t*)nullptr, (const uint64_t*)&user_syms, (const uint32_t*)nullptr, (const uint32_t*)fb_flag.data(), (const FbIdx*)fbx.data());
-    }
-    std::vector<IrCnt> cnt(n_funcs);
-    emu_launch(k_ir_counts, grid_for(n_funcs, 256), 256, (const FuncIr*)R->funcs.data(), n_funcs, cnt.data());
-    IrCnt tot{0, 0, 0, 0, 0, 0};
-    for (uint32_t i = 0; i < n_funcs; i++) { IrCnt c = cnt[i]; cnt[i] = tot; tot = OpAddIrCnt()(tot, c); }
     bool cleanup_only = false;
-    if (lstatus[0] >= DS_INTERNAL_CAPACITY) { u.status = OPUSFE_ERR_INTERNAL; cleanup_only = true; }
-    else if (lstatus[0] != DS_OK) { u.status = OPUSFE_UNSUPPORTED; u.dev_status = lstatus[0]; cleanup_only = true; }
-    if (!cleanup_only) {
-        R->n_sem_errors = lstatus[1];
-        R->n_vars = tot.vars; R->n_instrs = tot.instrs; R->n_bbs = tot.bbs; R->n_types = (uint64_t)n_gtypes + tot.types; R->n_cargs = tot.cargs; R->n_errs = tot.errs;
-        opusfe_variable* dv = exact<opusfe_variable>(R->n_vars); opusfe_instr* di = exact<opusfe_instr>(R->n_instrs);
-        uint32_t* dbo = exact<uint32_t>(R->n_bbs + 1); uint32_t* dc = exact<uint32_t>(R->n_cargs);
-        TypeRec* dty = exact<TypeRec>(R->n_types); SemErr* de = exact<SemErr>(R->n_errs);
+    for (int attempt = 0; attempt < 2; attempt++) {
+        lstatus[0] = lstatus[1] = 0;
+        unsigned long long counters[par::CTR_COUNT + 2] = {0};
+        opusfe_variable* dv = exact<opusfe_variable>(cap[0]); opusfe_instr* di = exact<opusfe_instr>(cap[1]);
+        uint32_t* dbo = exact<uint32_t>(cap[2] + 1); uint32_t* dc = exact<uint32_t>(cap[4]);
+        TypeRec* dty = exact<TypeRec>(n_gtypes + cap[3]); SemErr* de = nullptr;
         memcpy(dty, gtypes, (size_t)n_gtypes * sizeof(TypeRec));
-        dbo[R->n_bbs] = (uint32_t)R->n_instrs;
-        emu_launch(k_ir_bb_offsets, grid_for(n_funcs, 64), 64, R->funcs.data(), n_funcs, (const IrCnt*)cnt.data(), B, dbo, IrCnt{}, (const uint32_t*)fb_flag.data(), (const FbIdx*)fbx.data());
-        if (fb_funcs) {
+        emu_launch(par::k_par_init, grid_for(n_defs, 256), 256, nodes, def_nodes, n_defs, (const DefCnt*)def_excl.data(), R->funcs.data());
+        par::ParArgs PA{};
+        PA.def_nodes = def_nodes; PA.n_defs = n_defs; PA.n_nodes = n_nodes; PA.def_excl = def_excl.data(); PA.undefined_flag = undefined_flag.data(); PA.user_syms = &user_syms;
+        PA.pp_base = pp_base; PA.out = R->funcs.data(); PA.status = lstatus;
+        PA.counters = counters; PA.overflow = (uint32_t*)(counters + par::CTR_COUNT); PA.err_counter = (uint32_t*)(counters + par::CTR_COUNT + 1);
+        PA.cap_vars = cap[0]; PA.cap_instrs = cap[1]; PA.cap_bbs = cap[2]; PA.cap_types = cap[3]; PA.cap_cargs = cap[4]; PA.cap_errs = ~0ull;     // (the dense diagnostics block below has the sparse capacity)
+        PA.vars = dv; PA.instrs = di; PA.bb_offsets = dbo; PA.cargs = dc; PA.types_out = dty;
+        PA.list = nullptr; PA.n_list = n_defs; PA.nmax = getenv("EMU_PAR_NMAX") ? (uint32_t)atoi(getenv("EMU_PAR_NMAX")) : 2048u; PA.maxdef = getenv("EMU_PAR_MAXDEF") ? (uint32_t)atoi(getenv("EMU_PAR_MAXDEF")) : 256u;
+        S.types = gtypes;
+        if (!seq_only) {
+            const size_t lds = par::lds_bytes(PA.nmax, PA.maxdef, 1);
+            par::g_emu_lds = (uint32_t*)malloc(lds);
+            memset(par::g_emu_lds, 0xA5, lds);
+            emu_launch((par::k_lower_par<64>), n_defs, 1, S, PA);
+            free(par::g_emu_lds); par::g_emu_lds = nullptr;
+        }
+        emu_launch(k_fb_mark, grid_for(n_defs, 256), 256, (const FuncIr*)R->funcs.data(), n_funcs, def_nodes, n_defs, n_nodes, (const DefCnt*)def_excl.data(), nodes, fb_flag.data(), fbx.data());
+        FbIdx fbt{0, 0};
+        for (uint32_t i = 0; i < n_funcs; i++) { FbIdx c = fbx[i]; fbx[i] = fbt; fbt = OpAddFbIdx()(fbt, c); }
+        const uint32_t fb_nodes = fbt.nodes, fb_funcs = fbt.funcs;
+        R->n_fallback = fb_funcs;
+        if (getenv("EMU_VERBOSE")) { fprintf(stderr, "functions lowered by the sequential machine: %u of %u\n", fb_funcs, n_funcs); for (auto& fr : R->funcs) if (fr.status == par::DS_FALLBACK) fprintf(stderr, "  function %u (node %u): declined at lower_par.h:%u\n", fr.func, fr.def_node, fr.pad); }
+        if (getenv("EMU_REQUIRE_PAR") && fb_funcs) { fprintf(stderr, "emu: %u functions fell back\n", fb_funcs); u.status = OPUSFE_ERR_INTERNAL; cleanup_only = true; }
+        LowerBuffers B{};
+        B.type_sparse_base = n_gtypes;
+        TypeRec* types = nullptr;
+        if (fb_funcs && !cleanup_only) {
+            const uint64_t type_cap = (uint64_t)n_gtypes + lower_base(CAP_TYPES, fb_nodes, fb_funcs) + CAP_CONST;
+            types = exact<TypeRec>(type_cap);
+            memcpy(types, gtypes, (size_t)n_gtypes * sizeof(TypeRec));
+            S.types = types;
+            B.vars = exact<opusfe_variable>(lower_base(CAP_VARS, fb_nodes, fb_funcs) + CAP_CONST);
+            const uint64_t icap = lower_base(CAP_INSTRS, fb_nodes, fb_funcs) + CAP_CONST;
+            B.instrs = exact<opusfe_instr>(icap); B.ibb = exact<uint32_t>(icap); B.irank = exact<uint32_t>(icap);
+            const uint64_t bcap = lower_base(CAP_BBS, fb_nodes, fb_funcs) + CAP_CONST;
+            B.bbcnt = exact<uint32_t>(bcap); B.bblast = exact<uint32_t>(bcap);
+            B.cargs = exact<uint32_t>(lower_base(CAP_CARGS, fb_nodes, fb_funcs) + CAP_CONST);
+            const uint64_t lcap = lower_base(CAP_LOCALS, fb_nodes, fb_funcs) + CAP_CONST;
+            B.lname = exact<uint32_t>(lcap); B.lvar = exact<uint32_t>(lcap); B.lstack = exact<uint32_t>(lcap);
+            B.frames = exact<LFrame>(lower_base(CAP_FRAMES, fb_nodes, fb_funcs) + CAP_CONST);
+            const uint64_t ecap = lower_base(CAP_ERRS, fb_nodes, fb_funcs) + CAP_CONST;
+            B.errs = exact<SemErr>(ecap);
+            de = exact<SemErr>(ecap);
+            emu_launch(k_lower_functions, grid_for(n_defs, 64), 64, S, B, (const uint8_t*)undefined_flag.data(), def_nodes, n_defs, n_nodes, (uint32_t)u.n_tokens, (const DefCnt*)def_excl.data(),
+                       R->funcs.data(), lstatus, (uint64_t*)nullptr, (const uint64_t*)&user_syms, (const uint32_t*)nullptr, (const uint32_t*)fb_flag.data(), (const FbIdx*)fbx.data());
+            emu_launch(k_fb_bases, grid_for(n_funcs, 64), 64, R->funcs.data(), n_funcs, B, PA, (const uint32_t*)fb_flag.data(), (const FbIdx*)fbx.data());
             IrOut O{dv, di, dc, dty, de, dbo, n_gtypes};
             emu_launch(k_ir_compact, 2, 256, (const FuncIr*)R->funcs.data(), n_funcs, B, (const TypeRec*)types, O, (const uint32_t*)fb_flag.data(), (const FbIdx*)fbx.data());
         }
-        if (!seq_only) {
-            PA.fb_flag = fb_flag.data(); PA.vars = dv; PA.instrs = di; PA.bb_offsets = dbo; PA.cargs = dc; PA.types_out = dty;
-            S.types = gtypes;
-            par::g_emu_lds = (uint32_t*)malloc(lds);
-            memset(par::g_emu_lds, 0x5A, lds);
-            emu_launch((par::k_lower_par<64, true>), n_defs, 1, S, PA);
-            free(par::g_emu_lds); par::g_emu_lds = nullptr;
-            if (lstatus[0] >= DS_INTERNAL_CAPACITY) u.status = OPUSFE_ERR_INTERNAL;
+        const uint64_t tot[5] = {counters[par::CTR_VARS], counters[par::CTR_INSTR_BB] & ((1ull << par::CTR_BB_SHIFT) - 1), counters[par::CTR_INSTR_BB] >> par::CTR_BB_SHIFT, counters[par::CTR_TYPES], counters[par::CTR_CARGS]};
+        const bool overflow = (uint32_t)counters[par::CTR_COUNT] != 0;
+        if (lstatus[0] >= DS_INTERNAL_CAPACITY) { u.status = OPUSFE_ERR_INTERNAL; cleanup_only = true; }
+        else if (lstatus[0] != DS_OK) { u.status = OPUSFE_UNSUPPORTED; u.dev_status = lstatus[0]; cleanup_only = true; }
+        if (!cleanup_only && overflow && attempt == 1) { u.status = OPUSFE_ERR_INTERNAL; cleanup_only = true; }
+        const bool again = !cleanup_only && overflow;
+        if (!cleanup_only && !overflow) {
+            R->n_sem_errors = lstatus[1];
+            R->n_vars = tot[0]; R->n_instrs = tot[1]; R->n_bbs = tot[2]; R->n_types = (uint64_t)n_gtypes + tot[3]; R->n_cargs = tot[4]; R->n_errs = (uint32_t)counters[par::CTR_COUNT + 1];
+            dbo[R->n_bbs] = (uint32_t)R->n_instrs;
+            R->vars.assign(dv, dv + R->n_vars); R->instrs.assign(di, di + R->n_instrs); R->bb_offsets.assign(dbo, dbo + R->n_bbs + 1);
+            R->cargs.assign(dc, dc + R->n_cargs); R->types.assign(dty, dty + R->n_types); R->errs.assign(de, de + R->n_errs);
+            u.n_funcs = n_funcs; u.n_instrs = R->n_instrs; u.n_vars = R->n_vars;
         }
-        R->vars.assign(dv, dv + R->n_vars); R->instrs.assign(di, di + R->n_instrs); R->bb_offsets.assign(dbo, dbo + R->n_bbs + 1);
-        R->cargs.assign(dc, dc + R->n_cargs); R->types.assign(dty, dty + R->n_types); R->errs.assign(de, de + R->n_errs);
-        free(dv); free(di); free(dbo); free(dc); free(dty); free(de);
-        u.n_funcs = n_funcs; u.n_instrs = R->n_instrs; u.n_vars = R->n_vars;
+        free(dv); free(di); free(dbo); free(dc); free(dty); free(de); free(types);
+        free(B.vars); free(B.instrs); free(B.ibb); free(B.irank); free(B.bbcnt); free(B.bblast); free(B.cargs); free(B.lname); free(B.lvar); free(B.lstack);
+        free(B.frames); free(B.errs);
+        if (!again) break;
+        for (int k = 0; k < 5; k++) cap[k] = tot[k] + 16;
     }
-    free(slots); free(entries); free(gtypes); free(types);
-    free(B.vars); free(B.instrs); free(B.ibb); free(B.irank); free(B.bbcnt); free(B.bblast); free(B.cargs); free(B.lname); free(B.lvar); free(B.lstack);
-    free(B.frames); free(B.errs);
+    free(slots); free(entries); free(gtypes);
 }
 
 }  // namespace

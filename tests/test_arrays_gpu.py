@@ -37,9 +37,15 @@ def test_array_counts_agree_with_counts_and_structure(fe):
     off = v.bb_offsets.astype(np.int64)
     assert off[0] == 0 and off[-1] == len(v.instrs) and (np.diff(off) >= 0).all()
     f = v.functions
-    for name, base in (("n_vars", "var_base"), ("n_instrs", "instr_base"), ("n_bbs", "bb_base")):
-        want = np.concatenate([[0], np.cumsum(f[name].astype(np.int64))[:-1]])
-        assert (f[base].astype(np.int64) == want).all(), name
+    # (the order of the functions inside the arrays is the order in which they were lowered, not definition order: sort by base)
+    for name, base, total in (("n_vars", "var_base", len(v.variables)), ("n_instrs", "instr_base", len(v.instrs)), ("n_bbs", "bb_base", c["bbs"])):
+        body = f[f["n_bbs"] > 0]
+        o = np.argsort(body[base], kind="stable")
+        b, n = body[base][o].astype(np.int64), body[name][o].astype(np.int64)
+        assert b[0] == 0 and (b[1:] == (b + n)[:-1]).all() and b[-1] + n[-1] == total, name
+    # blocks and instructions are placed together: sorted by block base the instruction bases ascend too
+    o = np.argsort(f["bb_base"], kind="stable")
+    assert (np.diff(f["instr_base"][o].astype(np.int64)) >= 0).all()
     # every operand of every instruction is a variable of its own function; every jump target one of its blocks
     for i in range(0, len(v), max(1, len(v) // 50)):
         fv = v.function(i)
