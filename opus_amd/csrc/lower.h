@@ -1666,6 +1666,7 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
         PA.def_nodes = u->d_def_nodes; PA.n_defs = n_defs; PA.n_nodes = n_nodes; PA.def_excl = def_excl; PA.undefined_flag = undefined_flag; PA.user_syms = user_syms;
         PA.pp_base = pp_base; PA.out = R->d_funcs; PA.status = ctx->d_status + WL_STATUS;
         { static const char* sp = getenv("OPUSFE_PAR_STOP"); PA.stop_phase = sp ? (uint32_t)atoi(sp) : 0u; }
+        { static const char* sr = getenv("OPUSFE_PAR_ROUNDS"); PA.stop_rounds = sr ? (uint32_t)atoi(sr) : 0u; }
         PA.counters = counters; PA.overflow = (uint32_t*)(counters + par::CTR_COUNT); PA.err_counter = (uint32_t*)(counters + par::CTR_COUNT + 1);
         PA.cap_vars = cap[0]; PA.cap_instrs = cap[1]; PA.cap_bbs = cap[2]; PA.cap_types = cap[3]; PA.cap_cargs = cap[4]; PA.cap_errs = cap[5];
         PA.vars = R->d_vars; PA.instrs = R->d_instrs; PA.bb_offsets = R->d_bb_offsets; PA.cargs = R->d_cargs; PA.types_out = R->d_types;
@@ -1732,13 +1733,13 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
                 a.list = order + lo; a.n_list = hi - lo;
                 a.nmax = (uint32_t)order_class_lo(c + 1) - 1u; if (a.nmax < 63) a.nmax = 63;
                 a.maxdef = a.nmax / 8 < 32 ? 32 : a.nmax / 8;
-                // threads: as many waves per workgroup as it takes to reach 16 waves per CU (the register limit) with the workgroups
-                // that fit the 160 KB of LDS
+                // threads: as many waves per workgroup as it takes to reach the waves per CU that the registers allow
+                // (4 SIMDs x OPUSFE_PAR_WAVES) with the workgroups that fit the 160 KB of LDS
                 uint32_t threads;
                 if (shape_env) threads = a.nmax <= 256 ? ts : a.nmax <= 1024 ? tm : tl;
                 else {
                     const size_t blocks = std::max<size_t>(1, (160u << 10) / par::lds_bytes(a.nmax, a.maxdef, 256));
-                    const size_t want = (16 + blocks - 1) / blocks;
+                    const size_t want = (4 * OPUSFE_PAR_WAVES + blocks - 1) / blocks;      // waves per workgroup to fill the CU's wave slots
                     threads = want <= 1 ? 64 : want <= 2 ? 128 : want <= 4 ? 256 : want <= 8 ? 512 : 1024;
                 }
                 const size_t lds = par::lds_bytes(a.nmax, a.maxdef, threads);
