@@ -17,6 +17,11 @@ Workload (config.workload):
         `value` = N x --bytes / max-over-ranks time.  `--workload c3` at N>1 gives independent sources per rank
         (no collective at all).
 
+  "c5" (--workload c5): BASELINE.json configs[4] — a corpus of independent files (sizes log-uniform in [1 KB, 64 KB],
+        G(seed=5e6+i), every 100th file with one injected syntax fault), dealt to the ranks by cumulative bytes, NO collective;
+        --files sets the corpus size (default 6000 files, about 90 MB, so that the default run finishes in minutes; the
+        configuration names 100000).  The files are host buffers (opusfe_parse_batch): the rate includes their H2D copies.
+
 Extra objects on the JSON line:
   roofline     — the dominant kernel (largest share of HIP-event time, measured by the library on its own
                  stream with hipEventRecord around every launch while the timed steps run)
@@ -42,6 +47,16 @@ STAGE_OF = {"lex": ("lex_", "tok_", "scan_cnt3", "scan_depth", "scan_indent", "s
             "parse": ("parse_", "ast_"), "lower": ("sem_", "lower_", "ir_")}
 
 
+def lib_sha1():
+    """identity of the library a profile was taken with: roofline.traffic is only reported for the very same build"""
+    import hashlib
+    import opus_amd
+    try:
+        return hashlib.sha1(open(opus_amd.library_path(), "rb").read()).hexdigest()
+    except OSError:
+        return None
+
+
 def stage_of(name):
     for st, prefixes in STAGE_OF.items():
         if name.startswith(prefixes):
@@ -57,7 +72,8 @@ def main():
     ap.add_argument("--bytes", type=float, default=1e9, help="source bytes per GPU")
     ap.add_argument("--seed", type=int, default=3)
     ap.add_argument("--stage", default="ir", choices=["lex", "parse", "ir"], help="deepest stage to run (default: whole path)")
-    ap.add_argument("--workload", default=None, choices=["c3", "c4"],
+    ap.add_argument("--files", type=int, default=6000, help="c5: number of files of the corpus (whole job)")
+    ap.add_argument("--workload", default=None, choices=["c3", "c4", "c5"],
                     help="c3: one source per GPU (default at N=1; at N>1 independent shards, no collective); "
                          "c4: ONE logical source of N x bytes cut at arbitrary byte positions, carries exchanged by all-gather (default at N>1)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo lets several ranks share one GPU (rehearsal only)")
@@ -94,7 +110,26 @@ def main():
     t0 = time.time()
     # N ranks generate at the same time: share the host's cores (os.cpu_count() is the whole machine on the GPU boxes)
     gen_threads = max(2, min(16, (os.cpu_count() or 16) // world)) if world > 1 else threads
-    if workload == "c3":
+    corpus = None
+    if workload == "c5":
+        import math, random
+        from concurrent.futures import ThreadPoolExecutor
+        from opus_amd import sharding as _sh5
+        rnd = random.Random(5)
+        sizes_all = [int(math.exp(rnd.uniform(math.log(1024), math.log(65536)))) for _ in range(args.files)]
+        mine_idx = _sh5.shard_by_bytes(sizes_all, rank, world)
+
+        def make_file(i):
+            s = O.generate(5_000_000 + i, sizes_all[i], flags=0, threads=1)
+            if i % 100 == 7:                       # 1 % of the files carry one injected fault
+                bad = O.inject(s, i, (i // 100) % 10)
+                s = bad or s
+            return s
+        with ThreadPoolExecutor(max_workers=gen_threads) as ex:
+            corpus = list(ex.map(make_file, mine_idx))
+        src = b""
+        nbytes = sum(len(f) for f in corpus)
+    elif workload == "c3":
         src = O.generate(args.seed + 1000 * rank, nbytes, flags=args.gen_flags, threads=gen_threads)
     else:
         # rank r holds bytes [r*B + shift, (r+1)*B + shift) of ONE generated source of world*B bytes (rank 0 from byte 0):
@@ -109,7 +144,8 @@ def main():
     gen_s = time.time() - t0
     n_local = len(src)
     d_src = torch.empty(n_local + 64, dtype=torch.uint8, device="cuda")
-    d_src[:n_local].copy_(torch.frombuffer(bytearray(src), dtype=torch.uint8))
+    if n_local:
+        d_src[:n_local].copy_(torch.frombuffer(bytearray(src), dtype=torch.uint8))
     torch.cuda.synchronize()
 
     ctx = opus_amd.Context(local_rank)
@@ -131,7 +167,25 @@ def main():
         res["unit"].close()
         return c
 
+    lowering = {}
+
+    def step_c5():
+        units = ctx.compile_corpus(corpus, lower=(args.stage == "ir"))
+        tot = {}
+        nbad = 0
+        for uu in units:
+            if uu.status not in (opus_amd.OK, opus_amd.SYNTAX):
+                raise SystemExit(f"rank {rank}: corpus file failed: status {uu.status}: {ctx.message()}")
+            nbad += uu.status == opus_amd.SYNTAX
+            for k, v in uu.counts().items():
+                tot[k] = tot.get(k, 0) + v
+            uu.close()
+        tot["files"], tot["files_with_syntax_error"] = len(units), nbad
+        return tot
+
     def step():
+        if corpus is not None:
+            return step_c5()
         if gather is not None:
             return step_c4()
         if args.stage == "lex":
@@ -144,6 +198,7 @@ def main():
             rc = u.compile_source()
             if rc != opus_amd.OK:
                 raise SystemExit(f"rank {rank}: lowering failed: status {rc}: {ctx.message()}")
+            lowering["node_parallel"], lowering["sequential_machine"] = u.lowering_stats()
         c = u.counts()
         u.close()
         return c
@@ -165,45 +220,32 @@ def main():
     dt = time.perf_counter() - t0
     kstats = ctx.kernel_stats()
     ctx.set_profiling(False)
+    # the node-parallel lowering is ONE kernel (lower_par.h k_lower_par) launched once per size class with differently sized LDS:
+    # priced as one kernel with that many launches per step
+    par = [k for k in kstats if k[0].startswith("lower_par_")]
+    if par:
+        kstats = [k for k in kstats if not k[0].startswith("lower_par_")] + [("lower_par", sum(k[1] for k in par), sum(k[2] for k in par))]
+    held = ctx.memory_held()
+    total_bytes_all = nbytes
+    if dist is not None and workload == "c5":
+        from opus_amd import sharding as _sh6
+        total_bytes_all = int(_sh6.all_reduce_sum(nbytes, dist))
     if dist is not None:
         from opus_amd import sharding as _sh
         dt = _sh.all_reduce_max(dt, dist)
 
     S, T, N = counts["source_bytes"], counts["tokens"], counts["nodes"]
     I, V = counts["instrs"], counts["vars"]
-    alg = {"lex": S + 16 * T, "parse": 16 * T + 24 * N, "lower": 24 * N + 24 * I + 8 * V, "other": S}
-    total_alg = S + 16 * T + 24 * N + 24 * I + 8 * V
 
     out = None
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
-        value = world * nbytes / 1e6 / (dt / args.steps)
+        value = (total_bytes_all if workload == "c5" else world * nbytes) / 1e6 / (dt / args.steps)
         kstats.sort(key=lambda k: -k[1])
-        roofline = None
-        if kstats:
-            name, ms, launches = kstats[0]
-            avg_ms = ms / max(1, launches)
-            per_step = launches / args.steps
-            a = alg[stage_of(name)] / max(1.0, per_step) / (avg_ms * 1e-3) / 1e9
-            # HBM traffic per launch: PMC counters cannot be read from inside this process; the committed rocprofv3 passes
-            # (tools/profile.sh -> profiles/*_traffic.json) hold FETCH_SIZE + WRITE_SIZE per launch for one source size:
-            # reported only when this run is that same workload, else null
-            traffic = None
-            try:
-                tdir = os.path.join(ROOT, "profiles")
-                for fn in sorted(os.listdir(tdir), reverse=True):
-                    if fn.endswith("_traffic.json"):
-                        tj = json.load(open(os.path.join(tdir, fn)))
-                        if workload == "c3" and tj.get("source_bytes") == nbytes and name in tj["kernels"]:
-                            traffic = int(tj["kernels"][name]["fetch"] + tj["kernels"][name]["write"])
-                            break
-            except OSError:
-                pass
-            roofline = {"bound": "hbm", "kernel": name, "achieved": round(a, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(a / HBM_PEAK_GBS, 5), "traffic": traffic, "avg_ms": round(avg_ms, 4),
-                        "launches_per_step": per_step, "algorithmic_bytes_per_launch": int(alg[stage_of(name)] / max(1.0, per_step))}
+        # ---- CPU baseline (the oracle, "port") and the oracle as checker of the measured path, on bounded samples ----
         cpu = parity = None
-        if world == 1 and not args.no_cpu:
+        node_ratio = None        # reference-tree nodes per flat-AST node (the flat AST has list / pair carrier nodes the reference's boxed tree lacks)
+        if world == 1 and not args.no_cpu and workload != "c5":
             sample = src[:int(min(args.cpu_sample_bytes, nbytes))]
             # cut the sample at a top-level definition boundary (a line that starts in column 0 after a newline)
             cut = len(sample)
@@ -216,27 +258,100 @@ def main():
             if us.status == opus_amd.OK and args.stage == "ir":
                 us.compile_source()
             cs = us.counts()
-            # (node counts are not comparable: the flat AST has list / pair carrier nodes the reference's boxed tree does not)
             pairs = [("tokens", c2.tokens), ("definitions", c2.definitions)] if args.stage != "lex" else []
             if args.stage == "ir":
                 pairs += [("instrs", c2.instrs), ("vars", c2.vars)]
             parity = {"sample_bytes": len(sample), "oracle_status": c2.status, "gpu_status": us.status,
                       "counts_match": all(cs[k] == v for k, v in pairs) and (us.status == 0) == (c2.status == 0),
                       "compared": [k for k, _ in pairs]}
+            if cs["nodes"]:
+                node_ratio = c2.nodes / cs["nodes"]
             us.close()
+            # the reference's other single-thread cases, C1 (10k lines) and C2 (1 MB)
+            c1 = O.generate_lines(1, 10000)
+            t1, _ = O.time_run(c1, lower=(args.stage == "ir"))
+            c2src = O.generate(2, 1_000_000)
+            t2, _ = O.time_run(c2src, lower=(args.stage == "ir"))
             cpu = {"value": round(len(sample) / 1e6 / tcpu, 3), "unit": "MB/s", "cores": 1, "kind": "port",
-                   "sample": f"first {len(sample)} bytes of the same source (whole definitions), oracle {'lex+parse+IR' if args.stage == 'ir' else 'lex+parse'}, single thread like the reference; status {c2.status}"}
+                   "sample": f"first {len(sample)} bytes of the same source (whole definitions), oracle {'lex+parse+IR' if args.stage == 'ir' else 'lex+parse'}, single thread like the reference; status {c2.status}",
+                   "c1_10k_lines_mbs": round(len(c1) / 1e6 / t1, 3), "c2_1mb_mbs": round(len(c2src) / 1e6 / t2, 3)}
+        elif world == 1 and not args.no_cpu and workload == "c5":
+            # files are independent: one oracle worker per hardware thread this process may use (the GPU boxes give 16 to a one-GPU job)
+            from concurrent.futures import ThreadPoolExecutor
+            import hashlib
+            cores = max(1, min(16, os.cpu_count() or 1))
+            budget, sample_files, acc = 6e6 * cores * 4, [], 0      # about 4 s of work per worker at the single-thread rate
+            for f in corpus:
+                if acc >= budget:
+                    break
+                sample_files.append(f); acc += len(f)
+            t0c = time.perf_counter()
+            with ThreadPoolExecutor(max_workers=cores) as ex:
+                res = list(ex.map(lambda f: O.time_run(f, lower=(args.stage == "ir"))[1].status, sample_files))
+            tc = time.perf_counter() - t0c
+            # checker: the first files (every faulty one among them) must give the oracle's error line / IR text
+            check = sample_files[:200]
+            units = ctx.compile_corpus(check, lower=(args.stage == "ir"))
+            ok, nerr = True, 0
+            for f, uu in zip(check, units):
+                want_err = O.dump(f, O.ERROR)
+                nerr += want_err != "Ok\n"
+                if uu.dump_error() != want_err:
+                    ok = False
+                elif want_err == "Ok\n" and args.stage == "ir":
+                    if uu.status != opus_amd.OK or hashlib.sha1(uu.dump_ir().encode()).digest() != hashlib.sha1(O.dump(f, O.IR).encode()).digest():
+                        ok = False
+                uu.close()
+            parity = {"files_checked": len(check), "files_with_syntax_error": nerr, "error_tuples_and_ir_text_match": ok}
+            cpu = {"value": round(acc / 1e6 / tc, 3), "unit": "MB/s", "cores": cores, "kind": "port",
+                   "sample": f"{len(sample_files)} files ({int(acc)} bytes) of the same corpus, one oracle worker per hardware thread ({cores} threads), statuses {sorted(set(res))}"}
+        # ---- algorithmic bytes: S + 16 T + 24 N + 24 I + 8 V with N = nodes of the REFERENCE's tree ----
+        N_ref = int(round(N * node_ratio)) if node_ratio else N
+        alg = {"lex": S + 16 * T, "parse": 16 * T + 24 * N_ref, "lower": 24 * N_ref + 24 * I + 8 * V, "other": S}
+        total_alg = S + 16 * T + 24 * N_ref + 24 * I + 8 * V
+        roofline = None
+        if kstats:
+            name, ms, launches = kstats[0]
+            avg_ms = ms / max(1, launches)
+            per_step = launches / args.steps
+            a = alg[stage_of(name)] / max(1.0, per_step) / (avg_ms * 1e-3) / 1e9
+            # HBM traffic per launch: PMC counters cannot be read from inside this process; the committed rocprofv3 passes
+            # (tools/profile.sh -> profiles/*_traffic.json) hold FETCH_SIZE + WRITE_SIZE per launch for one source size:
+            # reported only when this run is that same workload on that same library build, else null
+            traffic = None
+            try:
+                tdir = os.path.join(ROOT, "profiles")
+                for fn in sorted(os.listdir(tdir), reverse=True):
+                    if fn.endswith("_traffic.json"):
+                        tj = json.load(open(os.path.join(tdir, fn)))
+                        if workload == "c3" and tj.get("source_bytes") == nbytes and name in tj["kernels"] and tj.get("library_sha1") == lib_sha1():
+                            traffic = int(tj["kernels"][name]["fetch"] + tj["kernels"][name]["write"])
+                            break
+            except OSError:
+                pass
+            roofline = {"bound": "hbm", "kernel": name, "achieved": round(a, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(a / HBM_PEAK_GBS, 5), "traffic": traffic, "avg_ms": round(avg_ms, 4),
+                        "launches_per_step": per_step, "algorithmic_bytes_per_launch": int(alg[stage_of(name)] / max(1.0, per_step)),
+                        "nodes_priced": "reference tree (oracle / GPU node ratio of the checked sample)" if node_ratio else "flat AST (no CPU leg ran: a few % high)"}
         stage_name = {"lex": "lex only (PARTIAL path)", "parse": "lex+parse (PARTIAL path)", "ir": "lex+parse+IR"}[args.stage]
+        if workload == "c3":
+            wl = f"C3: one synthetic source of {nbytes} B per GPU, generator G(seed={args.seed}), depth-1000 regions, {world} GPU(s)"
+            shd = "none" if world == 1 else "independent shards, no collective"
+        elif workload == "c4":
+            wl = f"C4: ONE synthetic source of {world * nbytes} B cut at arbitrary bytes over {world} GPUs ({nbytes} B each), carries by all-gather, generator G(seed={args.seed})"
+            shd = "byte-range shards; all-gather of ctx/tail/depth/cut carries, prefix halo, definition headers"
+        else:
+            wl = f"C5: corpus of {args.files} independent files of 1-64 KB ({total_bytes_all} B), 1 % with one injected syntax fault, dealt to {world} GPU(s) by cumulative bytes; host buffers (H2D included)"
+            shd = "files by cumulative bytes, no collective"
         out = {"metric": f"source MB/s {stage_name} (whole node)", "value": round(value, 2), "unit": "MB/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-               "config": {"workload": (f"C3: one synthetic source of {nbytes} B per GPU, generator G(seed={args.seed}), depth-1000 regions, {world} GPU(s)" if workload == "c3" else
-                                       f"C4: ONE synthetic source of {world * nbytes} B cut at arbitrary bytes over {world} GPUs ({nbytes} B each), carries by all-gather, generator G(seed={args.seed})"),
-                          "source_bytes_per_gpu": nbytes, "tokens": T, "nodes": N, "instrs": I, "vars": V,
-                          "functions": counts["functions"], "algorithmic_bytes": total_alg, "sharding": "none" if world == 1 else ("independent shards, no collective" if workload == "c3" else
-                                       "byte-range shards; all-gather of ctx/tail/depth/cut carries, prefix halo, definition headers")},
+               "scaling": "weak" if workload != "c5" else "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+               "config": {"workload": wl, "source_bytes_per_gpu": nbytes, "tokens": T, "nodes": N, "nodes_reference_tree": N_ref if node_ratio else None,
+                          "instrs": I, "vars": V, "functions": counts["functions"], "algorithmic_bytes": total_alg, "sharding": shd,
+                          "files": counts.get("files"), "files_with_syntax_error": counts.get("files_with_syntax_error")},
                "hbm_gbs_whole_path": round(world * total_alg / (dt / args.steps) / 1e9, 2),
                "hbm_frac_whole_path": round(total_alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 5),
+               "hbm_held_bytes": held, "lowering_functions": lowering or None,
                "roofline": roofline, "cpu_baseline": cpu, "parity_check": parity if cpu is not None else None,
                "kernels": [{"name": n, "ms_per_step": round(ms / args.steps, 4), "launches_per_step": l / args.steps} for n, ms, l in kstats[:24]],
                "gen_seconds": round(gen_s, 1)}

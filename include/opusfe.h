@@ -164,6 +164,14 @@ int opusfe_lower(opusfe_ctx* ctx, opusfe_unit* unit);
    are the finalize-time errors of compile.rs:1002-1065 and no IR exists) and opusfe_dump(unit, 4). */
 int opusfe_semantic_error_count(const opusfe_unit* unit, uint64_t* n);
 
+/* how the functions of a lowered unit were lowered: by the node-parallel kernels (lower_par.h) / by the sequential machine (the
+   functions the parallel path declines: semantic errors, shadowing, structural comparisons of record / function types, 2048 nodes
+   and more).  No counterpart in the reference; both produce the reference's IR. */
+int opusfe_lowering_stats(const opusfe_unit* unit, uint64_t* n_parallel, uint64_t* n_sequential);
+/* device memory this context holds (result buffers of live units + the caching allocator's free blocks): the high-water mark
+   of the HBM footprint of the calls made so far */
+int opusfe_memory_held(opusfe_ctx* ctx, uint64_t* bytes);
+
 /* ---- results ---- */
 /* number of resync passes opusfe_parse took for this unit (0 for well-formed input).  A byte-range shard of a
    larger source that needed one cannot be combined with its neighbours: behind the resync point the reference's lexer

@@ -689,6 +689,22 @@ int opusfe_semantic_error_count(const opusfe_unit* u, uint64_t* n) {
     return OPUSFE_OK;
 }
 
+int opusfe_lowering_stats(const opusfe_unit* u, uint64_t* n_parallel, uint64_t* n_sequential) {
+    if (!u || !n_parallel || !n_sequential) return OPUSFE_ERR_ARG;
+    *n_parallel = *n_sequential = 0;
+    const IrResult* R = (const IrResult*)u->ir;
+    if (!R || !u->lowered || u->status != OPUSFE_OK) return OPUSFE_OK;
+    *n_sequential = R->n_fallback;
+    *n_parallel = R->n_bodies - R->n_fallback;
+    return OPUSFE_OK;
+}
+
+int opusfe_memory_held(opusfe_ctx* ctx, uint64_t* bytes) {
+    if (!ctx || !bytes) return OPUSFE_ERR_ARG;
+    *bytes = ctx->bytes_allocated;
+    return OPUSFE_OK;
+}
+
 int opusfe_unit_resync_passes(const opusfe_unit* u, uint32_t* n) {
     if (!u || !n) return OPUSFE_ERR_ARG;
     *n = (uint32_t)u->resync.size();

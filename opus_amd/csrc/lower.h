@@ -1503,7 +1503,7 @@ struct IrResult {
     uint32_t* d_cargs = nullptr; TypeRec* d_types = nullptr; SemErr* d_errs = nullptr; FuncRec* d_funcrecs = nullptr; GlobalRec* d_globals = nullptr;
     uint32_t* d_tid_of_node = nullptr;
     uint64_t n_funcs = 0, n_globals = 0, n_vars = 0, n_instrs = 0, n_bbs = 0, n_types = 0, n_gtypes = 0, n_cargs = 0, n_errs = 0, n_sem_errors = 0;
-    uint64_t n_fallback = 0;   // functions (with bodies) that the sequential machine lowered; the node-parallel path did the rest
+    uint64_t n_fallback = 0, n_bodies = 0;   // functions that the sequential machine lowered, of n_bodies functions with bodies
     // host mirrors
     bool have_host = false;
     std::vector<FuncIr> funcs; std::vector<opusfe_variable> vars; std::vector<opusfe_instr> instrs; std::vector<uint32_t> bb_offsets, cargs, tid_of_node;
@@ -1520,7 +1520,7 @@ inline void free_ir(opusfe_ctx* ctx, opusfe_unit* u) {
     u->ir = nullptr;
 }
 
-enum { WL_STATUS = 32, WL_ERRS = 33, WL_FBTOT = 34 /* FbIdx: 2 */, WL_DEFTOT = 36 /* DefCnt: 4 */, WL_GT = 40, WL_FINERR = 41, WL_IRTOT = 44 /* IrCnt: 6 */, WL_SLOTTOT = 50 };
+enum { WL_STATUS = 32, WL_ERRS = 33, WL_FBTOT = 34 /* FbIdx: 2 */, WL_BODIES = 52, WL_DEFTOT = 36 /* DefCnt: 4 */, WL_GT = 40, WL_FINERR = 41, WL_IRTOT = 44 /* IrCnt: 6 */, WL_SLOTTOT = 50 };
 
 inline uint32_t next_pow2(uint64_t v) { uint32_t p = 16; while (p < v) p <<= 1; return p; }
 
@@ -1660,8 +1660,9 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
         R->d_errs = dev_alloc_t<SemErr>(ctx, cap[5]);
         HIP_TRY(hipMemsetAsync(counters, 0, (par::CTR_COUNT + 2) * sizeof(unsigned long long), st));
         HIP_TRY(hipMemsetAsync(ctx->d_status + WL_STATUS, 0, 2 * sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(ctx->d_status + WL_BODIES, 0, sizeof(uint32_t), st));
         HIP_TRY(hipMemcpyAsync(R->d_types, gtypes, (size_t)n_gtypes * sizeof(TypeRec), hipMemcpyDeviceToDevice, st));
-        LAUNCH(ctx, "par_init", par::k_par_init, grid_for(n_defs, 256), 256, u->d_nodes, u->d_def_nodes, n_defs, def_excl, R->d_funcs);
+        LAUNCH(ctx, "par_init", par::k_par_init, grid_for(n_defs, 256), 256, u->d_nodes, u->d_def_nodes, n_defs, def_excl, R->d_funcs, ctx->d_status + WL_BODIES);
         par::ParArgs PA{};
         PA.def_nodes = u->d_def_nodes; PA.n_defs = n_defs; PA.n_nodes = n_nodes; PA.def_excl = def_excl; PA.undefined_flag = undefined_flag; PA.user_syms = user_syms;
         PA.pp_base = pp_base; PA.out = R->d_funcs; PA.status = ctx->d_status + WL_STATUS;
@@ -1766,7 +1767,7 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
         HIP_TRY(hipStreamSynchronize(st));
         prof_collect(ctx);
         const uint32_t fb_nodes = ctx->h_status[WL_FBTOT], fb_funcs = ctx->h_status[WL_FBTOT + 1];
-        R->n_fallback = fb_funcs + big_funcs;
+        R->n_fallback = fb_funcs + big_funcs; R->n_bodies = ctx->h_status[WL_BODIES];
         if (fb_funcs) { if (!machine_pass(st, fb_flag, fbx, fb_nodes, fb_funcs, true)) return; }
         unsigned long long hc[par::CTR_COUNT + 2];
         HIP_TRY(hipMemcpyAsync(hc, counters, sizeof hc, hipMemcpyDeviceToHost, st));

@@ -1608,7 +1608,8 @@ __global__ MACHINE_ATTR(OPUSFE_PAR_WAVES) __launch_bounds__(THREADS) void k_lowe
 }
 
 // every function starts as "declined": the count pass overwrites the ones it lowers
-__global__ void k_par_init(const opusfe_node* __restrict__ nodes, const uint32_t* __restrict__ def_nodes, uint32_t n_defs, const DefCnt* __restrict__ def_excl, FuncIr* __restrict__ out) {
+__global__ void k_par_init(const opusfe_node* __restrict__ nodes, const uint32_t* __restrict__ def_nodes, uint32_t n_defs, const DefCnt* __restrict__ def_excl, FuncIr* __restrict__ out,
+                           uint32_t* __restrict__ n_bodies) {
     const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= n_defs) return;
     const uint32_t dn = def_nodes[d];
@@ -1616,6 +1617,7 @@ __global__ void k_par_init(const opusfe_node* __restrict__ nodes, const uint32_t
     if (k != D_Function && k != D_Extern) return;
     FuncIr r{}; r.def_node = dn; r.func = def_excl[d].funcs; r.status = k == D_Function ? (uint32_t)DS_FALLBACK : (uint32_t)DS_OK;
     out[r.func] = r;
+    if (k == D_Function) atomicAdd(n_bodies, 1u);
 }
 
 }  // namespace par

@@ -74,6 +74,8 @@ def lib():
         L.opusfe_unit_from_arrays.argtypes = [vp, vp, u64, vp, u64, vp, u64, vp, u64, vp, u64, vp, u64, C.POINTER(vp)]
         L.opusfe_lower.argtypes = [vp, vp]
         L.opusfe_unit_status.argtypes = [vp]
+        L.opusfe_lowering_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
+        L.opusfe_memory_held.argtypes = [vp, C.POINTER(u64)]
         L.opusfe_unit_resync_passes.argtypes = [vp, C.POINTER(u32)]
         L.opusfe_get_counts.argtypes = [vp, C.POINTER(Counts)]
         L.opusfe_get_error.argtypes = [vp, C.POINTER(Error)]
@@ -155,6 +157,12 @@ class Unit:
         self.status = rc
         return rc
 
+    def lowering_stats(self):
+        """(functions lowered by the node-parallel kernels, functions lowered by the sequential machine)"""
+        a, b = C.c_uint64(), C.c_uint64()
+        lib().opusfe_lowering_stats(self.handle, C.byref(a), C.byref(b))
+        return a.value, b.value
+
     def join(self, hdr, split_pos):
         """self (+) hdr (opusfe_unit_join): a new parsed Unit with hdr's definitions that start before byte `split_pos` of
         hdr's source, then self's, then the rest of hdr's."""
@@ -225,6 +233,12 @@ class Context:
 
     def stream(self):
         return lib().opusfe_stream(self.handle)
+
+    def memory_held(self):
+        """device bytes this context holds (live results + cached blocks): high-water mark of its HBM footprint"""
+        n = C.c_uint64()
+        lib().opusfe_memory_held(self.handle, C.byref(n))
+        return n.value
 
     def _finish(self, rc, out):
         if rc not in (OK, SYNTAX, UNSUPPORTED):

@@ -229,12 +229,13 @@ void emu_lower(EmuUnit& E) {
     bool cleanup_only = false;
     for (int attempt = 0; attempt < 2; attempt++) {
         lstatus[0] = lstatus[1] = 0;
+        uint32_t n_bodies = 0;
         unsigned long long counters[par::CTR_COUNT + 2] = {0};
         opusfe_variable* dv = exact<opusfe_variable>(cap[0]); opusfe_instr* di = exact<opusfe_instr>(cap[1]);
         uint32_t* dbo = exact<uint32_t>(cap[2] + 1); uint32_t* dc = exact<uint32_t>(cap[4]);
         TypeRec* dty = exact<TypeRec>(n_gtypes + cap[3]); SemErr* de = nullptr;
         memcpy(dty, gtypes, (size_t)n_gtypes * sizeof(TypeRec));
-        emu_launch(par::k_par_init, grid_for(n_defs, 256), 256, nodes, def_nodes, n_defs, (const DefCnt*)def_excl.data(), R->funcs.data());
+        emu_launch(par::k_par_init, grid_for(n_defs, 256), 256, nodes, def_nodes, n_defs, (const DefCnt*)def_excl.data(), R->funcs.data(), &n_bodies);
         par::ParArgs PA{};
         PA.def_nodes = def_nodes; PA.n_defs = n_defs; PA.n_nodes = n_nodes; PA.def_excl = def_excl.data(); PA.undefined_flag = undefined_flag.data(); PA.user_syms = &user_syms;
         PA.pp_base = pp_base; PA.out = R->funcs.data(); PA.status = lstatus;

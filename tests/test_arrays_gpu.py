@@ -123,3 +123,24 @@ def test_unit_from_arrays_round_trip(fe):
     assert v.compile_source() == 0 and v.dump_ir() == O.dump(src, O.IR)
     with pytest.raises(Exception):
         fe.unit_from_arrays([(0, 5)] + arrs[1:])       # a count without a pointer is an argument error
+
+
+def test_lowering_stats_and_memory_held(fe):
+    """opusfe_lowering_stats / opusfe_memory_held: every function with a body is lowered by exactly one of the two paths, the
+    node-parallel kernels take (nearly) all of a generated source, and the context's device footprint is reported"""
+    src = O.generate(33, 400_000)
+    u = fe.get_definitions(src)
+    assert u.lowering_stats() == (0, 0)                 # nothing lowered yet
+    assert u.compile_source() == 0
+    par, seq = u.lowering_stats()
+    f = u.array(V.A_FUNCTIONS)
+    assert par + seq == int((f["n_bbs"] > 0).sum()) > 0
+    assert par >= 0.95 * (par + seq)
+    held = fe.memory_held()
+    assert held >= len(src) + 16 * u.counts()["tokens"] + 24 * u.counts()["nodes"] + 24 * u.counts()["instrs"]
+    assert held < 400 * len(src)
+    # a function beyond the node-parallel kernels' size limit goes to the sequential machine, with the same IR
+    big = b"f(x int32) int32\n\tvar y int32 = x\n" + b"".join(b"\ty = y * %d + x\n" % (i % 97) for i in range(600)) + b"\treturn y\n"
+    v = fe.get_definitions(big)
+    assert v.compile_source() == 0 and v.lowering_stats() == (0, 1)
+    assert v.dump_ir() == O.dump(big, O.IR)

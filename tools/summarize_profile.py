@@ -48,11 +48,26 @@ with open(os.path.join("profiles", f"{tag}_summary.md"), "w") as f:
 import json
 import re
 m = re.search(r"--bytes\s+(\S+)", " ".join(sys.argv[2:]))
-traffic = {"tag": tag, "source_bytes": int(float(m.group(1))) if m else None, "unit": "bytes per launch", "kernels": {}}
+import hashlib
+sys.path.insert(0, os.getcwd())
+try:
+    import opus_amd
+    sha = hashlib.sha1(open(opus_amd.library_path(), "rb").read()).hexdigest()
+except Exception:
+    sha = None
+traffic = {"tag": tag, "source_bytes": int(float(m.group(1))) if m else None, "unit": "bytes per launch", "library_sha1": sha, "kernels": {}}
 for r in stats:
     k = short(r["Name"])
     if fetch[k][0] and write[k][0]:
         name = k[2:] if k.startswith("k_") else k
         traffic["kernels"][name] = {"fetch": fetch[k][1] / fetch[k][0] * 1e3, "write": write[k][1] / write[k][0] * 1e3, "avg_ms": float(r["AverageNs"]) / 1e6}
+# bench.py prices the node-parallel lowering as ONE kernel "lower_par" (k_lower_par<THREADS>, one launch per size class):
+# per-launch averages over all its instantiations
+par = [(k, fetch[k], write[k], r) for r in stats for k in [short(r["Name"])] if k.startswith("par::k_lower_par") and fetch[k][0] and write[k][0]]
+if par:
+    calls = sum(int(r["Calls"]) for _, _, _, r in par)
+    traffic["kernels"]["lower_par"] = {"fetch": sum(f[1] for _, f, _, _ in par) / sum(f[0] for _, f, _, _ in par) * 1e3,
+                                       "write": sum(w[1] for _, _, w, _ in par) / sum(w[0] for _, _, w, _ in par) * 1e3,
+                                       "avg_ms": sum(float(r["AverageNs"]) * int(r["Calls"]) for _, _, _, r in par) / calls / 1e6, "calls": calls}
 json.dump(traffic, open(os.path.join("profiles", f"{tag}_traffic.json"), "w"), indent=1)
 print(open(os.path.join("profiles", f"{tag}_summary.md")).read())
