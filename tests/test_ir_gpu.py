@@ -13,6 +13,8 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 with open(os.path.join(HERE, "golden", "kats.json")) as f:
     KATS = json.load(f)
+with open(os.path.join(HERE, "golden", "kats2.json")) as f:
+    KATS2 = json.load(f)["kats"]
 
 
 def first_diff(got, want):
@@ -52,6 +54,23 @@ def test_kat_ir_matches_hand_derived_fixtures(fe):
     e2 = KATS["kat_e"][1]
     u = fe.get_definitions(e2["src"].encode())
     assert u.compile_source() == 0 and u.dump_ir() == e2["ir"]
+
+
+@pytest.mark.parametrize("case", KATS2, ids=[c["name"] for c in KATS2])
+def test_kats2_gpu_against_the_hand_derived_text(fe, case):
+    """the HIP path against the expectations derived by hand from the Rust (no oracle in between): IR text, the same text
+    rebuilt from the flat arrays, the semantic diagnostics (kind, position, length) and, where given, the AST shape"""
+    src = case["src"].encode()
+    u = fe.get_definitions(src)
+    assert u.status == 0
+    if case["ast_contains"]:
+        assert case["ast_contains"] in u.dump_ast()
+    assert u.compile_source() == 0
+    assert u.dump_ir() == case["ir"], first_diff(u.dump_ir(), case["ir"])
+    assert u.ir_view().text() == case["ir"]
+    assert u._dump(4).splitlines() == case["errors"]
+    par, seq = u.lowering_stats()
+    assert par + seq == 1
 
 
 @pytest.mark.parametrize("src", IR_CASES, ids=[f"ir{i}" for i in range(len(IR_CASES))])

@@ -75,3 +75,18 @@ def test_generator_is_deterministic_and_injector_produces_errors():
         if bad and O.dump(bad, O.ERROR) != "Ok\n":
             hits += 1
     assert hits >= 6
+
+
+# ---- second set: 53 hand-derived IR-generation cases (tests/golden/make_kats2.py; first-contact record in oracle/REVIEW.md)
+with open(os.path.join(HERE, "golden", "kats2.json")) as f:
+    KATS2 = json.load(f)["kats"]
+
+
+@pytest.mark.parametrize("case", KATS2, ids=[c["name"] for c in KATS2])
+def test_kats2_ir_and_diagnostics(case):
+    src = case["src"].encode()
+    assert O.dump(src, O.ERROR) == "Ok\n"
+    assert O.dump(src, O.IR) == case["ir"]
+    assert O.dump(src, O.SEM).splitlines() == case["errors"]
+    if case["ast_contains"]:
+        assert case["ast_contains"] in O.dump(src, O.AST)
