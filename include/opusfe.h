@@ -213,7 +213,7 @@ enum {
     OPUSFE_A_TOKENS = 1,      /* opusfe_token */
     OPUSFE_A_VAL64 = 2,       /* uint64_t  integer / float-bit / error payload pool */
     OPUSFE_A_STRINGS = 3,     /* uint8_t   string pool: [u32 n][n bytes] padded to 4 */
-    OPUSFE_A_NODES = 4,       /* opusfe_node, dense, definitions in file order, pre-order inside a definition */
+    OPUSFE_A_NODES = 4,       /* opusfe_node, dense, definitions in file order, each definition contiguous, nodes in the parser's creation order (operands before the operator / postfix node that takes them; NOT pre-order) */
     OPUSFE_A_DEFINITIONS = 5, /* uint32_t  root node of each definition */
     OPUSFE_A_SIGNATURES = 6,  /* opusfe_signature, one per function / extern (after opusfe_lower) */
     OPUSFE_A_GLOBALS = 7,     /* opusfe_global */
@@ -225,7 +225,11 @@ enum {
     OPUSFE_A_INSTRS = 13,     /* opusfe_instr */
     OPUSFE_A_CALL_ARGS = 14,  /* uint32_t  variable ids of Call arguments (instr.c = offset, instr.sub = count) */
     OPUSFE_A_SEM_ERRORS = 15, /* opusfe_semantic_error, in report order */
-    OPUSFE_A_COUNT = 16
+    OPUSFE_A_PARENTS = 16,    /* uint32_t  per node: index of its parent node, 0xFFFFFFFF for the root of a definition.  Built by a node-parallel
+                                 kernel on first request (device memory of the unit, freed with it); not an input of opusfe_unit_from_arrays.
+                                 The reference has no such field: a Rust Box tree is walked from the root (parse.rs:253-328); flat consumers
+                                 (tree-parallel passes like lower_par.h) need the upward link. */
+    OPUSFE_A_COUNT = 17
 };
 /* device pointer (owned by the unit, valid until opusfe_free_unit / the next opusfe_lower), element count and size */
 int opusfe_array(opusfe_unit* unit, int which, const void** d_ptr, uint64_t* count, uint32_t* elem_size);

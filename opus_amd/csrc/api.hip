@@ -468,7 +468,7 @@ static uint32_t swallowed_resync_point(opusfe_ctx* ctx, opusfe_unit* u) {
 
 static void drop_lex_and_parse(opusfe_ctx* ctx, opusfe_unit* u) {
     dev_free(ctx, u->d_tokens); dev_free(ctx, u->d_val64); dev_free(ctx, u->d_strpool); dev_free(ctx, u->d_seg_start);
-    dev_free(ctx, u->d_nodes); dev_free(ctx, u->d_seg_info); dev_free(ctx, u->d_def_nodes);
+    dev_free(ctx, u->d_nodes); dev_free(ctx, u->d_seg_info); dev_free(ctx, u->d_def_nodes); dev_free(ctx, u->d_parents); u->d_parents = nullptr;
     u->d_tokens = nullptr; u->d_val64 = nullptr; u->d_strpool = nullptr; u->d_seg_start = nullptr; u->d_nodes = nullptr; u->d_seg_info = nullptr; u->d_def_nodes = nullptr;
     u->n_tokens = u->n_val64 = u->n_strpool = u->n_segs = u->n_nodes = u->n_defs = 0;
     u->parsed = false; u->has_error = false; u->have_h_lex = u->have_h_ast = false;
@@ -766,6 +766,24 @@ int opusfe_array(opusfe_unit* u, int which, const void** d_ptr, uint64_t* count,
             es = sizeof(SemErr);
             if (u->lowered && u->ir && (u->status == OPUSFE_OK || u->status == OPUSFE_SEMANTIC)) { p = ((const IrResult*)u->ir)->d_errs; n = ((const IrResult*)u->ir)->n_errs; }
             break;
+        case OPUSFE_A_PARENTS: {
+            es = 4;
+            if (!u->parsed || !u->d_nodes || !u->n_nodes || (u->status != OPUSFE_OK && u->status != OPUSFE_SEMANTIC)) break;
+            if (!u->d_parents) {
+                int rc = guarded(u->ctx, [&] {
+                    opusfe_ctx* ctx = u->ctx;
+                    uint32_t* d = dev_alloc_t<uint32_t>(ctx, u->n_nodes);
+                    HIP_TRY(hipMemsetAsync(d, 0xFF, u->n_nodes * 4, ctx->stream));
+                    LAUNCH(ctx, "ast_parents", k_ast_parents, grid_for(u->n_nodes, 256), 256, (const opusfe_node*)u->d_nodes, (uint32_t)u->n_nodes, d);
+                    HIP_TRY(hipStreamSynchronize(ctx->stream));
+                    u->d_parents = d;
+                    return (int)OPUSFE_OK;
+                });
+                if (rc != OPUSFE_OK) return rc;
+            }
+            p = u->d_parents; n = u->n_nodes;
+            break;
+        }
     }
     if (!p) n = 0;   // a stage that did not run (or stopped early) has no array
     if (d_ptr) *d_ptr = n ? p : nullptr;
@@ -826,7 +844,7 @@ void opusfe_free_unit(opusfe_unit* u) {
     (void)hipStreamSynchronize(ctx->stream);
     if (u->own_src) dev_free(ctx, (void*)u->d_src);
     dev_free(ctx, u->d_tokens); dev_free(ctx, u->d_val64); dev_free(ctx, u->d_strpool); dev_free(ctx, u->d_seg_start);
-    dev_free(ctx, u->d_nodes); dev_free(ctx, u->d_seg_info); dev_free(ctx, u->d_def_nodes); dev_free(ctx, u->d_headers);
+    dev_free(ctx, u->d_nodes); dev_free(ctx, u->d_seg_info); dev_free(ctx, u->d_def_nodes); dev_free(ctx, u->d_headers); dev_free(ctx, u->d_parents);
     free_ir(ctx, u);
     delete u;
 }

@@ -1745,13 +1745,11 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
                 }
                 const size_t lds = par::lds_bytes(a.nmax, a.maxdef, threads);
                 prof_begin(ctx, NAMES[name_i < 0 ? 11 : name_i]);
-#define OPUSFE_PAR_LAUNCH(T) do { HIP_TRY(hipFuncSetAttribute((const void*)par::k_lower_par<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-                                  hipLaunchKernelGGL((par::k_lower_par<T>), dim3(a.n_list), dim3(T), lds, st, S, a); } while (0)
-                switch (threads) {
-                    case 64: OPUSFE_PAR_LAUNCH(64); break; case 128: OPUSFE_PAR_LAUNCH(128); break; case 256: OPUSFE_PAR_LAUNCH(256); break;
-                    case 512: OPUSFE_PAR_LAUNCH(512); break; default: OPUSFE_PAR_LAUNCH(1024); break;
+{
+                    static bool attr_done = false;      // (the limit is a property of the function: raised once to what the largest class needs)
+                    if (!attr_done) { HIP_TRY(hipFuncSetAttribute((const void*)par::k_lower_par, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160u << 10))); attr_done = true; }
+                    hipLaunchKernelGGL(par::k_lower_par, dim3(a.n_list), dim3(threads), lds, st, S, a);
                 }
-#undef OPUSFE_PAR_LAUNCH
                 HIP_TRY(hipGetLastError());
                 prof_end(ctx);
             }

@@ -37,6 +37,7 @@ inline bool par_sync_or(bool v) { return v; }
 inline void par_fence() {}
 inline uint32_t* g_emu_lds = nullptr;          // tests/emu: heap block of exactly the kernel's dynamic LDS size (ASan checks it)
 #define PAR_LDS_BASE() (::opusfe::par::g_emu_lds)
+inline uint64_t g_emu_stat[8] = {0};          // tests/emu: rounds of the three fixpoints, weighted by nodes (EMU_VERBOSE prints them)
 #else
 #define PAR_SYNC() __syncthreads()
 __device__ __forceinline__ bool par_sync_or(bool v) { return __syncthreads_or(v ? 1 : 0) != 0; }
@@ -1493,7 +1494,12 @@ __device__ __forceinline__ void lower_function(Fn& f) {
             if (!operands_done(f, i)) continue;
             if (visit<false>(f, i)) { par_fence(); f.st[i] |= ST_DONE; progress = true; }
         }
-        if (!par_sync_or(progress && !failed(f))) break;
+        if (!par_sync_or(progress && !failed(f))) {
+#ifdef OPUSFE_EMU
+            g_emu_stat[0] += 1; g_emu_stat[1] += round + 1; g_emu_stat[2] += (uint64_t)(round + 1) * n_active; g_emu_stat[3] += n_active; g_emu_stat[4] += nn;
+#endif
+            break;
+        }
     }
     if (failed(f)) return;
     if (!(f.st[0] & ST_DONE)) { fallback(f); return; }
@@ -1558,8 +1564,9 @@ __device__ __forceinline__ void lower_function(Fn& f) {
 #ifndef OPUSFE_PAR_WAVES
 #define OPUSFE_PAR_WAVES 4
 #endif
-template <int THREADS>
-__global__ MACHINE_ATTR(OPUSFE_PAR_WAVES) __launch_bounds__(THREADS) void k_lower_par(SemView S, ParArgs A) {
+// (One instantiation for every workgroup size: with 4 waves per SIMD the register budget of a 1024-thread workgroup is the same 128
+// VGPRs, and five copies of the two inlined visits made the library take 17 minutes to compile.)
+__global__ MACHINE_ATTR(OPUSFE_PAR_WAVES) __launch_bounds__(1024) void k_lower_par(SemView S, ParArgs A) {
     const uint32_t slot = blockIdx.x;
     if (slot >= A.n_list) return;
     const uint32_t d = A.list ? A.list[slot] : slot;

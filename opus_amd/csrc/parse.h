@@ -899,4 +899,13 @@ inline void run_parser(opusfe_ctx* ctx, opusfe_unit* u) {
 
 #endif  // OPUSFE_EMU
 
+// OPUSFE_A_PARENTS: every node writes its index into the slot of each of its children (the chain is bounded by the node count, like
+// every walk over links that came from memory)
+__global__ void k_ast_parents(const opusfe_node* __restrict__ nodes, uint32_t n_nodes, uint32_t* __restrict__ parents) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_nodes) return;
+    uint32_t c = nodes[p].first_child, guard = 0;
+    while (c != OPUSFE_NONE && c < n_nodes && guard++ < n_nodes) { parents[c] = p; c = nodes[c].next; }
+}
+
 }  // namespace opusfe

@@ -12,11 +12,11 @@ from decimal import Decimal
 import numpy as np
 
 (A_SOURCE, A_TOKENS, A_VAL64, A_STRINGS, A_NODES, A_DEFINITIONS, A_SIGNATURES, A_GLOBALS, A_TYPES, A_NODE_TYPES, A_FUNCTIONS,
- A_VARIABLES, A_BB_OFFSETS, A_INSTRS, A_CALL_ARGS, A_SEM_ERRORS) = range(16)
+ A_VARIABLES, A_BB_OFFSETS, A_INSTRS, A_CALL_ARGS, A_SEM_ERRORS, A_PARENTS) = range(17)
 
 u8, u16, u32, u64 = np.uint8, np.uint16, np.uint32, np.uint64
 DTYPES = {
-    A_SOURCE: u8, A_VAL64: u64, A_STRINGS: u8, A_DEFINITIONS: u32, A_NODE_TYPES: u32, A_BB_OFFSETS: u32, A_CALL_ARGS: u32,
+    A_SOURCE: u8, A_VAL64: u64, A_STRINGS: u8, A_DEFINITIONS: u32, A_NODE_TYPES: u32, A_BB_OFFSETS: u32, A_CALL_ARGS: u32, A_PARENTS: u32,
     A_TOKENS: np.dtype([("kind", u8), ("flags", u8), ("aux", u16), ("low", u32), ("len", u32), ("payload", u32)]),
     A_NODES: np.dtype([("kind", u8), ("sub", u8), ("nchild", u16), ("first_child", u32), ("next", u32), ("payload", u32),
                        ("low", u32), ("high", u32)]),

@@ -248,7 +248,7 @@ void emu_lower(EmuUnit& E) {
             const size_t lds = par::lds_bytes(PA.nmax, PA.maxdef, 1);
             par::g_emu_lds = (uint32_t*)malloc(lds);
             memset(par::g_emu_lds, 0xA5, lds);
-            emu_launch((par::k_lower_par<64>), n_defs, 1, S, PA);
+            emu_launch(par::k_lower_par, n_defs, 1, S, PA);
             free(par::g_emu_lds); par::g_emu_lds = nullptr;
         }
         emu_launch(k_fb_mark, grid_for(n_defs, 256), 256, (const FuncIr*)R->funcs.data(), n_funcs, def_nodes, n_defs, n_nodes, (const DefCnt*)def_excl.data(), nodes, fb_flag.data(), fbx.data());
@@ -256,6 +256,7 @@ void emu_lower(EmuUnit& E) {
         for (uint32_t i = 0; i < n_funcs; i++) { FbIdx c = fbx[i]; fbx[i] = fbt; fbt = OpAddFbIdx()(fbt, c); }
         const uint32_t fb_nodes = fbt.nodes, fb_funcs = fbt.funcs;
         R->n_fallback = fb_funcs;
+        if (getenv("EMU_VERBOSE")) fprintf(stderr, "type fixpoint: %llu functions, %.1f rounds each, %.1f rounds per active node (node-weighted), active %llu of %llu nodes\n", (unsigned long long)par::g_emu_stat[0], (double)par::g_emu_stat[1] / (par::g_emu_stat[0] ? par::g_emu_stat[0] : 1), (double)par::g_emu_stat[2] / (par::g_emu_stat[3] ? par::g_emu_stat[3] : 1), (unsigned long long)par::g_emu_stat[3], (unsigned long long)par::g_emu_stat[4]);
         if (getenv("EMU_VERBOSE")) { fprintf(stderr, "functions lowered by the sequential machine: %u of %u\n", fb_funcs, n_funcs); for (auto& fr : R->funcs) if (fr.status == par::DS_FALLBACK) fprintf(stderr, "  function %u (node %u): declined at lower_par.h:%u\n", fr.func, fr.def_node, fr.pad); }
         if (getenv("EMU_REQUIRE_PAR") && fb_funcs) { fprintf(stderr, "emu: %u functions fell back\n", fb_funcs); u.status = OPUSFE_ERR_INTERNAL; cleanup_only = true; }
         LowerBuffers B{};

@@ -34,7 +34,7 @@ def test_record_sizes_match_the_header():
              V.A_FUNCTIONS: 64, V.A_SEM_ERRORS: 12, V.A_VAL64: 8, V.A_DEFINITIONS: 4}
     for which, size in sizes.items():
         assert np.dtype(V.DTYPES[which]).itemsize == size, which
-    assert len(V.DTYPES) == 16
+    assert len(V.DTYPES) == 17
 
 
 def test_hand_off_text_helpers_follow_rust_formatting():
@@ -61,3 +61,24 @@ def test_integration_doc_binds_every_entry_point():
     text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     missing = [n for n in declared_functions() if f"pub fn {n}(" not in text]
     assert not missing, missing
+
+
+def test_static_library_links_into_a_plain_c_program(tmp_path):
+    """libopusfe.a: a C program that includes only include/opusfe.h links against the archive with the HIP
+    runtime and the C++ runtime, and every declared entry point is defined in it"""
+    import shutil
+    import subprocess
+    static = os.path.join(os.path.dirname(opus_amd.library_path()), "libopusfe.a")
+    assert os.path.exists(static), "build() writes libopusfe.a next to libopusfe.so"
+    nm = subprocess.run(["nm", "--defined-only", static], capture_output=True, text=True, check=True).stdout
+    defined = set(re.findall(r" T (opusfe_[a-z0-9_]+)$", nm, flags=re.M))
+    assert set(declared_functions()) <= defined
+    cc = shutil.which("gcc")
+    src = tmp_path / "main.c"
+    src.write_text('#include "opusfe.h"\n#include <stdio.h>\nint main(void) { opusfe_ctx* c = 0; int rc = opusfe_create(&c, 0);\n'
+                   ' printf("rc=%d\\n", rc); if (rc == OPUSFE_OK) opusfe_destroy(c); return 0; }\n')
+    exe = tmp_path / "main"
+    subprocess.run([cc, "-I", os.path.join(ROOT, "include"), str(src), static, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lamdhip64", "-lstdc++",
+                    "-lpthread", "-lm", "-ldl", "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and re.match(r"rc=-?\d+", out.stdout)      # OPUSFE_ERR_HIP without a GPU, OPUSFE_OK with one: never a crash

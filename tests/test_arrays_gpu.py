@@ -144,3 +144,28 @@ def test_lowering_stats_and_memory_held(fe):
     v = fe.get_definitions(big)
     assert v.compile_source() == 0 and v.lowering_stats() == (0, 1)
     assert v.dump_ir() == O.dump(big, O.IR)
+
+
+def test_parent_array(fe):
+    """OPUSFE_A_PARENTS: the upward link of every node, built on request; the inverse of the first_child / next chains"""
+    src = O.generate(34, 300_000)
+    u = fe.get_definitions(src)
+    assert u.status == 0
+    nodes, defs, par = u.array(V.A_NODES), u.array(V.A_DEFINITIONS), u.array(V.A_PARENTS)
+    assert len(par) == len(nodes) == u.counts()["nodes"]
+    roots = np.zeros(len(nodes), dtype=bool)
+    roots[defs] = True
+    assert ((par == V.NONE) == roots).all()                       # exactly the definition roots have no parent
+    # rebuild the parent array on the host from the child chains
+    want = np.full(len(nodes), V.NONE, dtype=np.uint32)
+    fc, nx = nodes["first_child"], nodes["next"]
+    for p in range(len(nodes)):
+        c = int(fc[p])
+        while c != V.NONE:
+            want[c] = p
+            c = int(nx[c])
+    assert (par == want).all()
+    assert u.array_device(V.A_PARENTS)[0] == u.array_device(V.A_PARENTS)[0] != 0       # built once, same device array
+    # a unit that did not parse has none
+    bad = fe.get_definitions(b"f( int32\n")
+    assert bad.status != 0 and len(bad.array(V.A_PARENTS)) == 0
