@@ -81,12 +81,6 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--gen-flags", type=int, default=1, help="generator flags (bit 0: inject the three depth-1000 regions of BASELINE configs[2]); diagnostics only")
     args = ap.parse_args()
-    if args.workload == "c5":
-        # A corpus is many small, latency-bound pipelines: the batch entry point runs W worker contexts side by side, and HIP maps
-        # their streams onto the hardware queues of the process (4 by default).  Both are set before HIP initialises.
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-        os.environ.setdefault("OPUSFE_BATCH_WORKERS", "16")
-
     import torch
     import opus_amd
     import oracle_lib as O   # generator (and, on rank 0 at N=1, the oracle as the timed CPU baseline)

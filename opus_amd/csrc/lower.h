@@ -1746,8 +1746,7 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
                 const size_t lds = par::lds_bytes(a.nmax, a.maxdef, threads);
                 prof_begin(ctx, NAMES[name_i < 0 ? 11 : name_i]);
 {
-                    static bool attr_done = false;      // (the limit is a property of the function: raised once to what the largest class needs)
-                    if (!attr_done) { HIP_TRY(hipFuncSetAttribute((const void*)par::k_lower_par, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160u << 10))); attr_done = true; }
+                    HIP_TRY(hipFuncSetAttribute((const void*)par::k_lower_par, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                     hipLaunchKernelGGL(par::k_lower_par, dim3(a.n_list), dim3(threads), lds, st, S, a);
                 }
                 HIP_TRY(hipGetLastError());
