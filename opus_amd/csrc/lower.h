@@ -1668,6 +1668,7 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
         PA.pp_base = pp_base; PA.out = R->d_funcs; PA.status = ctx->d_status + WL_STATUS;
         { static const char* sp = getenv("OPUSFE_PAR_STOP"); PA.stop_phase = sp ? (uint32_t)atoi(sp) : 0u; }
         { static const char* sr = getenv("OPUSFE_PAR_ROUNDS"); PA.stop_rounds = sr ? (uint32_t)atoi(sr) : 0u; }
+        { static const char* cl = getenv("OPUSFE_PAR_CLIMB"); PA.climb = cl ? (uint32_t)atoi(cl) : 0u; }
         PA.counters = counters; PA.overflow = (uint32_t*)(counters + par::CTR_COUNT); PA.err_counter = (uint32_t*)(counters + par::CTR_COUNT + 1);
         PA.cap_vars = cap[0]; PA.cap_instrs = cap[1]; PA.cap_bbs = cap[2]; PA.cap_types = cap[3]; PA.cap_cargs = cap[4]; PA.cap_errs = cap[5];
         PA.vars = R->d_vars; PA.instrs = R->d_instrs; PA.bb_offsets = R->d_bb_offsets; PA.cargs = R->d_cargs; PA.types_out = R->d_types;

@@ -81,6 +81,7 @@ struct ParArgs {
     // When an array is too small nothing is written, `overflow` is raised and the host runs again with the exact totals.
     uint32_t stop_phase;      // diagnostics (OPUSFE_PAR_STOP): leave after phase n, 0 = run everything
     uint32_t stop_rounds;     // diagnostics (OPUSFE_PAR_ROUNDS): at most n rounds of the type fixpoint, 0 = no limit
+    uint32_t climb;           // type fixpoint: the lane that lowers the last operand goes on with the parent (OPUSFE_PAR_CLIMB=0 turns it off)
     unsigned long long* counters; uint32_t* overflow; uint32_t* err_counter;   // (semantic errors: sequential machine only)
     uint64_t cap_vars, cap_instrs, cap_bbs, cap_types, cap_cargs, cap_errs;
     opusfe_variable* vars; opusfe_instr* instrs; uint32_t* bb_offsets; uint32_t* cargs; TypeRec* types_out;
@@ -106,9 +107,10 @@ struct ArgEnt { uint32_t hash, low, len, pad; Desc vt; };
 enum { MAX_ARGS = 16, MAX_CALL_ARGS = 8 };
 
 // per-node state bits (st[])
-enum : uint32_t { ST_DONE = 1u, ST_STAGE1 = 2u /* for: the loop variable has its type */, ST_DIV = 4u, ST_DEAD = 8u, ST_CTX = 16u /* rank, depth and context assigned */, ST_HASBREAK = 32u,
+enum : uint32_t { ST_DONE = 1u, ST_STAGE1 = 2u /* for: the loop variable has its type */, ST_DIV = 4u, ST_DEAD = 8u, ST_CTX = 16u /* rank, depth and context assigned */, ST_HASBREAK = 32u, ST_CLAIM = 64u /* a lane is lowering it */,
                   ST_MODE_E = 1u << 8, ST_MODE_P = 2u << 8, ST_MODE_MASK = 3u << 8, ST_PT_SHIFT = 10, ST_DEREF = 1u << 12, ST_MUSTLV = 1u << 13,
-                  ST_EXP_SHIFT = 16, ST_EXP_MASK = 15u << 16 };
+                  ST_EXP_SHIFT = 16, ST_EXP_MASK = 15u << 16,
+                  ST_PEND_SHIFT = 20, ST_PEND_ONE = 1u << 20, ST_PEND_MASK = 0xFFFu << 20 /* operands that are not lowered yet (type fixpoint) */ };
 enum : uint32_t { EXP_NONE = 0, EXP_GENINT, EXP_BOOL, EXP_RET, EXP_SIZE, EXP_ASSIGN, EXP_FIELD, EXP_ARG };
 // name resolution results (ref[]): tag in the top 3 bits
 enum : uint32_t { RF_NONE = 0u, RF_LOCAL = 1u << 29, RF_ARG = 2u << 29, RF_GLOBAL = 3u << 29, RF_CONST = 4u << 29, RF_FUNC = 5u << 29, RF_CALL = 6u << 29, RF_CALL1 = 7u << 29 /* exactly one function of that name: its index */, RF_TAG = 7u << 29, RF_VAL = ~(7u << 29) };
@@ -121,13 +123,33 @@ __device__ __forceinline__ uint64_t pack4(const Cnt4& c) { return (uint64_t)c.v 
 __device__ __forceinline__ Cnt4 unpack4(uint64_t w) { return Cnt4{(uint32_t)(w & 0xFFFF), (uint32_t)((w >> 16) & 0xFFFF), (uint32_t)((w >> 32) & 0xFFFF), (uint32_t)(w >> 48)}; }
 
 // The function being lowered: tables, LDS arrays, result bases.  Lives in registers (everything is inlined into the kernel).
+// The per-node arrays live in LDS.  Their pointers carry the address space in the type: 32-bit offsets instead of 64-bit generic
+// pointers (twenty of them were most of the kernel's scalar-register pressure: 1279 spilled SGPRs), and every access is a
+// ds_read / ds_write by construction, never a flat instruction that decides at run time where the address points.
+#ifdef OPUSFE_EMU
+#define LDS_AS
+#else
+#define LDS_AS __attribute__((address_space(3)))
+#endif
+typedef LDS_AS uint64_t lds_u64; typedef LDS_AS uint32_t lds_u32; typedef LDS_AS uint16_t lds_u16; typedef LDS_AS uint8_t lds_u8;
+#ifdef OPUSFE_EMU
+inline uint32_t lds_add(lds_u32* p, uint32_t v) { const uint32_t o = *p; *p = o + v; return o; }
+inline uint32_t lds_sub(lds_u32* p, uint32_t v) { const uint32_t o = *p; *p = o - v; return o; }
+inline uint32_t lds_or(lds_u32* p, uint32_t v) { const uint32_t o = *p; *p = o | v; return o; }
+inline uint32_t lds_and(lds_u32* p, uint32_t v) { const uint32_t o = *p; *p = o & v; return o; }
+#else
+__device__ __forceinline__ uint32_t lds_add(lds_u32* p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ uint32_t lds_sub(lds_u32* p, uint32_t v) { return __hip_atomic_fetch_add(p, 0u - v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ uint32_t lds_or(lds_u32* p, uint32_t v) { return __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ uint32_t lds_and(lds_u32* p, uint32_t v) { return __hip_atomic_fetch_and(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+#endif
 struct Fn {
     SemView S; ParArgs A;
     uint32_t dn, nn, fidx, nargs; FuncRec F; uint64_t user_syms;
     // LDS
-    uint64_t* rt; uint64_t* cnt; uint32_t* kn; uint32_t* st; uint32_t* ref; uint32_t* rvi; uint32_t* pay;
-    uint16_t* fc; uint16_t* nx; uint16_t* pa; uint16_t* rk; uint16_t* sz; uint16_t* pe; uint16_t* cg; uint16_t* by_kind; uint8_t* tail;
-    DefEnt* defs; ArgEnt* args; uint32_t* misc; uint64_t* scratch;
+    lds_u64* rt; lds_u64* cnt; lds_u32* kn; lds_u32* st; lds_u32* ref; lds_u32* rvi; lds_u32* pay;
+    lds_u16* fc; lds_u16* nx; lds_u16* pa; lds_u16* rk; lds_u16* sz; lds_u16* pe; lds_u16* cg; lds_u16* by_kind; lds_u8* tail;
+    DefEnt* defs; ArgEnt* args; lds_u32* misc; lds_u64* scratch;
     // emit bases
     uint32_t var_base, instr_base, bb_base, type_base, carg_base, n_vars_tot, n_instrs_tot, n_bbs_tot, n_types_tot, n_cargs_tot;
     uint32_t tid, nthreads;
@@ -1203,7 +1225,7 @@ __device__ __forceinline__ uint32_t kind_class(const Fn& f, uint32_t i) {
 }
 
 // ---- block-wide exclusive scan of an LDS array (packed event counters; call-argument counts); returns the total -------
-template <class E> __device__ __forceinline__ uint64_t block_scan(Fn& f, E* a, uint32_t n) {
+template <class E, class P> __device__ __forceinline__ uint64_t block_scan(Fn& f, P a, uint32_t n) {
     const uint32_t T = f.nthreads, per = (n + T - 1) / T;
     const uint32_t lo = f.tid * per < n ? f.tid * per : n, hi = lo + per < n ? lo + per : n;
     uint64_t sum = 0;
@@ -1263,7 +1285,7 @@ __device__ __forceinline__ void lower_function(Fn& f) {
         uint32_t a = f.pa[i], child = i, depth = 0;
         bool dead = false;
         while (a != NONE16 && depth <= nn) {
-            atomicAdd(&f.rvi[a], 1u);
+            lds_add(&f.rvi[a], 1u);
             if (KIND(f, a) == E_Operator && SUB(f, a) == OP_Not && f.fc[a] == child) dead = true;     // Q9: the left operand of `not` is never evaluated
             child = a; a = f.pa[a]; depth++;
         }
@@ -1372,7 +1394,7 @@ __device__ __forceinline__ void lower_function(Fn& f) {
         if (!(f.st[i] & ST_CTX)) { fallback(f); continue; }
         if (k == S_VariableDefinition || k == E_VariableDefinition || k == S_For) {
             if (f.st[i] & ST_DEAD) { fallback(f); continue; }                           // a definition in code that is never evaluated
-            const uint32_t slot = atomicAdd(&f.misc[MI_NDEFS], 1u);
+            const uint32_t slot = lds_add(&f.misc[MI_NDEFS], 1u);
             if (slot >= f.A.maxdef) { fallback(f); continue; }
             const opusfe_token t = f.S.tok[f.pay[i]];
             if (t.kind != T_Identifier) { fallback(f); continue; }
@@ -1394,7 +1416,7 @@ __device__ __forceinline__ void lower_function(Fn& f) {
         if (k == S_Break || k == S_Continue) {
             const uint32_t loop = enclosing_loop(f, i);
             f.ref[i] = loop;
-            if (loop != NONE16 && k == S_Break) atomicOr(&f.st[loop], (uint32_t)ST_HASBREAK);
+            if (loop != NONE16 && k == S_Break) lds_or(&f.st[loop], (uint32_t)ST_HASBREAK);
         }
     }
     PAR_SYNC();
@@ -1480,18 +1502,22 @@ __device__ __forceinline__ void lower_function(Fn& f) {
     // ---- nodes by kind (kind_class): the sweeps below go through the nodes in this order; nodes with nothing to lower are left out ----
     for (uint32_t k = tid; k < KC_COUNT; k += T) f.misc[MI_KHIST + k] = 0;
     PAR_SYNC();
-    for (uint32_t i = tid; i < nn; i += T) atomicAdd(&f.misc[MI_KHIST + kind_class(f, i)], 1u);
+    for (uint32_t i = tid; i < nn; i += T) lds_add(&f.misc[MI_KHIST + kind_class(f, i)], 1u);
     PAR_SYNC();
     if (tid == 0) { uint32_t run = 0; for (uint32_t c = 0; c < KC_COUNT; c++) { const uint32_t v = f.misc[MI_KHIST + c]; f.misc[MI_KHIST + c] = run; run += v; if (c == KC_NONE - 1) f.misc[MI_NACTIVE] = run; } }
     PAR_SYNC();
     for (uint32_t i = tid; i < nn; i += T) {
         const uint32_t c = kind_class(f, i);
-        const uint32_t pos = atomicAdd(&f.misc[MI_KHIST + c], 1u);
+        const uint32_t pos = lds_add(&f.misc[MI_KHIST + c], 1u);
         f.by_kind[pos] = (uint16_t)i;
         if (c == KC_NONE && !(f.st[i] & ST_DEAD)) f.st[i] |= ST_DONE;                      // nothing to lower: its parent need not wait
     }
     PAR_SYNC();
     const uint32_t n_active = f.misc[MI_NACTIVE];
+    // every node counts the operands it has to wait for (in its own state word, so that "ready?" is one LDS read per round instead
+    // of a walk over the children): each node that will be lowered adds one to its parent
+    for (uint32_t i = tid; i < nn; i += T) if (!(f.st[i] & (ST_DONE | ST_DEAD)) && f.pa[i] != NONE16) lds_add(&f.st[f.pa[i]], (uint32_t)ST_PEND_ONE);
+    PAR_SYNC();
     // ---- types, counts (bottom-up fixpoint) ----
     // (A variant that first compacted the ready nodes of a round into dense per-class queues and lowered those with all lanes was
     // measured slower: 32 ms against 21 ms per 256 MB — two more barriers and the queue bookkeeping cost more than the idle lanes.)
@@ -1499,18 +1525,35 @@ __device__ __forceinline__ void lower_function(Fn& f) {
         bool progress = false;
         if (f.A.stop_rounds && round >= f.A.stop_rounds) break;
         for (uint32_t j = tid; j < n_active; j += T) {
-            const uint32_t i = f.by_kind[j];
-            const uint32_t s = f.st[i];
-            if (s & (ST_DONE | ST_DEAD)) continue;
-            if (KIND(f, i) == S_For && !(s & ST_STAGE1)) {       // the loop variable gets its type as soon as the iteree has one
-                uint32_t cond, tb, eb; blocks_of(f, i, &cond, &tb, &eb);
-                if (cond != NONE16 && (f.st[cond] & ST_DONE)) {
-                    const Desc vt = for_variable_type(f, i);
-                    if (!failed(f)) { f.defs[f.ref[i]].vt = vt; par_fence(); f.st[i] |= ST_STAGE1; progress = true; }
+            // A lane lowers its node and then, as long as it was the last operand its parent waited for, the parent (and so on up):
+            // what is left for the next round are the nodes that wait for the type of a local (and what hangs above them).
+            uint32_t i = f.by_kind[j];
+            for (;;) {
+                const uint32_t s = f.st[i];
+                if (s & (ST_DONE | ST_DEAD | ST_CLAIM)) break;
+                if (KIND(f, i) == S_For && !(s & ST_STAGE1)) {       // the loop variable gets its type as soon as the iteree has one
+                    uint32_t cond, tb, eb; blocks_of(f, i, &cond, &tb, &eb);
+                    if (cond != NONE16 && (f.st[cond] & ST_DONE)) {
+                        const Desc vt = for_variable_type(f, i);
+                        if (!failed(f)) { f.defs[f.ref[i]].vt = vt; par_fence(); lds_or(&f.st[i], (uint32_t)ST_STAGE1); progress = true; }
+                    }
                 }
+                if (s & ST_PEND_MASK) break;
+                if (lds_or(&f.st[i], (uint32_t)ST_CLAIM) & (ST_CLAIM | ST_DONE)) break;       // another lane got here first
+                par_fence();
+#ifdef OPUSFE_EMU
+                if (!operands_done(f, i)) f.misc[MI_BAD] = 1;        // the counter and the walk must agree
+#endif
+                if (!visit<false>(f, i)) { lds_and(&f.st[i], ~(uint32_t)ST_CLAIM); break; }   // an input is not ready: next round
+                par_fence();
+                lds_or(&f.st[i], (uint32_t)ST_DONE);
+                progress = true;
+                const uint32_t p = f.pa[i];
+                if (p == NONE16) break;
+                const uint32_t before = lds_sub(&f.st[p], (uint32_t)ST_PEND_ONE);
+                if ((before & ST_PEND_MASK) != ST_PEND_ONE || !f.A.climb) break;
+                i = p;
             }
-            if (!operands_done(f, i)) continue;
-            if (visit<false>(f, i)) { par_fence(); f.st[i] |= ST_DONE; progress = true; }
         }
         if (!par_sync_or(progress && !failed(f))) {
 #ifdef OPUSFE_EMU
@@ -1526,15 +1569,15 @@ __device__ __forceinline__ void lower_function(Fn& f) {
     {   // the packed 16-bit fields must not carry into each other: check the four sums first
         uint32_t sv = 0, stt = 0, si = 0, sb = 0;
         for (uint32_t p = tid; p < 2 * nn; p += T) { const Cnt4 c = unpack4(f.cnt[p]); sv += c.v; stt += c.t; si += c.i; sb += c.b; }
-        if (sv) atomicAdd(&f.misc[MI_SUM_V], sv);
-        if (stt) atomicAdd(&f.misc[MI_SUM_T], stt);
-        if (si) atomicAdd(&f.misc[MI_SUM_I], si);
-        if (sb) atomicAdd(&f.misc[MI_SUM_B], sb);
+        if (sv) lds_add(&f.misc[MI_SUM_V], sv);
+        if (stt) lds_add(&f.misc[MI_SUM_T], stt);
+        if (si) lds_add(&f.misc[MI_SUM_I], si);
+        if (sb) lds_add(&f.misc[MI_SUM_B], sb);
         PAR_SYNC();
         if (f.misc[MI_SUM_V] > 0xFFF0u || f.misc[MI_SUM_T] > 0xFFF0u || f.misc[MI_SUM_I] > 0xFFF0u || f.misc[MI_SUM_B] > 0xFFF0u) { fallback(f); return; }
     }
-    const Cnt4 tot = unpack4(block_scan(f, f.cnt, 2 * nn));
-    const uint32_t tot_cargs = (uint32_t)block_scan(f, f.cg, nn);
+    const Cnt4 tot = unpack4(block_scan<uint64_t>(f, f.cnt, 2 * nn));
+    const uint32_t tot_cargs = (uint32_t)block_scan<uint16_t>(f, f.cg, nn);
     if (tot_cargs > 0xFFF0u) { fallback(f); return; }
     if (f.A.stop_phase == 7) { fallback(f); return; }
     // ---- the function's place in the dense arrays ----
@@ -1600,30 +1643,30 @@ __global__ MACHINE_ATTR(OPUSFE_PAR_WAVES) __launch_bounds__(1024) void k_lower_p
     f.var_base = f.instr_base = f.bb_base = f.type_base = f.carg_base = 0;
     f.n_vars_tot = f.n_instrs_tot = f.n_bbs_tot = f.n_types_tot = f.n_cargs_tot = 0;
     // carve the dynamic LDS block (same order as lds_bytes)
-    uint8_t* base = (uint8_t*)PAR_LDS_BASE();
+    LDS_AS uint8_t* base = (LDS_AS uint8_t*)PAR_LDS_BASE();
     const uint32_t nmax = A.nmax;
-    f.rt = (uint64_t*)base; base += 8ull * nmax;
-    f.cnt = (uint64_t*)base; base += 16ull * nmax;
-    f.kn = (uint32_t*)base; base += 4ull * nmax;
-    f.st = (uint32_t*)base; base += 4ull * nmax;
-    f.ref = (uint32_t*)base; base += 4ull * nmax;
-    f.rvi = (uint32_t*)base; base += 4ull * nmax;
-    f.pay = (uint32_t*)base; base += 4ull * nmax;
-    f.fc = (uint16_t*)base; base += 2ull * nmax;
-    f.nx = (uint16_t*)base; base += 2ull * nmax;
-    f.pa = (uint16_t*)base; base += 2ull * nmax;
-    f.rk = (uint16_t*)base; base += 2ull * nmax;
-    f.sz = (uint16_t*)base; base += 2ull * nmax;
-    f.pe = (uint16_t*)base; base += 2ull * nmax;
-    f.cg = (uint16_t*)base; base += 2ull * nmax;
-    f.by_kind = (uint16_t*)base; base += 2ull * nmax;
-    f.tail = (uint8_t*)base; base += 2ull * nmax;
-    base = (uint8_t*)(((uintptr_t)base + 7) & ~(uintptr_t)7);
+    f.rt = (lds_u64*)base; base += 8u * nmax;
+    f.cnt = (lds_u64*)base; base += 16u * nmax;
+    f.kn = (lds_u32*)base; base += 4u * nmax;
+    f.st = (lds_u32*)base; base += 4u * nmax;
+    f.ref = (lds_u32*)base; base += 4u * nmax;
+    f.rvi = (lds_u32*)base; base += 4u * nmax;
+    f.pay = (lds_u32*)base; base += 4u * nmax;
+    f.fc = (lds_u16*)base; base += 2u * nmax;
+    f.nx = (lds_u16*)base; base += 2u * nmax;
+    f.pa = (lds_u16*)base; base += 2u * nmax;
+    f.rk = (lds_u16*)base; base += 2u * nmax;
+    f.sz = (lds_u16*)base; base += 2u * nmax;
+    f.pe = (lds_u16*)base; base += 2u * nmax;
+    f.cg = (lds_u16*)base; base += 2u * nmax;
+    f.by_kind = (lds_u16*)base; base += 2u * nmax;
+    f.tail = (lds_u8*)base; base += 2u * nmax;
+    base += (8u - (uint32_t)(uintptr_t)base % 8u) % 8u;
     f.defs = (DefEnt*)base; base += sizeof(DefEnt) * A.maxdef;
     f.args = (ArgEnt*)base; base += sizeof(ArgEnt) * MAX_ARGS;
-    f.misc = (uint32_t*)base; base += 4 * MI_WORDS;
-    base = (uint8_t*)(((uintptr_t)base + 7) & ~(uintptr_t)7);
-    f.scratch = (uint64_t*)base;
+    f.misc = (lds_u32*)base; base += 4 * MI_WORDS;
+    base += (8u - (uint32_t)(uintptr_t)base % 8u) % 8u;
+    f.scratch = (lds_u64*)base;
     lower_function(f);
     PAR_SYNC();
     if (f.tid == 0) {

@@ -242,7 +242,7 @@ void emu_lower(EmuUnit& E) {
         PA.counters = counters; PA.overflow = (uint32_t*)(counters + par::CTR_COUNT); PA.err_counter = (uint32_t*)(counters + par::CTR_COUNT + 1);
         PA.cap_vars = cap[0]; PA.cap_instrs = cap[1]; PA.cap_bbs = cap[2]; PA.cap_types = cap[3]; PA.cap_cargs = cap[4]; PA.cap_errs = ~0ull;     // (the dense diagnostics block below has the sparse capacity)
         PA.vars = dv; PA.instrs = di; PA.bb_offsets = dbo; PA.cargs = dc; PA.types_out = dty;
-        PA.list = nullptr; PA.n_list = n_defs; PA.nmax = getenv("EMU_PAR_NMAX") ? (uint32_t)atoi(getenv("EMU_PAR_NMAX")) : 2048u; PA.maxdef = getenv("EMU_PAR_MAXDEF") ? (uint32_t)atoi(getenv("EMU_PAR_MAXDEF")) : 256u;
+        PA.list = nullptr; PA.n_list = n_defs; PA.nmax = getenv("EMU_PAR_NMAX") ? (uint32_t)atoi(getenv("EMU_PAR_NMAX")) : 2048u; PA.maxdef = getenv("EMU_PAR_MAXDEF") ? (uint32_t)atoi(getenv("EMU_PAR_MAXDEF")) : 256u; PA.climb = getenv("EMU_PAR_CLIMB") ? 1u : 0u;
         S.types = gtypes;
         if (!seq_only) {
             const size_t lds = par::lds_bytes(PA.nmax, PA.maxdef, 1);

@@ -31,6 +31,8 @@ template <class T, class U> inline T atomicMin(T* p, U v) { T o = *p; if ((T)v <
 template <class T, class U, class V> inline T atomicCAS(T* p, U cmp, V val) { T o = *p; if (o == (T)cmp) *p = (T)val; return o; }
 template <class T, class U> inline T atomicAdd(T* p, U v) { T o = *p; *p = o + (T)v; return o; }
 template <class T, class U> inline T atomicOr(T* p, U v) { T o = *p; *p = o | (T)v; return o; }
+template <class T, class U> inline T atomicSub(T* p, U v) { T o = *p; *p = o - (T)v; return o; }
+template <class T, class U> inline T atomicAnd(T* p, U v) { T o = *p; *p = o & (T)v; return o; }
 [[noreturn]] inline void emu_collective() { fprintf(stderr, "emu: cross-lane primitive executed\n"); abort(); }
 inline int __shfl_up(int, int, int) { emu_collective(); }
 inline int __shfl_down(int, int, int) { emu_collective(); }
