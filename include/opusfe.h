@@ -206,7 +206,11 @@ typedef struct opusfe_signature {        /* compile.rs:300-352 Function / Functi
     uint32_t def_node, name_tok, nargs, ret_type, first_arg /* node; siblings follow */, flags /* bit0 extern */;
 } opusfe_signature;
 typedef struct opusfe_global { uint32_t def_node, type_id, is_const, name_tok; } opusfe_global;
-typedef struct opusfe_semantic_error { uint32_t kind /* compile.rs:124-152 variant index */, low, len; } opusfe_semantic_error;
+/* kind and span, plus what the message of compile.rs:816-915 prints besides the span: `name` = token index of the variable /
+   field / function name (0x80000000 | token kind for a builtin operator symbol, 0xFFFFFFFF = none); `nargs` = number of argument
+   types of a function identifier (compile.rs:115-122), the first four of them in t[]; for the typed kinds t[0], t[1] are the one
+   or two types (expected, found / from, to / left, right); type ids index OPUSFE_A_TYPES */
+typedef struct opusfe_semantic_error { uint32_t kind /* compile.rs:124-152 variant index */, low, len, name, nargs, t[4]; } opusfe_semantic_error;
 
 enum {
     OPUSFE_A_SOURCE = 0,      /* uint8_t   source bytes */
@@ -217,7 +221,7 @@ enum {
     OPUSFE_A_DEFINITIONS = 5, /* uint32_t  root node of each definition */
     OPUSFE_A_SIGNATURES = 6,  /* opusfe_signature, one per function / extern (after opusfe_lower) */
     OPUSFE_A_GLOBALS = 7,     /* opusfe_global */
-    OPUSFE_A_TYPES = 8,       /* opusfe_type */
+    OPUSFE_A_TYPES = 8,       /* opusfe_type (also after OPUSFE_SEMANTIC: the global records, which the finalize-time diagnostics name) */
     OPUSFE_A_NODE_TYPES = 9,  /* uint32_t  per node: resolved type id of a type node (compile.rs:919 resolve_type), else 0xFFFFFFFF */
     OPUSFE_A_FUNCTIONS = 10,  /* opusfe_function_ir */
     OPUSFE_A_VARIABLES = 11,  /* opusfe_variable  (generate_ir.rs:69 variables) */

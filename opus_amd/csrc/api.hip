@@ -745,6 +745,7 @@ int opusfe_array(opusfe_unit* u, int which, const void** d_ptr, uint64_t* count,
     if (!u || which < 0 || which >= OPUSFE_A_COUNT) return OPUSFE_ERR_ARG;
     // the IR-side arrays exist only after a successful opusfe_lower (finalize errors leave no IR, frontend.rs:145)
     const IrResult* R = u->lowered && u->status == OPUSFE_OK ? (const IrResult*)u->ir : nullptr;
+    const IrResult* RS = u->lowered && u->ir && (u->status == OPUSFE_OK || u->status == OPUSFE_SEMANTIC) ? (const IrResult*)u->ir : nullptr;
     const void* p = nullptr; uint64_t n = 0; uint32_t es = 0;
     switch (which) {
         case OPUSFE_A_SOURCE: p = u->d_src; n = u->len; es = 1; break;
@@ -755,8 +756,9 @@ int opusfe_array(opusfe_unit* u, int which, const void** d_ptr, uint64_t* count,
         case OPUSFE_A_DEFINITIONS: p = u->d_def_nodes; n = u->n_defs; es = 4; break;
         case OPUSFE_A_SIGNATURES: es = sizeof(FuncRec); if (R) { p = R->d_funcrecs; n = R->n_funcs; } break;
         case OPUSFE_A_GLOBALS: es = sizeof(GlobalRec); if (R) { p = R->d_globals; n = R->n_globals; } break;
-        case OPUSFE_A_TYPES: es = sizeof(TypeRec); if (R) { p = R->d_types; n = R->n_types; } break;
-        case OPUSFE_A_NODE_TYPES: es = 4; if (R) { p = R->d_tid_of_node; n = u->n_nodes; } break;
+        // (types and the type of every type node also after OPUSFE_SEMANTIC: the finalize-time diagnostics name them)
+        case OPUSFE_A_TYPES: es = sizeof(TypeRec); if (RS) { p = RS->d_types; n = RS->n_types; } break;
+        case OPUSFE_A_NODE_TYPES: es = 4; if (RS) { p = RS->d_tid_of_node; n = u->n_nodes; } break;
         case OPUSFE_A_FUNCTIONS: es = sizeof(FuncIr); if (R) { p = R->d_funcs; n = R->n_funcs; } break;
         case OPUSFE_A_VARIABLES: es = sizeof(opusfe_variable); if (R) { p = R->d_vars; n = R->n_vars; } break;
         case OPUSFE_A_BB_OFFSETS: es = 4; if (R) { p = R->d_bb_offsets; n = R->n_bbs + 1; } break;

@@ -223,11 +223,19 @@ struct Lowerer {
     MACHINE_STATE uint64_t user_syms;   // bit per operator-symbol token kind that has user-defined overloads in this unit
 
     // ---- spans / errors -------------------------------------------------------------------------
+    // what the message of the NEXT report() prints besides its span (SemErr in sem.h): set right before the report, consumed by it
+    MACHINE_STATE uint32_t ei_name, ei_nargs, ei_t0, ei_t1, ei_t2, ei_t3;
+    __device__ void einfo(uint32_t name, uint32_t nargs, uint32_t t0, uint32_t t1 = OPUSFE_NONE, uint32_t t2 = OPUSFE_NONE, uint32_t t3 = OPUSFE_NONE) {
+        ei_name = uni(name); ei_nargs = uni(nargs); ei_t0 = uni(t0); ei_t1 = uni(t1); ei_t2 = uni(t2); ei_t3 = uni(t3);
+    }
+    __device__ void einfo_clear() { ei_name = OPUSFE_NONE; ei_nargs = 0; ei_t0 = ei_t1 = ei_t2 = ei_t3 = OPUSFE_NONE; }
+    __device__ static uint32_t einfo_key(NameKey k) { return k.tok != OPUSFE_NONE ? k.tok : (0x80000000u | (uint32_t)k.sym); }
     __device__ void report(uint32_t kind, uint32_t low, uint32_t high) {
         kind = uni(kind); low = uni(low); high = uni(high);
-        if (nerrs < ecap) gst(errs + nerrs, SemErr{kind, low, high - low});
+        if (nerrs < ecap) gst(errs + nerrs, sem_err(kind, low, high - low, ei_name, ei_nargs, ei_t0, ei_t1, ei_t2, ei_t3));
         else internal();   // more diagnostics than the region holds (one per node + 16): an internal-capacity status, never a clipped list
         nerrs++;
+        einfo_clear();
     }
     __device__ void report_node(uint32_t kind, uint32_t node) { kind = uni(kind); node = uni(node); report(kind, N(node).low, N(node).high); }
     __device__ void report_tok(uint32_t kind, uint32_t t) { kind = uni(kind); t = uni(t); const opusfe_token x = TK(t); report(kind, x.low, x.low + x.len); }
@@ -444,6 +452,7 @@ struct Lowerer {
             push(ins(I_Cast, r, variable, 0, 0, 0, (uint16_t)ct));
             return r;
         }
+        einfo(OPUSFE_NONE, 0, expected, found);
         report_node(SE_UnexpectedType, span_node);
         return generate_error();
     }
@@ -482,6 +491,7 @@ struct Lowerer {
             return generate_error();
         }
         if (r.kind == TY_Error) return generate_error();
+        einfo(OPUSFE_NONE, 0, vtype(v));
         report(SE_InvalidOperandType, sp_low, sp_high);
         return generate_error();
     }
@@ -546,9 +556,10 @@ struct Lowerer {
         }
         const NameFns nf = name_has_functions(name);
         const uint32_t slot = nf.slot;
-        if (!nf.has) { report(SE_UndefinedFunction, sp_low, sp_high); return FN_NONE; }
-        if (n > 64) { unsupported(); return FN_NONE; }
 #define ARG_T(i) (types_in ? uni(gld(types_in + (i))) : vtype(argv.get(i)))
+#define FN_IDENT() einfo(einfo_key(name), n, n > 0 ? ARG_T(0) : OPUSFE_NONE, n > 1 ? ARG_T(1) : OPUSFE_NONE, n > 2 ? ARG_T(2) : OPUSFE_NONE, n > 3 ? ARG_T(3) : OPUSFE_NONE)
+        if (!nf.has) { FN_IDENT(); report(SE_UndefinedFunction, sp_low, sp_high); return FN_NONE; }
+        if (n > 64) { unsupported(); return FN_NONE; }
         uint32_t total = 0; candidate(name, slot, 0, &total);
         uint32_t first = FN_NONE; uint64_t ignorable = ~0ull;
         for (uint32_t c = 0; c < total; c++) {
@@ -561,7 +572,7 @@ struct Lowerer {
                 if ((ignorable >> i) & 1) if (!T().types_match_allow_generic(t2, t1)) ignorable &= ~(1ull << i);
             }
         }
-        if (first == FN_NONE) { report(SE_NoOverloadForFunction, sp_low, sp_high); return FN_NONE; }
+        if (first == FN_NONE) { FN_IDENT(); report(SE_NoOverloadForFunction, sp_low, sp_high); return FN_NONE; }
         for (uint32_t c = 0; c < total; c++) {
             uint32_t f = candidate(name, slot, c, &total);
             if (f == FN_NONE || !candidate_ok(f, argv, types_in, n)) continue;
@@ -574,8 +585,10 @@ struct Lowerer {
             }
             if (all) return f;
         }
+        FN_IDENT();
         report(SE_AmbiguousOverload, sp_low, sp_high);
         return FN_NONE;
+#undef FN_IDENT
 #undef ARG_T
     }
 
@@ -624,7 +637,7 @@ struct Lowerer {
             uint32_t nv = new_var(typ, true);
             push(ins(I_Load, nv, variable));
             ftype = trec(typ);
-            if (ftype.kind != TY_Function) { report(SE_CallOfNonFunction, sp_low, sp_high); return res; }
+            if (ftype.kind != TY_Function) { einfo(OPUSFE_NONE, 0, typ); report(SE_CallOfNonFunction, sp_low, sp_high); return res; }
             fv = nv; ret = ftype.sub; arg_src = 1;
         } else {
             fid = compiler_lookup_function(sp_low, sp_high, name, argv, nullptr, n);
@@ -678,6 +691,7 @@ struct Lowerer {
                 }
                 c = T().member_next(c);
             }
+            einfo(field_tok, 0, get_lvalue_type(rec));
             report(SE_FieldDoesNotExist, sp_low, sp_high);
             return generate_error();
         }
@@ -685,11 +699,12 @@ struct Lowerer {
             uint32_t idx, ft;
             if (name_is(S.src, TokView{}, field_tok, "data", 4)) { idx = 0; ft = type_pointer(PT_Array, TP_Natural8); }
             else if (name_is(S.src, TokView{}, field_tok, "length", 6)) { idx = 1; ft = TP_Size; }
-            else { report(SE_FieldDoesNotExist, sp_low, sp_high); return generate_error(); }
+            else { einfo(field_tok, 0, get_lvalue_type(rec)); report(SE_FieldDoesNotExist, sp_low, sp_high); return generate_error(); }
             uint32_t rvv = new_var(type_pointer(pt, ft), true);
             push(ins(I_BuiltinField, rvv, rec, 0, idx));
             return rvv;
         }
+        einfo(OPUSFE_NONE, 0, get_lvalue_type(rec));
         report(SE_FieldAccessOnNonRecord, sp_low, sp_high);
         return generate_error();
     }
@@ -865,7 +880,7 @@ struct Lowerer {
             case LS_ST_EXPR_1: rdiv = false; retn(); goto next;
             case LS_ST_VDEF_1: {
                 uint32_t v = rv, typ = vtype(v);
-                if (contains_local(nd.payload)) report_node(SE_ShadowedName, cur.node);
+                if (contains_local(nd.payload)) { einfo(nd.payload, 0, OPUSFE_NONE); report_node(SE_ShadowedName, cur.node); }
                 else {
                     uint32_t nv = new_var(type_mut(typ), false);
                     push(ins(I_Allocate, nv));
@@ -940,7 +955,7 @@ struct Lowerer {
                 uint32_t scope = nstack;
                 uint32_t pointer_type = tnode != OPUSFE_NONE ? type_mut(resolve_type(tnode, undefined_flag)) : (uint32_t)TP_Generic;
                 uint32_t iteration_variable;
-                if (contains_local(nd.payload)) { report_node(SE_ShadowedName, cur.node); iteration_variable = generate_error(); }
+                if (contains_local(nd.payload)) { einfo(nd.payload, 0, OPUSFE_NONE); report_node(SE_ShadowedName, cur.node); iteration_variable = generate_error(); }
                 else {
                     iteration_variable = new_var(pointer_type, false);
                     push(ins(I_Allocate, iteration_variable));
@@ -1065,7 +1080,7 @@ struct Lowerer {
                     uint32_t v = new_var(TP_Bool, true);
                     push(ins(I_Equals, v, l, r));
                     rv = v;
-                } else { report_node(SE_InvalidOperandTypes, cur.node); rv = generate_error(); }
+                } else { einfo(0x80000000u | (uint32_t)T_Is, 0, vtype(l), vtype(r)); report_node(SE_InvalidOperandTypes, cur.node); rv = generate_error(); }
                 retn(); goto next;
             }
             case LS_OP_AND_1: {
@@ -1077,6 +1092,7 @@ struct Lowerer {
             case LS_OP_AND_2: {
                 uint32_t then_var = rv;
                 if (!T().types_match(vtype(then_var), TP_Bool)) {       // Q15: returns with bb_index left in the RHS block, no Branch
+                    einfo(OPUSFE_NONE, 0, vtype(then_var));
                     report_node(SE_InvalidOperandType, N(nd.first_child).next);
                     rv = generate_error(); retn(); goto next;
                 }
@@ -1123,7 +1139,7 @@ struct Lowerer {
                 uint32_t typ = resolve_type(N(nd.first_child).next, undefined_flag);
                 int ct = T().can_cast(old_type, typ);
                 if (ct >= 0) { uint32_t nv = new_var(typ, true); push(ins(I_Cast, nv, v, 0, 0, 0, (uint16_t)ct)); rv = nv; }
-                else { report_node(SE_InvalidCast, cur.node); rv = generate_error(); }
+                else { einfo(OPUSFE_NONE, 0, old_type, typ); report_node(SE_InvalidCast, cur.node); rv = generate_error(); }
                 retn(); goto next;
             }
             case LS_NEG_1: {   // :749-789
@@ -1145,7 +1161,7 @@ struct Lowerer {
                         rv = li.dst;
                     } else { unsupported(); rv = generate_error(); }   // reference: unreachable!()
                 } else if (k == TY_Error) rv = generate_error();
-                else { report_node(SE_InvalidOperandType, cur.node); rv = generate_error(); }
+                else { einfo(OPUSFE_NONE, 0, st); report_node(SE_InvalidOperandType, cur.node); rv = generate_error(); }
                 retn(); goto next;
             }
 
@@ -1156,7 +1172,7 @@ struct Lowerer {
                     case E_Variable: p_variable(cnode, cur.aux, cur.f); retn(); goto next;
                     case E_VariableDefinition: {
                         uint32_t var;
-                        if (contains_local(nd.payload)) { report_node(SE_ShadowedName, cur.node); var = generate_error(); }
+                        if (contains_local(nd.payload)) { einfo(nd.payload, 0, OPUSFE_NONE); report_node(SE_ShadowedName, cur.node); var = generate_error(); }
                         else {
                             uint32_t typ = resolve_type(nd.first_child, undefined_flag);
                             uint32_t v = new_var(type_mut(typ), false);
@@ -1239,7 +1255,7 @@ struct Lowerer {
                     uint32_t n = 0; for (uint32_t c = cur.c; c != OPUSFE_NONE; c = N(c).next) n++;
                     cur.b = (IDX_FN << 1);
                     cur.d = reserve_cargs(n);
-                } else { report(SE_InvalidOperandType, isl, ish); p_finish(generate_error(), true); goto next; }
+                } else { einfo(OPUSFE_NONE, 0, indexee_type); report(SE_InvalidOperandType, isl, ish); p_finish(generate_error(), true); goto next; }
                 cur.e = 0;
                 cur.st = LS_P_IDX_LOOP;
                 goto next;
@@ -1264,7 +1280,7 @@ struct Lowerer {
                     uint32_t result_type;
                     if (r.ptr == PT_Array) result_type = type_pointer(PT_Array, r.sub);
                     else if (r.ptr == PT_ArrayMutable) result_type = type_pointer(PT_ArrayMutable, r.sub);
-                    else { report(SE_InvalidOperandType, isl, ish); p_finish(generate_error(), true); goto next; }
+                    else { einfo(OPUSFE_NONE, 0, vtype(cur.a)); report(SE_InvalidOperandType, isl, ish); p_finish(generate_error(), true); goto next; }
                     uint32_t v = new_var(result_type, true);
                     push(ins(I_IndexPointer, v, cur.a, cur.d));
                     p_finish(try_cast_pointer(v, pt, isl, ish), true); goto next;
@@ -1361,7 +1377,7 @@ __global__ MACHINE_ATTR(OPUSFE_LOWER_WAVES) __launch_bounds__(64) void k_lower_f
     L.lname = B.lname + lb; L.lvar = B.lvar + lb; L.nlocals = 0; L.lcap = (uint32_t)lower_cap(CAP_LOCALS, nn);
     L.lstack = B.lstack + lb; L.nstack = 0;
     L.frames = B.frames + lower_base(CAP_FRAMES, sb_n, sb_f); L.sp = 0; L.fcap = (uint32_t)lower_cap(CAP_FRAMES, nn);
-    L.errs = B.errs + lower_base(CAP_ERRS, sb_n, sb_f); L.nerrs = 0; L.ecap = (uint32_t)lower_cap(CAP_ERRS, nn);
+    L.errs = B.errs + lower_base(CAP_ERRS, sb_n, sb_f); L.nerrs = 0; L.ecap = (uint32_t)lower_cap(CAP_ERRS, nn); L.einfo_clear();
     L.bb_index = 0; L.break_head = OPUSFE_NONE; L.loop_begin = OPUSFE_NONE; L.dev_status = DS_OK;
     L.rv = 0; L.rl = false; L.rdiv = false; L.sym_locals = false;
     for (uint32_t j = lane; j < (LDS_VARS + 31) / 32; j += UNIT_LANES) L.lds.vnamed[j] = 0;
@@ -1437,7 +1453,7 @@ __global__ __launch_bounds__(256) void k_ir_compact(const FuncIr* __restrict__ f
         const uint32_t* sc = B.cargs + lower_base(CAP_CARGS, sb_n, sb_f);
         for (uint32_t j = lane; j < r.n_cargs; j += 64) O.cargs[r.carg_base + j] = sc[j];
         const SemErr* se = B.errs + lower_base(CAP_ERRS, sb_n, sb_f);
-        for (uint32_t j = lane; j < r.n_errs; j += 64) O.errs[r.err_base + j] = se[j];
+        for (uint32_t j = lane; j < r.n_errs; j += 64) { SemErr e = se[j]; for (int q = 0; q < 4; q++) if (e.t[q] != OPUSFE_NONE) e.t[q] = REMAP_TYPE(e.t[q]); O.errs[r.err_base + j] = e; }
         const uint64_t ib = lower_base(CAP_INSTRS, sb_n, sb_f);
         for (uint32_t j = lane; j < r.n_instrs; j += 64) {
             opusfe_instr in = B.instrs[ib + j];
@@ -1624,6 +1640,10 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
         R->n_errs = R->n_sem_errors;
         R->d_errs = dev_alloc_t<SemErr>(ctx, R->n_errs);
         LAUNCH(ctx, "sem_fin_emit", k_sem_fin_emit, grid_for(n_defs, 256), 256, u->d_nodes, u->d_def_nodes, n_defs, R->d_tid_of_node, undefined_flag, ph_def, ph_prev, n_nodes, gtypes, fin_cnt, R->d_errs);
+        // the types the diagnostics name (InvalidType prints one, compile.rs:844-847) stay readable: OPUSFE_A_TYPES = the global records
+        R->d_types = dev_alloc_t<TypeRec>(ctx, n_gtypes);
+        HIP_TRY(hipMemcpyAsync(R->d_types, gtypes, (size_t)n_gtypes * sizeof(TypeRec), hipMemcpyDeviceToDevice, st));
+        R->n_types = n_gtypes; R->n_gtypes = n_gtypes;
         HIP_TRY(hipStreamSynchronize(st));
         prof_collect(ctx);
         u->status = OPUSFE_SEMANTIC;

@@ -565,7 +565,15 @@ __global__ void k_sem_pp_types(TypeRec* __restrict__ pp) {
     pp[i] = r;
 }
 
-struct SemErr { uint32_t kind, low, len; };
+// kind, span, and what the message prints besides the span (compile.rs:816-915): `name` = a token index (variable / field /
+// function name; an operator token for `operator +` definitions) or 0x80000000 | token kind of a builtin symbol, or NONE;
+// `nargs` argument types of a function identifier (t[0..3]: the first four); t[0], t[1] = the one or two types of the typed kinds
+// (expected/found, from/to, left/right); type ids index OPUSFE_A_TYPES
+struct SemErr { uint32_t kind, low, len, name, nargs, t[4]; };
+__host__ __device__ inline SemErr sem_err(uint32_t kind, uint32_t low, uint32_t len, uint32_t name = OPUSFE_NONE, uint32_t nargs = 0, uint32_t t0 = OPUSFE_NONE,
+                                          uint32_t t1 = OPUSFE_NONE, uint32_t t2 = OPUSFE_NONE, uint32_t t3 = OPUSFE_NONE) {
+    SemErr e; e.kind = kind; e.low = low; e.len = len; e.name = name; e.nargs = nargs; e.t[0] = t0; e.t[1] = t1; e.t[2] = t2; e.t[3] = t3; return e;
+}
 // compile.rs:124-152 order
 enum SErrKind : uint32_t { SE_ParseError, SE_UndefinedVariable, SE_ShadowedName, SE_UndefinedFunction, SE_NoOverloadForFunction, SE_AmbiguousOverload,
     SE_AmbiguousFunctionReference, SE_UnexpectedType, SE_InvalidType, SE_InvalidOperandType, SE_InvalidOperandTypes, SE_FunctionMightNotReturn,
@@ -609,7 +617,7 @@ __device__ __forceinline__ uint32_t sem_finalize_errors(const opusfe_node* __res
     uint32_t nerr = 0;
     auto undefined_in = [&](uint32_t lo, uint32_t hi) {
         for (uint32_t y = lo; y < hi; y++)
-            if (undefined_flag[y]) { if (out) out[nerr] = SemErr{SE_UndefinedType, nodes[y].low, nodes[y].high - nodes[y].low}; nerr++; }
+            if (undefined_flag[y]) { if (out) out[nerr] = sem_err(SE_UndefinedType, nodes[y].low, nodes[y].high - nodes[y].low); nerr++; }
     };
     switch (n.kind) {
         case D_Function: case D_Extern: {
@@ -628,7 +636,7 @@ __device__ __forceinline__ uint32_t sem_finalize_errors(const opusfe_node* __res
                 uint32_t kind = OPUSFE_NONE;
                 if (!is_int) kind = SE_InvalidConstantExpression;
                 else if (!kind_is_integral(sem_contents_at(nodes, tid_of_node, types, ph_def, ph_prev, tid_of_node[ty], dn, n_defs).kind)) kind = SE_InvalidType;
-                if (kind != OPUSFE_NONE) { if (out) out[nerr] = SemErr{kind, v.low, v.high - v.low}; nerr++; }
+                if (kind != OPUSFE_NONE) { if (out) out[nerr] = sem_err(kind, v.low, v.high - v.low, OPUSFE_NONE, 0, kind == SE_InvalidType ? tid_of_node[ty] : OPUSFE_NONE); nerr++; }
             }
             break;
         }

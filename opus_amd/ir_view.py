@@ -28,7 +28,7 @@ DTYPES = {
                                                "error_base", "status", "_pad")]),
     A_VARIABLES: np.dtype([("type_id", u32), ("is_temporary", u32)]),
     A_INSTRS: np.dtype([("opcode", u16), ("sub", u16), ("dst", u32), ("a", u32), ("b", u32), ("c", u32), ("extra", u32)]),
-    A_SEM_ERRORS: np.dtype([("kind", u32), ("low", u32), ("len", u32)]),
+    A_SEM_ERRORS: np.dtype([("kind", u32), ("low", u32), ("len", u32), ("name", u32), ("nargs", u32), ("t", u32, (4,))]),
 }
 NONE = 0xFFFFFFFF
 

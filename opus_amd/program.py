@@ -58,9 +58,10 @@ class Program:
                 with open(path, "rb") as f:
                     return f.read()
         out = []
-        for e in self.unit.array(V.A_SEM_ERRORS):
+        view = self.unit.ir_view()
+        for e in view.sem_errors:
             i, off = self.locate(int(e["low"]))
-            out.append(R.render_semantic(int(e["kind"]), self.filenames[i], read(self.source_files[i]), off, int(e["len"])))
+            out.append(R.render_semantic_record(e, view, self.filenames[i], read(self.source_files[i]), off))
         return "".join(out)
 
 

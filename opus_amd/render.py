@@ -2,9 +2,11 @@
 
 Restates, byte for byte, ``frontend::print_span`` (frontend.rs:201-256) and the message lines of ``Compiler::print_error``
 (compile.rs:782-917) for (a) all seven ``parse::Error`` kinds, rendered from ``opusfe_error`` + the token arrays, and (b) the
-semantic error kinds whose message needs nothing beyond the span (text of the span, or no argument at all).  The kinds that
-print types or function identifiers (UnexpectedType, NoOverloadForFunction, ...) are NOT rendered yet: the diagnostic records
-carry (kind, low, len) only — ``semantic_message`` returns None for them and ``render_semantic`` falls back to the kind name.
+semantic error kinds.  Those whose message needs nothing beyond the span are rendered from (kind, low, len) alone
+(``semantic_message``); those that print types, names or function identifiers (UnexpectedType, NoOverloadForFunction, ...,
+compile.rs:820-899 with TypePrinter / FunctionIdentifierPrinter, compile.rs:200-320) from the payload of the diagnostic record
+(``opusfe_semantic_error``: name, nargs, t[4]) and the unit's type arrays (``semantic_message_of_record``).  A function
+identifier with more than four argument types is not rendered (the record carries four).
 PARITY UNPINNED: the reference ships no expected outputs; tests/test_render.py holds strings derived by hand from the cited
 lines.  Pure host formatting: nothing here runs or replaces the GPU path.
 """
@@ -137,6 +139,60 @@ def semantic_message(kind: int, span_text: str):
     if m is None:
         return None
     return m(span_text) if callable(m) else m
+
+
+def _record_name(rec, view) -> str:
+    """text of the record's `name`: an identifier, or Operator::symbol (parse.rs:224-243) of an operator token / builtin symbol"""
+    name = int(rec["name"])
+    if name & 0x80000000:
+        kind = name & 0xFF
+        return "=" if kind == 8 else TOKEN_TEXT[kind]
+    return view.token_name(name)
+
+
+def semantic_message_of_record(rec, view):
+    """message line of compile.rs:816-915 for one opusfe_semantic_error record; `view` = Unit.ir_view() (types, tokens, source).
+    None when the record does not carry enough (a function identifier with more than four argument types)."""
+    kind, low, length = int(rec["kind"]), int(rec["low"]), int(rec["len"])
+    plain = semantic_message(kind, view.source[low:low + length].decode("utf-8", errors="replace"))
+    if plain is not None:
+        return plain
+    ty = lambda k: view.type_text(int(rec["t"][k]))
+    if kind == 2:                                                    # ShadowedName :820
+        return f"shadowed variable: {_record_name(rec, view)}"
+    if kind in (3, 4, 5):                                            # UndefinedFunction / NoOverloadForFunction / AmbiguousOverload :824-835
+        n = int(rec["nargs"])
+        if n > 4:
+            return None
+        ident = f"{_record_name(rec, view)}[" + " ".join(":" + ty(k) for k in range(n)) + "]"      # FunctionIdentifierPrinter, compile.rs:302-319
+        return ("undefined function: ", "no matching overload for function: ", "call to overloaded function is ambiguous: ")[kind - 3] + ident
+    if kind == 7:                                                    # UnexpectedType :840
+        return f"invalid type: expected {ty(0)}, found {ty(1)}"
+    if kind == 8:                                                    # InvalidType :844
+        return f"invalid type: {ty(0)}"
+    if kind == 9:                                                    # InvalidOperandType :848
+        return f"invalid operand type: {ty(0)}"
+    if kind == 10:                                                   # InvalidOperandTypes :852
+        return f"invalid operand types: {ty(0)} {_record_name(rec, view)} {ty(1)}"
+    if kind == 17:                                                   # InvalidCast :880
+        return f"invalid cast: {ty(0)} to {ty(1)}"
+    if kind == 19:                                                   # FieldAccessOnNonRecord :888
+        return f"attempt to set or access field of non-record: {ty(0)}"
+    if kind == 20:                                                   # FieldDoesNotExist :892
+        return f"type {ty(0)} has no field named '{_record_name(rec, view)}'"
+    if kind == 21:                                                   # CallOfNonFunction :896
+        return f"cannot call value of type {ty(0)}"
+    return None
+
+
+def render_semantic_record(rec, view, filename: str, source: bytes = None, low: int = None) -> str:
+    """stderr text of one diagnostic record: message + print_span.  `source` / `low` override the unit's own source and position
+    (a multi-file program renders the span inside the file it belongs to)."""
+    msg = semantic_message_of_record(rec, view)
+    if msg is None:
+        msg = f"<{SEMANTIC_NAMES[int(rec['kind'])]}>"
+    src = view.source if source is None else source
+    return f"{RED}Error:{RESET} {msg}\n" + print_span(filename, src, int(rec["low"]) if low is None else low, int(rec["len"]))
 
 
 def render_semantic(kind: int, filename: str, source: bytes, low: int, length: int) -> str:

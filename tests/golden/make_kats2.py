@@ -18,13 +18,15 @@ K = []
 
 
 def kat(name, cites, src, ir, errors=(), ast_contains=None):
-    errs = []
-    for kind, text, nth in errors:
+    errs, msgs = [], []
+    for kind, text, nth, *message in errors:
         pos = -1
         for _ in range(nth + 1):
             pos = src.index(text, pos + 1)
         errs.append(f"{kind} {pos} {len(text)}")
-    K.append({"name": name, "cites": cites, "src": src, "ir": ir.lstrip("\n"), "errors": errs, "ast_contains": ast_contains})
+        msgs.append(message[0] if message else None)
+    # "messages": the message line of compile.rs:816-915 for each error, hand-derived like the rest (None = not derived)
+    K.append({"name": name, "cites": cites, "src": src, "ir": ir.lstrip("\n"), "errors": errs, "messages": msgs, "ast_contains": ast_contains})
 
 
 FOR_EXTERNS = "extern operator for(n int32) int32\nextern operator continue(it @mut int32, x @mut int32) bool\n"
@@ -134,7 +136,7 @@ VAR %8: null
 @5
   %8 = null
   return %8
-""", errors=[("UndefinedFunction", "1", 0), ("UndefinedFunction", "1", 0)])
+""", errors=[("UndefinedFunction", "1", 0, "undefined function: for[:int32]"), ("UndefinedFunction", "1", 0, "undefined function: continue[:@mut <error> :@mut int32]")])
 
 kat("record_literal", "generate_ir.rs:1064-1078 (no autocast of field values), 1090-1101, 1103-1128; compile.rs:204-207 (alias name printed)",
     "type P = record { x int32 y nat8 }\nmk() P\n\treturn record P { x = 1 y = 2 }\n", """
@@ -171,7 +173,7 @@ VAR %3: P
   in %2 store %1
   %3 = load %0
   return %3
-""", errors=[("FieldDoesNotExist", "1", 0)])
+""", errors=[("FieldDoesNotExist", "1", 0, "type P has no field named 'z'")])
 
 kat("record_literal_of_non_record", "generate_ir.rs:1144-1147", "f() int32\n\treturn record int32 { x = 1 }\n", """
 f[]: int32
@@ -186,7 +188,7 @@ VAR %3: int32
   in %2 store %1
   %3 = load %0
   return %3
-""", errors=[("FieldAccessOnNonRecord", "1", 0)])
+""", errors=[("FieldAccessOnNonRecord", "1", 0, "attempt to set or access field of non-record: int32")])
 
 kat("string_length", "generate_ir.rs:1129-1143 (builtin field 1 = length: size)", "len(s string) size\n\treturn s.length\n", """
 len[:string]: size
@@ -302,7 +304,7 @@ VAR %7: null
   in %4 store %6
   %7 = null
   return %7
-""", errors=[("ImmutableLvalue", "p", 1)])
+""", errors=[("ImmutableLvalue", "p", 1, "lvalue is immutable")])
 
 kat("casts_integer_and_pointer", "generate_ir.rs:720-732; compile.rs:682-696 (Integer, PointerToInteger, IntegerToPointer)",
     "c(x int32, p @int32) nat64\n\tvar a = x:nat8\n\tvar b = p:size\n\tvar q = b:@nat8\n\treturn x:nat64\n", """
@@ -400,7 +402,7 @@ VAR %5: int32
   %4 = error
   %5 = cast Error [<error> to int32] %4
   return %5
-""", errors=[("InvalidCast", "b:int32", 0)])
+""", errors=[("InvalidCast", "b:int32", 0, "invalid cast: bool to int32")])
 
 kat("negate_typed_literal_is_not_folded", "generate_ir.rs:749-765 (the literal takes the expected type int8 first, so Negate is emitted)",
     "n() int8\n\treturn -5\n", """
@@ -442,7 +444,7 @@ VAR %5: nat32
   %4 = error
   %5 = cast Error [<error> to nat32] %4
   return %5
-""", errors=[("InvalidOperandType", "-x", 0)])
+""", errors=[("InvalidOperandType", "-x", 0, "invalid operand type: nat32")])
 
 kat("is_on_references", "generate_ir.rs:616-628", "same(a @int32, b @int32) bool\n\treturn a is b\n", """
 same[:@int32 :@int32]: bool
@@ -486,7 +488,7 @@ VAR %6: bool
   %5 = error
   %6 = cast Error [<error> to bool] %5
   return %6
-""", errors=[("InvalidOperandTypes", "a is 1", 0)])
+""", errors=[("InvalidOperandTypes", "a is 1", 0, "invalid operand types: int32 is int32")])
 
 kat("is_on_different_pointer_kinds", "generate_ir.rs:624 (pointer kinds must be equal, no autocast)", "d(a @mut int32, b @int32) bool\n\treturn a is b\n", """
 d[:@mut int32 :@int32]: bool
@@ -512,7 +514,7 @@ VAR %9: bool
   %8 = error
   %9 = cast Error [<error> to bool] %8
   return %9
-""", errors=[("InvalidOperandTypes", "a is b", 0)])
+""", errors=[("InvalidOperandTypes", "a is b", 0, "invalid operand types: @mut int32 is @int32")])
 
 kat("q9_equals_not", "parse.rs:1027-1038, 837-869 (`a == not b` rotates to Not(Equals(a, Null), b)); generate_ir.rs:694-718 (only the right operand is evaluated)",
     "q(a bool, b bool) bool\n\treturn a == not b\n", """
@@ -586,7 +588,7 @@ VAR %6: bool
   %5 = error
   %6 = cast Error [<error> to bool] %5
   return %6
-""", errors=[("InvalidOperandType", "1", 0)])
+""", errors=[("InvalidOperandType", "1", 0, "invalid operand type: int32")])
 
 kat("or_phi", "generate_ir.rs:635-669 (`or` branches to merge on true; Phi from the branching block and the end of the RHS)",
     "o(a bool, b bool) bool\n\treturn a or b\n", """
@@ -664,7 +666,7 @@ VAR %7: int32
   %6 = load %5
   %7 = cast Error [<error> to int32] %6
   return %7
-""", errors=[("UndefinedVariable", "x", 2)])
+""", errors=[("UndefinedVariable", "x", 2, "undefined variable: x")])
 
 kat("shadowed_local", "generate_ir.rs:255-257 (the value is generated, nothing is allocated; span = the statement)", "v() null\n\tvar a = 1\n\tvar a = 2\n", """
 v[]: null
@@ -679,7 +681,7 @@ VAR %3: null
   %2 = 2
   %3 = null
   return %3
-""", errors=[("ShadowedName", "var a = 2", 0)])
+""", errors=[("ShadowedName", "var a = 2", 0, "shadowed variable: a")])
 
 kat("ambiguous_overload", "compile.rs:1104-1134 (a GenericInteger argument that no int32 overload takes)",
     "extern g(a int8) null\nextern g(a int16) null\namb() null\n\tg(1)\n", """
@@ -692,7 +694,7 @@ VAR %2: null
   %1 = error
   %2 = null
   return %2
-""", errors=[("AmbiguousOverload", "g(1)", 0)])
+""", errors=[("AmbiguousOverload", "g(1)", 0, "call to overloaded function is ambiguous: g[:<integer>]")])
 
 kat("overload_defaults_to_int32", "compile.rs:1120-1131 (types_match_default_generic), generate_ir.rs:1166-1176, 214-218",
     "extern g(a int8) null\nextern g(a int32) null\npick() null\n\tg(1)\n", """
@@ -742,7 +744,7 @@ VAR %2: null
   %1 = error
   %2 = null
   return %2
-""", errors=[("NoOverloadForFunction", "h(true)", 0)])
+""", errors=[("NoOverloadForFunction", "h(true)", 0, "no matching overload for function: h[:bool]")])
 
 kat("index_with_two_arguments", "generate_ir.rs:910-914 (all arguments evaluated, InvalidNumberOfArgs, the LAST one indexes)",
     "ix(p {} int32) int32\n\treturn p(1, 2)\n", """
@@ -767,7 +769,7 @@ VAR %8: int32
   %7 = cast PointerType [{} int32 to @int32] %6
   %8 = load %7
   return %8
-""", errors=[("InvalidNumberOfArgs", "p(1, 2)", 0)])
+""", errors=[("InvalidNumberOfArgs", "p(1, 2)", 0, "invalid number of indices")])
 
 kat("call_through_local_function_pointer", "generate_ir.rs:871-887 (function name as a value), 1042-1046, 948-960 (arguments with no expected type, no autocast)",
     "extern g(a int32) int32\ncall() int32\n\tvar fp = g\n\treturn fp(2)\n", """
@@ -823,7 +825,7 @@ VAR %2: null
   %1 = load %0
   %2 = null
   return %2
-""", errors=[("AttemptToCallOrIndexConstant", "kc(1)", 0)])
+""", errors=[("AttemptToCallOrIndexConstant", "kc(1)", 0, "attempt to call or index constant")])
 
 kat("function_might_not_return", "generate_ir.rs:157-171 (span = the signature, parse.rs:1324-1325), 310-311 (jump after return)",
     "fm(a bool) int32\n\tif a\n\t\treturn 1\n", """
@@ -846,7 +848,7 @@ VAR %4: int32
 @2
   jump @3
 @3
-""", errors=[("FunctionMightNotReturn", "fm(a bool) int32", 0)])
+""", errors=[("FunctionMightNotReturn", "fm(a bool) int32", 0, "function might not return")])
 
 kat("infinite_loop_diverges", "generate_ir.rs:321, 345 (while true without break diverges), 481-485, 165-166 (unreachable)",
     "lp() int32\n\twhile true\n\t\tcontinue\n", """
@@ -884,7 +886,7 @@ VAR %4: null
   in %3 store %2
   %4 = null
   return %4
-""", errors=[("ReferenceToBuiltinFunction", "proc operator +(int32, int32)", 0)])
+""", errors=[("ReferenceToBuiltinFunction", "proc operator +(int32, int32)", 0, "refernce to built-in function")])
 
 kat("sizeof_alignof", "generate_ir.rs:790-801, 1227-1228", "type P = record { x int32 }\nsz() size\n\treturn sizeof P + alignof @P\n", """
 sz[]: size
@@ -991,7 +993,7 @@ VAR %3: null
   in %2 store %1
   %3 = null
   return %3
-""", errors=[("InvalidLvalue", "5", 0)])
+""", errors=[("InvalidLvalue", "5", 0, "invalid lvalue")])
 
 kat("break_and_continue_outside_loop", "generate_ir.rs:477-479, 486-488", "bo() null\n\tbreak\n\tcontinue\n", """
 bo[]: null
@@ -999,7 +1001,7 @@ VAR %0: null
 @0
   %0 = null
   return %0
-""", errors=[("BreakOutsideLoop", "break", 0), ("ContinueOutsideLoop", "continue", 0)])
+""", errors=[("BreakOutsideLoop", "break", 0, "break outside loop"), ("ContinueOutsideLoop", "continue", 0, "continue outside loop")])
 
 kat("while_else_break", "generate_ir.rs:315-362 (break jumps to merge, past the else block)",
     "we(a bool) int32\n\twhile a\n\t\tbreak\n\telse\n\t\treturn 1\n\treturn 2\n", """
@@ -1070,7 +1072,7 @@ VAR %5: null
   %4 = load %3
   %5 = null
   return %5
-""", errors=[("FieldAccessOnNonRecord", "a.x", 0)])
+""", errors=[("FieldAccessOnNonRecord", "a.x", 0, "attempt to set or access field of non-record: int32")])
 
 kat("autocast_pointer_to_array", "compile.rs:656-667 (@mut {N} T -> mut {} T is PointerToArray), generate_ir.rs:219-223",
     "extern fill(p {} mut int32) null\npa() null\n\tvar a {4} int32\n\tfill(mut a)\n", """
@@ -1101,7 +1103,27 @@ VAR %1: <error>
   %0 = true
   %1 = error
   return %1
-""", errors=[("UnexpectedType", "true", 0)])
+""", errors=[("UnexpectedType", "true", 0, "invalid type: expected int32, found bool")])
+
+kat("call_of_local_that_shadows_a_function", "generate_ir.rs:1152-1165 (a local with the callee's name: Load, then CallOfNonFunction), 1031-1041 (arguments first)",
+    "extern g(a int32) int32\nf() null\n\tvar g = 1\n\tg(2)\n", """
+f[]: null
+VAR %0: int32
+VAR %1: @mut int32
+VAR %2: <integer>
+VAR %3: int32
+VAR %4: <error>
+VAR %5: null
+@0
+  %0 = 1
+  %1 = alloc
+  in %1 store %0
+  %2 = 2
+  %3 = load %1
+  %4 = error
+  %5 = null
+  return %5
+""", errors=[("CallOfNonFunction", "g(2)", 0, "cannot call value of type int32")])
 
 
 def main():

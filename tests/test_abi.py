@@ -31,7 +31,7 @@ def test_record_sizes_match_the_header():
     from opus_amd import ir_view as V
     import numpy as np
     sizes = {V.A_TOKENS: 16, V.A_NODES: 24, V.A_INSTRS: 24, V.A_VARIABLES: 8, V.A_TYPES: 16, V.A_SIGNATURES: 24, V.A_GLOBALS: 16,
-             V.A_FUNCTIONS: 64, V.A_SEM_ERRORS: 12, V.A_VAL64: 8, V.A_DEFINITIONS: 4}
+             V.A_FUNCTIONS: 64, V.A_SEM_ERRORS: 36, V.A_VAL64: 8, V.A_DEFINITIONS: 4}
     for which, size in sizes.items():
         assert np.dtype(V.DTYPES[which]).itemsize == size, which
     assert len(V.DTYPES) == 17

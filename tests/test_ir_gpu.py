@@ -71,6 +71,27 @@ def test_kats2_gpu_against_the_hand_derived_text(fe, case):
     assert u._dump(4).splitlines() == case["errors"]
     par, seq = u.lowering_stats()
     assert par + seq == 1
+    # the message line of every diagnostic (compile.rs:816-915), rendered from the record's payload and the type arrays
+    from opus_amd import render as R
+    view = u.ir_view()
+    assert len(view.sem_errors) == len(case["messages"])
+    for rec, want in zip(view.sem_errors, case["messages"]):
+        if want is not None:
+            assert R.semantic_message_of_record(rec, view) == want
+
+
+def test_finalize_time_invalid_type_is_rendered_with_its_type(fe):
+    """compile.rs:1031-1034, 844-847: a global whose initialiser does not fit its type; no IR (frontend.rs:145), but the record
+    names the type and OPUSFE_A_TYPES stays readable (hand-derived message, unpinned like all rendering)"""
+    from opus_amd import render as R
+    src = b"type T = record { x int32 }\nvar a bool = 5\nvar b @T = -1\nf() null\n\tnosuch()\n"
+    u = fe.get_definitions(src)
+    assert u.compile_source() == 7
+    view = u.ir_view()
+    got = [R.semantic_message_of_record(rec, view) for rec in view.sem_errors]
+    assert got == ["invalid type: bool", "invalid type: @T"]
+    text = R.render_semantic_record(view.sem_errors[1], view, "g.opus")
+    assert text.startswith("\x1b[31;1mError:\x1b[0m invalid type: @T\n") and "var b @T = " in text
 
 
 @pytest.mark.parametrize("src", IR_CASES, ids=[f"ir{i}" for i in range(len(IR_CASES))])

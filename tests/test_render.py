@@ -34,7 +34,7 @@ def test_semantic_messages_without_payload():
     assert R.semantic_message(1, "nosuch") == "undefined variable: nosuch"
     assert R.semantic_message(18, "T") == "undefined type: T"
     assert R.semantic_message(22, "") == "refernce to built-in function"      # the reference's spelling, compile.rs:901
-    assert R.semantic_message(7, "x") is None                                   # UnexpectedType prints types: not rendered yet
+    assert R.semantic_message(7, "x") is None                                   # UnexpectedType prints types: needs the record (semantic_message_of_record)
     src = b"f() int32\n\treturn nosuch\n"
     assert R.render_semantic(1, "m.opus", src, 18, 6) == (f"{RED}Error:{Z} undefined variable: nosuch\n{Y}m.opus:{Z}\n"
                                                           f"{Y}   2:{Z}     return {RED}nosuch{Z}\n")
