@@ -163,6 +163,7 @@ def main():
         own = res["own_counts"]
         for k in ("source_bytes", "tokens", "nodes"):
             c[k] = own[k]                  # tokens / nodes of the bytes this rank owns (the unit also holds the other ranks' headers)
+        c["definitions_own"] = own["definitions"]
         res["unit"].close()
         return c
 
@@ -229,6 +230,12 @@ def main():
     if dist is not None and workload == "c5":
         from opus_amd import sharding as _sh6
         total_bytes_all = int(_sh6.all_reduce_sum(nbytes, dist))
+    sharded_totals = None
+    if dist is not None and workload == "c4":
+        # what the ranks produced together: comparable with the same logical source lexed / parsed / lowered as ONE unit
+        # (tests/test_shard_gpu.py::test_two_process_gloo_run_matches_the_whole_source)
+        from opus_amd import sharding as _sh7
+        sharded_totals = {k: int(_sh7.all_reduce_sum(counts[k], dist)) for k in ("source_bytes", "tokens", "nodes", "definitions_own", "instrs", "vars")}
     if dist is not None:
         from opus_amd import sharding as _sh
         dt = _sh.all_reduce_max(dt, dist)
@@ -350,7 +357,7 @@ def main():
                           "files": counts.get("files"), "files_with_syntax_error": counts.get("files_with_syntax_error")},
                "hbm_gbs_whole_path": round(world * total_alg / (dt / args.steps) / 1e9, 2),
                "hbm_frac_whole_path": round(total_alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 5),
-               "hbm_held_bytes": held, "lowering_functions": lowering or None,
+               "hbm_held_bytes": held, "lowering_functions": lowering or None, "sharded_totals": sharded_totals,
                "roofline": roofline, "cpu_baseline": cpu, "parity_check": parity if cpu is not None else None,
                "kernels": [{"name": n, "ms_per_step": round(ms / args.steps, 4), "launches_per_step": l / args.steps} for n, ms, l in kstats[:24]],
                "gen_seconds": round(gen_s, 1)}

@@ -144,3 +144,31 @@ def test_shard_with_a_swallowed_lexical_error_is_refused(fe):
     assert st in (1, 2)
     if st == 1:      # a syntax error reported before the trap wins, exactly as on one GPU
         assert O.dump(src, O.ERROR) != "Ok\n"
+
+
+def test_two_process_gloo_run_matches_the_whole_source(fe, tmp_path):
+    """The real thing in two processes: `bench.py --gpus 2` under torch.distributed (gloo, both ranks on this one GPU) runs plan()
+    and compile_sharded() with real gathers between processes; what the two ranks produced together must be what the same
+    logical source gives as ONE unit."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    nbytes, nblk = 8_000_000, 16
+    blk = nbytes // nblk
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29571",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--bytes", str(nbytes), "--steps", "1", "--warmup", "0", "--no-cpu"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["sharded_totals"] is not None
+    tot = d["sharded_totals"]
+    whole = O.generate_range(3, 0, 2 * nblk, blk, flags=1)
+    assert tot["source_bytes"] == len(whole) == 2 * blk * nblk
+    u = fe.get_definitions(whole)
+    assert u.compile_source() == 0
+    c = u.counts()
+    assert tot["tokens"] == c["tokens"] + 1            # every rank's unit ends with an EndOfFile token of its own
+    assert (tot["nodes"], tot["definitions_own"], tot["instrs"], tot["vars"]) == (c["nodes"], c["definitions"], c["instrs"], c["vars"])
