@@ -151,7 +151,14 @@ def main():
     gather = None
     if workload == "c4" and world > 1:
         from opus_amd import shard, sharding
-        gather = sharding.make_gather(dist, torch.device("cuda", local_rank))
+        raw_gather = sharding.make_gather(dist, torch.device("cuda", local_rank))
+        shard_times = {"comm_s": 0.0, "header_reparse_s": 0.0, "header_bytes": 0}
+
+        def gather(name, values):          # (host time of the exchange steps, waiting for the slowest rank included)
+            t = time.perf_counter()
+            r = raw_gather(name, values)
+            shard_times["comm_s"] += time.perf_counter() - t
+            return r
 
     def step_c4():
         st = shard.RankState(ctx, d_src[:n_local], rank, world)
@@ -161,6 +168,8 @@ def main():
             raise SystemExit(f"rank {rank}: sharded hot path failed: status {res['status']} (first bad rank {res['first_bad_rank']}): {ctx.message()}")
         c = res["unit"].counts()
         own = res["own_counts"]
+        shard_times["header_reparse_s"] += res["header_reparse_s"]
+        shard_times["header_bytes"] = res["header_bytes"]
         for k in ("source_bytes", "tokens", "nodes"):
             c[k] = own[k]                  # tokens / nodes of the bytes this rank owns (the unit also holds the other ranks' headers)
         c["definitions_own"] = own["definitions"]
@@ -232,10 +241,17 @@ def main():
         total_bytes_all = int(_sh6.all_reduce_sum(nbytes, dist))
     sharded_totals = None
     if dist is not None and workload == "c4":
+        steps_run = max(1, args.steps + args.warmup)
+        counts["comm_ms_x1000"] = int(1e6 * shard_times["comm_s"] / steps_run)
+        counts["header_reparse_ms_x1000"] = int(1e6 * shard_times["header_reparse_s"] / steps_run)
         # what the ranks produced together: comparable with the same logical source lexed / parsed / lowered as ONE unit
         # (tests/test_shard_gpu.py::test_two_process_gloo_run_matches_the_whole_source)
         from opus_amd import sharding as _sh7
         sharded_totals = {k: int(_sh7.all_reduce_sum(counts[k], dist)) for k in ("source_bytes", "tokens", "nodes", "definitions_own", "instrs", "vars")}
+        # per step, mean over ranks: the carry / halo / header exchanges (host clock, waiting included) and the re-parse of the other ranks' headers
+        sharded_totals["comm_ms"] = round(_sh7.all_reduce_sum(counts["comm_ms_x1000"], dist) / 1000.0 / world, 3)
+        sharded_totals["header_reparse_ms"] = round(_sh7.all_reduce_sum(counts["header_reparse_ms_x1000"], dist) / 1000.0 / world, 3)
+        sharded_totals["header_bytes_rank0"] = shard_times["header_bytes"]
     if dist is not None:
         from opus_amd import sharding as _sh
         dt = _sh.all_reduce_max(dt, dist)

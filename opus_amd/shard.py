@@ -203,15 +203,18 @@ def compile_sharded(states, gather, lower=True):
         htext = torch.cat(before + after + [torch.zeros(64, dtype=torch.uint8, device=s.own.device)])
         n = htext.numel() - 64
         torch.cuda.synchronize()
+        import time
+        t0 = time.perf_counter()
         uh = s.ctx.get_definitions_device(htext.data_ptr(), n)
         s._hdr_text = htext
         rc = uh.status
         u2 = u
         if rc == F.OK:
             u2 = u.join(uh, split_pos)
-            if lower:
-                rc = u2.compile_source()
-        results.append(dict(status=rc, unit=u2, own_counts=own_counts, first_bad_rank=None))
+        hdr_s = time.perf_counter() - t0       # the price of lowering against whole-program tables: the others' headers, parsed and joined
+        if rc == F.OK and lower:
+            rc = u2.compile_source()
+        results.append(dict(status=rc, unit=u2, own_counts=own_counts, first_bad_rank=None, header_bytes=n, header_reparse_s=hdr_s))
         uh.close()
         if u2 is not u:
             u.close()

@@ -155,12 +155,12 @@ def test_two_process_gloo_run_matches_the_whole_source(fe, tmp_path):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    nbytes, nblk = 8_000_000, 16
+    nbytes, nblk = 16_000_000, 16         # (the generator needs blocks of at least 1 MB for the depth-1000 regions)
     blk = nbytes // nblk
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29571",
            os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--bytes", str(nbytes), "--steps", "1", "--warmup", "0", "--no-cpu"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
-    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.returncode == 0, "\n".join(l for l in out.stderr.splitlines() if "rank" in l)[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["sharded_totals"] is not None
