@@ -1760,9 +1760,20 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
                 uint32_t threads;
                 if (shape_env) threads = a.nmax <= 256 ? ts : a.nmax <= 1024 ? tm : tl;
                 else {
-                    const size_t blocks = std::max<size_t>(1, (160u << 10) / par::lds_bytes(a.nmax, a.maxdef, 256));
-                    const size_t want = (4 * OPUSFE_PAR_WAVES + blocks - 1) / blocks;      // waves per workgroup to fill the CU's wave slots
-                    threads = want <= 1 ? 64 : want <= 2 ? 128 : want <= 4 ? 256 : want <= 8 ? 512 : 1024;
+                    // any number of waves per workgroup: the one that keeps the most functions resident among those that fill the
+                    // CU's wave slots to within one wave (16 = 4 SIMDs x OPUSFE_PAR_WAVES; LDS is allocated in 1280-byte granules)
+                    uint32_t best_waves = 0;
+                    uint32_t resident[17] = {0};
+                    for (uint32_t w = 1; w <= 16; w++) {
+                        const size_t need = (par::lds_bytes(a.nmax, a.maxdef, 64 * w) + 256 + 1279) / 1280 * 1280;
+                        const uint32_t blocks = (uint32_t)std::min<size_t>((160u << 10) / need, (4 * OPUSFE_PAR_WAVES) / w);
+                        resident[w] = blocks * w;
+                        best_waves = std::max(best_waves, resident[w]);
+                    }
+                    uint32_t w = 1;
+                    static const uint32_t slack = getenv("OPUSFE_PAR_SLACK") ? (uint32_t)atoi(getenv("OPUSFE_PAR_SLACK")) : 1u;      // (diagnostics)
+                    while (w < 16 && resident[w] + slack < best_waves) w++;
+                    threads = 64 * w;
                 }
                 const size_t lds = par::lds_bytes(a.nmax, a.maxdef, threads);
                 prof_begin(ctx, NAMES[name_i < 0 ? 11 : name_i]);
