@@ -50,6 +50,18 @@ def fold_tail(prev_kinds, ntok, tail_kinds):
     return out
 
 
+_HIP = None
+
+
+def _hip():
+    """the HIP runtime, loaded once (the headers of a unit are copied device to device into a torch tensor)"""
+    global _HIP
+    if _HIP is None:
+        _HIP = C.cdll.LoadLibrary("libamdhip64.so")
+        _HIP.hipMemcpy.restype = C.c_int
+    return _HIP
+
+
 class LocalComm:
     """W simulated ranks in one process: all_gather returns the list the driver assembled."""
     def __init__(self, world):
@@ -190,7 +202,9 @@ def compile_sharded(states, gather, lower=True):
         p, n = u.headers_device()
         t = torch.empty(n, dtype=torch.uint8, device=s.own.device)
         if n:
-            C.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(C.c_void_p(t.data_ptr()), C.c_void_p(p), C.c_size_t(n), 3)   # device to device
+            rc = _hip().hipMemcpy(C.c_void_p(t.data_ptr()), C.c_void_p(p), C.c_size_t(n), 3)   # device to device
+            if rc != 0:
+                raise RuntimeError(f"hipMemcpy of the definition headers failed: hip error {rc}")
         hdrs.append(t)
     all_hdrs = gather("headers", hdrs)
     for s, u in zip(states, parsed):
