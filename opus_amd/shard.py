@@ -8,7 +8,7 @@ all-gathers; each rank then owns whole top-level segments, i.e. a standalone wel
   2. ctx        composed context-DFA transition function of the rank's bytes            (4 B / rank)   -> start state
   3. tails      number of raw tokens + kinds of the last 8 tokens                       (16 B / rank)  -> `record {` look-back
   4. depth      net change of the bracket counter                                       (8 B / rank)   -> absolute depth
-  5. cuts       first top-level segment start provable inside the shard                 (8 B / rank)   -> ownership
+  5. cuts       first top-level segment start provable inside the shard, and its length (16 B / rank)  -> ownership
   6. halo       the bytes before a rank's cut go to its left neighbour                  (bulk, one neighbour)
   7. headers    definition headers (functions as `extern` signatures, types, globals)   (bulk, variable) -> global tables for IR
 
@@ -160,8 +160,8 @@ def plan(states, gather):
             prev = fold_tail(prev, tails[q][0], tails[q][1])
         s.prev_kinds = prev
     nets = gather("depth", [s.net_depth(s.prev_kinds) for s in states])
-    cuts = gather("cuts", [s.cut(sum(nets[:s.rank])) for s in states])
-    lens = gather("lens", [s.n for s in states])
+    cl = gather("cuts", [(s.cut(sum(nets[:s.rank])), s.n) for s in states])      # (cut, length): one exchange
+    cuts, lens = [int(x[0]) for x in cl], [int(x[1]) for x in cl]
     prefixes = gather("prefixes", [s.prefix() for s in states])
     for s in states:
         right = []
