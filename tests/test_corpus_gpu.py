@@ -125,3 +125,35 @@ def test_config5_shape_at_scale(fe):
             assert hashlib.sha256(u.dump_ir().encode()).digest() == hashlib.sha256(O.dump(src, O.IR).encode()).digest()
         u.close()
     assert faulty >= 8
+
+
+def test_every_diagnostic_of_the_mutants_renders(fe):
+    """the payload of the diagnostic records (name, argument types, type ids) is usable for every error the mutants raise: the
+    type ids index OPUSFE_A_TYPES, the names are tokens of the unit, and render.py produces a message for each record"""
+    import mutate as M
+    from opus_amd import render as R
+    kinds = set()
+    n_rendered = n_records = 0
+    for src in M.mutants(250, seed0=61_000):
+        u = fe.get_definitions(src)
+        if u.status != 0:
+            continue
+        rc = u.compile_source()
+        if rc not in (0, 7):
+            continue
+        view = u.ir_view()
+        for rec in view.sem_errors:
+            n_records += 1
+            for t in rec["t"]:
+                assert int(t) == 0xFFFFFFFF or int(t) < len(view.types)
+            name = int(rec["name"])
+            assert name == 0xFFFFFFFF or (name & 0x80000000) or name < len(view.tokens)
+            msg = R.semantic_message_of_record(rec, view)
+            if msg is None:
+                assert int(rec["kind"]) in (3, 4, 5) and int(rec["nargs"]) > 4      # the one documented gap
+            else:
+                n_rendered += 1
+                kinds.add(int(rec["kind"]))
+                assert "\n" not in msg and "?" not in msg.split(":")[0]
+        u.close()
+    assert n_records > 50 and n_rendered >= 0.95 * n_records and len(kinds) >= 8
