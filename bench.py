@@ -232,7 +232,7 @@ def main():
     # the node-parallel lowering is ONE kernel (lower_par.h k_lower_par) launched once per size class with differently sized LDS:
     # priced as one kernel with that many launches per step
     par = [k for k in kstats if k[0].startswith("lower_par_")]
-    if par:
+    if par and not os.environ.get("OPUSFE_BENCH_RAW_KERNELS"):      # (diagnostics: keep the class launches apart)
         kstats = [k for k in kstats if not k[0].startswith("lower_par_")] + [("lower_par", sum(k[1] for k in par), sum(k[2] for k in par))]
     held = ctx.memory_held()
     total_bytes_all = nbytes
