@@ -906,7 +906,17 @@ template <bool EMIT> __device__ __forceinline__ bool visit(Fn& f, uint32_t i) {
             case E_Operator: {
                 const uint32_t l = f.fc[i], r = f.nx[l];
                 const uint8_t op = SUB(f, i);
-                if (op == OP_Is) { fallback(f); return true; }
+                if (op == OP_Is) {       // :616-634: pointer identity; anything else is InvalidOperandTypes (sequential machine)
+                    const TView vl = view(f, f.rt[l]), vr = view(f, f.rt[r]);
+                    if (vl.kind != TY_Pointer || vr.kind != TY_Pointer || vl.ptr != vr.ptr || match3(f, vl.sub, vr.sub) != M_YES) { fallback(f); return true; }
+                    Em<EMIT> e = open_slot<EMIT>(f, POS_EXIT(f, r));
+                    Val<EMIT> o; o.t = d_id(TP_Bool); o.info = own_rv(e.pos, e.v);
+                    o.var = e.newvar(f, o.t, true);
+                    e.ins(f, I_Equals, o.var, child_val<EMIT>(f, l).var, child_val<EMIT>(f, r).var);
+                    close_slot(f, e);
+                    set_result<EMIT>(f, i, o);
+                    return true;
+                }
                 if (op == OP_And || op == OP_Or) {   // :635-669
                     Em<EMIT> e = open_slot<EMIT>(f, POS_EXIT(f, l));
                     Val<EMIT> c = autocast<EMIT>(f, e, child_val<EMIT>(f, l), l, d_id(TP_Bool));

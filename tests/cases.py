@@ -140,6 +140,10 @@ def many_overloads(n=40):
 
 
 IR_CASES.append(many_overloads())
+# pointer identity (generate_ir.rs:616-634) inside conditions and under `not`: lowered by the node-parallel path
+IS_CASE = ("same(a @int32, b @int32, c @mut int32) int32\n\tvar n = 0\n\tif a is b\n\t\tn = n + 1\n\twhile not (a is b) and n < 3\n\t\tn = n + 1\n"
+           "\tvar q = mut n\n\tif q is c\n\t\treturn 1\n\treturn n\n")
+IR_CASES.append(IS_CASE)
 
 # finalize_definition errors (compile.rs:1002-1065): reported in definition order, no IR is generated (frontend.rs:145)
 FINALIZE_ERROR_CASES = [

@@ -6,7 +6,7 @@ import os
 import pytest
 
 import oracle_lib as O
-from cases import FINALIZE_ERROR_CASES, IR_CASES, PARSE_CASES, big_function as _big_function
+from cases import FINALIZE_ERROR_CASES, IR_CASES, IS_CASE, PARSE_CASES, big_function as _big_function
 
 pytestmark = pytest.mark.gpu
 
@@ -78,6 +78,11 @@ def test_kats2_gpu_against_the_hand_derived_text(fe, case):
     for rec, want in zip(view.sem_errors, case["messages"]):
         if want is not None:
             assert R.semantic_message_of_record(rec, view) == want
+
+
+def test_pointer_identity_takes_the_node_parallel_path(fe):
+    u = check_ir(fe, IS_CASE.encode())
+    assert u.lowering_stats() == (1, 0)
 
 
 def test_finalize_time_invalid_type_is_rendered_with_its_type(fe):
