@@ -8,6 +8,6 @@ for lib in "$@"; do
 import json, sys
 d = json.loads(open('/tmp/v.json').read().strip().splitlines()[-1])
 k = {x['name']: x['ms_per_step'] for x in d['kernels']}
-print(f"{sys.argv[1]:48s} {d['value']:8.1f} MB/s  step {d['ms_per_step']:7.1f} ms  lower_par {k.get("lower_par", 0):7.1f}  parse {k.get('parse_segments', 0):7.1f}  lex_emit {k.get('lex_emit', 0):6.2f}  lex_count {k.get('lex_count', 0):6.2f}")
+print(f"{sys.argv[1]:48s} {d['value']:8.1f} MB/s  step {d['ms_per_step']:7.1f} ms  lower_par {k.get('lower_par', 0):7.1f}  parse {k.get('parse_segments', 0):7.1f}  lex_emit {k.get('lex_emit', 0):6.2f}  lex_count {k.get('lex_count', 0):6.2f}")
 PY
 done
