@@ -144,6 +144,13 @@ IR_CASES.append(many_overloads())
 IS_CASE = ("same(a @int32, b @int32, c @mut int32) int32\n\tvar n = 0\n\tif a is b\n\t\tn = n + 1\n\twhile not (a is b) and n < 3\n\t\tn = n + 1\n"
            "\tvar q = mut n\n\tif q is c\n\t\treturn 1\n\treturn n\n")
 IR_CASES.append(IS_CASE)
+# `proc` expressions (generate_ir.rs:586-602) and calls through variables of function type (local, argument, global; :948-960:
+# arguments without expected type or autocast) — both lowered by the node-parallel path
+PROC_CASE = ("extern g(a int32) int32\nextern g(a nat8) int32\npr(x int32) int32\n\tvar f = proc g(int32)\n\tvar h = proc pr(int32)\n\tvar k = proc g(nat8)\n"
+             "\tif x > 2\n\t\treturn x\n\treturn 0\n")
+FNPTR_CASE = ("extern g(a int32, b nat8) int32\nextern z() null\nvar gp (int32, nat8) int32\ncall(p (int32, nat8) int32) int32\n\tvar fp = g\n\tvar zz = z\n\tzz()\n"
+              "\tvar x = fp(2, 3n8)\n\tif x > 0\n\t\treturn p(x, 4n8) + gp(1, 5n8)\n\treturn fp(x + 1, 6n8)\n")
+IR_CASES += [PROC_CASE, FNPTR_CASE]
 
 # finalize_definition errors (compile.rs:1002-1065): reported in definition order, no IR is generated (frontend.rs:145)
 FINALIZE_ERROR_CASES = [

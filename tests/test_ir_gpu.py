@@ -6,7 +6,7 @@ import os
 import pytest
 
 import oracle_lib as O
-from cases import FINALIZE_ERROR_CASES, IR_CASES, IS_CASE, PARSE_CASES, big_function as _big_function
+from cases import FINALIZE_ERROR_CASES, FNPTR_CASE, IR_CASES, IS_CASE, PARSE_CASES, PROC_CASE, big_function as _big_function
 
 pytestmark = pytest.mark.gpu
 
@@ -83,6 +83,14 @@ def test_kats2_gpu_against_the_hand_derived_text(fe, case):
 def test_pointer_identity_takes_the_node_parallel_path(fe):
     u = check_ir(fe, IS_CASE.encode())
     assert u.lowering_stats() == (1, 0)
+
+
+def test_proc_expressions_and_calls_through_function_variables(fe):
+    """declined by the node-parallel path (lowering them there was tried: the two extra branches of the inlined visit cost 19 % of the
+    kernel's time in register pressure for every function); the sequential machine gives the reference's IR"""
+    for src in (PROC_CASE, FNPTR_CASE):
+        u = check_ir(fe, src.encode())
+        assert u.lowering_stats() == (0, 1), src
 
 
 def test_finalize_time_invalid_type_is_rendered_with_its_type(fe):
