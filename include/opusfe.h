@@ -168,6 +168,13 @@ int opusfe_semantic_error_count(const opusfe_unit* unit, uint64_t* n);
    functions the parallel path declines: semantic errors, shadowing, structural comparisons of record / function types, 2048 nodes
    and more).  No counterpart in the reference; both produce the reference's IR. */
 int opusfe_lowering_stats(const opusfe_unit* unit, uint64_t* n_parallel, uint64_t* n_sequential);
+/* how the top-level segments of a parsed unit were parsed: by the data-parallel parser (parse_par.h: grammar automaton + one thread per
+   token) / by the sequential machine SegParser (the segments the former declines: every segment with a syntax or lexical error, blocks
+   that are not indented, a prefix operator directly followed by `not`, segments beyond 65535 tokens).  Both produce the reference's AST. */
+int opusfe_parsing_stats(const opusfe_unit* unit, uint64_t* n_parallel, uint64_t* n_sequential);
+/* mode 0 (default): data-parallel parser with SegParser as fallback; mode 1: SegParser alone (diagnostic: A/B tests of the two parsers).
+   No counterpart in the reference. */
+int opusfe_set_parser_mode(opusfe_ctx* ctx, int mode);
 /* device memory this context holds (result buffers of live units + the caching allocator's free blocks): the high-water mark
    of the HBM footprint of the calls made so far */
 int opusfe_memory_held(opusfe_ctx* ctx, uint64_t* bytes);

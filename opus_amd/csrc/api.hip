@@ -403,6 +403,7 @@ void opusfe_destroy(opusfe_ctx* ctx) {
     for (auto& kv : ctx->live_blocks) (void)hipFree(kv.first);
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     (void)hipFree(ctx->d_status);
+    (void)hipFree(ctx->d_pp_table);
     (void)hipHostFree(ctx->h_status);
     (void)hipStreamDestroy(ctx->stream);
     if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
@@ -541,6 +542,7 @@ int opusfe_parse_batch(opusfe_ctx* ctx, uint32_t n, const uint8_t* const* srcs, 
         opusfe_ctx* w = nullptr;
         int rc = opusfe_create(&w, ctx->device);
         if (rc != OPUSFE_OK) { ctx->msg = "opusfe_parse_batch: cannot create a worker context"; return rc; }
+        w->parser_mode = ctx->parser_mode;
         ctx->workers.push_back(w);
     }
     for (uint32_t i = 0; i < n; i++) { units[i] = nullptr; statuses[i] = OPUSFE_ERR_INTERNAL; }
@@ -696,6 +698,22 @@ int opusfe_lowering_stats(const opusfe_unit* u, uint64_t* n_parallel, uint64_t* 
     if (!R || !u->lowered || u->status != OPUSFE_OK) return OPUSFE_OK;
     *n_sequential = R->n_fallback;
     *n_parallel = R->n_bodies - R->n_fallback;
+    return OPUSFE_OK;
+}
+
+int opusfe_parsing_stats(const opusfe_unit* u, uint64_t* n_parallel, uint64_t* n_sequential) {
+    if (!u || !n_parallel || !n_sequential) return OPUSFE_ERR_ARG;
+    *n_parallel = *n_sequential = 0;
+    if (!u->parsed) return OPUSFE_OK;
+    *n_sequential = u->n_seg_sequential;
+    *n_parallel = u->n_segs - u->n_seg_sequential;
+    return OPUSFE_OK;
+}
+
+int opusfe_set_parser_mode(opusfe_ctx* ctx, int mode) {
+    if (!ctx || (mode != 0 && mode != 1)) return OPUSFE_ERR_ARG;
+    ctx->parser_mode = mode;
+    for (opusfe_ctx* w : ctx->workers) w->parser_mode = mode;
     return OPUSFE_OK;
 }
 

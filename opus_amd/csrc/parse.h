@@ -16,12 +16,16 @@
 #include <hip/hip_runtime.h>
 #include "unit.h"
 #include "scan.h"
+#include "parse_par.h"
 
 namespace opusfe {
 
 // per-segment info words
 enum { SI_NODE_BASE = 0, SI_NODE_COUNT, SI_DEF_COUNT, SI_FIRST_DEF, SI_ERR_KIND, SI_ERR_TOK, SI_ERR_LOW, SI_ERR_LEN, SI_ERR_EXPECTED,
-       SI_END_TOK, SI_MAX_DEPTH, SI_WORDS = 12 };
+       SI_END_TOK, SI_MAX_DEPTH, SI_SPARSE_BASE /* SegParser's node region */, SI_FRAME_BASE, SI_PATH /* 0: data-parallel parser (parse_par.h), 1: SegParser */,
+       SI_WORDS = 14 };
+static_assert(SI_NODE_COUNT == pp::PSI_NODE_COUNT && SI_DEF_COUNT == pp::PSI_DEF_COUNT && SI_ERR_KIND == pp::PSI_ERR_KIND && SI_SPARSE_BASE == pp::PSI_SPARSE_BASE &&
+              SI_FRAME_BASE == pp::PSI_FRAME_BASE && SI_PATH == pp::PSI_PATH && SI_WORDS == pp::PSI_WORDS, "parse_par.h shares these words");
 
 #ifndef OPUSFE_PARSE_LDS_FRAMES
 #define OPUSFE_PARSE_LDS_FRAMES 48
@@ -34,9 +38,8 @@ enum { PARSE_RING = OPUSFE_PARSE_RING };
 struct PFrame { uint8_t st; uint8_t aux; uint16_t cnt; uint32_t a, b, c; };
 static_assert(sizeof(PFrame) == 16, "frame is one 16-byte store");
 
-__host__ __device__ __forceinline__ uint64_t seg_node_base(uint32_t tok_begin, uint32_t seg) { return 2ull * tok_begin + 8ull * seg; }
+// sparse regions of a segment that SegParser parses (reserved by pp::k_pp_roles / k_pp_all_sequential with the same formulas)
 __host__ __device__ __forceinline__ uint64_t seg_node_cap(uint32_t tok_begin, uint32_t tok_end) { return 2ull * (tok_end - tok_begin) + 8ull; }
-__host__ __device__ __forceinline__ uint64_t seg_frame_base(uint32_t tok_begin, uint32_t seg) { return 2ull * tok_begin + 16ull * seg; }
 __host__ __device__ __forceinline__ uint64_t seg_frame_cap(uint32_t tok_begin, uint32_t tok_end) { return 2ull * (tok_end - tok_begin) + 16ull; }
 
 // parse.rs:179-196 binary operator of a token kind, OP_None otherwise
@@ -685,16 +688,18 @@ struct SegParser {
 
 __global__ MACHINE_ATTR(OPUSFE_PARSE_WAVES) __launch_bounds__(64) void k_parse_segments(const opusfe_token* __restrict__ tok, uint32_t n_tokens, const uint32_t* __restrict__ seg_start,
                                                         uint32_t n_segs, opusfe_node* __restrict__ nodes, PFrame* __restrict__ frames,
-                                                        uint32_t* __restrict__ seg_info, uint32_t* __restrict__ status, uint32_t* __restrict__ first_err_seg, const uint32_t* __restrict__ order) {
+                                                        uint32_t* __restrict__ seg_info, uint32_t* __restrict__ status, uint32_t* __restrict__ first_err_seg,
+                                                        const uint32_t* __restrict__ list, uint32_t n_list) {
     const uint32_t slot = blockIdx.x * (blockDim.x / UNIT_LANES) + threadIdx.x / UNIT_LANES;
     const uint32_t lane = threadIdx.x % UNIT_LANES;
-    if (slot >= n_segs) return;
-    const uint32_t s = order ? order[slot] : slot;     // largest segments first (scan.h)
+    if (slot >= n_list) return;
+    const uint32_t s = list[slot];     // the segments the data-parallel parser declined
+    if (s >= n_segs) return;
     uint32_t tb = seg_start[s], te = (s + 1 < n_segs) ? seg_start[s + 1] : n_tokens;
     SegParser P;    // no fields of its own: the state is static LDS (see lower.h)
     P.tok.p = tok; P.nodes = nodes; P.n_tokens = n_tokens;
-    P.nbase = (uint32_t)seg_node_base(tb, s); P.ncap = (uint32_t)seg_node_cap(tb, te);
-    P.stack = frames + seg_frame_base(tb, s); P.fcap = (uint32_t)seg_frame_cap(tb, te);
+    P.nbase = seg_info[(uint64_t)s * SI_WORDS + SI_SPARSE_BASE]; P.ncap = (uint32_t)seg_node_cap(tb, te);
+    P.stack = frames + seg_info[(uint64_t)s * SI_WORDS + SI_FRAME_BASE]; P.fcap = (uint32_t)seg_frame_cap(tb, te);
     P.i = tb; P.peeked = false; P.position = tb > 0 ? P.end_at(tb - 1) : 0u;
     P.nn = 0; P.sp = 0; P.max_sp = 0; P.ret = OPUSFE_NONE;
     P.err_kind = OPUSFE_NONE; P.err_tok = 0; P.err_low = 0; P.err_len = 0; P.err_expected = 0; P.dev_status = DS_OK; P.unsup_pos = OPUSFE_NONE;
@@ -732,18 +737,19 @@ __global__ void k_ast_counts(const uint32_t* __restrict__ seg_info, uint32_t n_s
     out[s] = Cnt2{seg_info[(uint64_t)s * SI_WORDS + SI_NODE_COUNT], seg_info[(uint64_t)s * SI_WORDS + SI_DEF_COUNT]};
 }
 
-// One wave per segment (grid-stride): copies the segment's sparse nodes to the dense array, rebasing indices;
+// One wave per SegParser segment (grid-stride): copies the segment's sparse nodes to the dense array, rebasing indices;
 // lane 0 then walks the definition chain.
-__global__ __launch_bounds__(256) void k_ast_compact(const opusfe_node* __restrict__ sparse, const uint32_t* __restrict__ seg_start, uint32_t n_segs,
+__global__ __launch_bounds__(256) void k_ast_compact(const opusfe_node* __restrict__ sparse, const uint32_t* __restrict__ list, uint32_t n_list,
                                                       uint32_t* __restrict__ seg_info, const Cnt2* __restrict__ base, opusfe_node* __restrict__ dense,
                                                       uint32_t* __restrict__ def_nodes) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-    for (uint32_t s = wave; s < n_segs; s += nwaves) {
+    for (uint32_t q = wave; q < n_list; q += nwaves) {
+        const uint32_t s = list[q];
         uint32_t* si = seg_info + (uint64_t)s * SI_WORDS;
         const uint32_t count = si[SI_NODE_COUNT];
-        const uint64_t sb = seg_node_base(seg_start[s], s);
+        const uint64_t sb = si[SI_SPARSE_BASE];
         const uint32_t db = base[s].nodes;
         const uint32_t delta = db - (uint32_t)sb;     // mod 2^32 arithmetic: new = old + delta
         for (uint32_t j = lane; j < count; j += 64) {
@@ -798,52 +804,88 @@ __global__ __launch_bounds__(256) void k_hdr_copy(const uint8_t* __restrict__ sr
 
 #ifndef OPUSFE_EMU
 // ---- host driver ------------------------------------------------------------------------------
-enum { WP_FIRST_ERR = 16, WP_LINES = 17, WP_TOTALS = 18 /* Cnt2 */ };
+enum { WP_FIRST_ERR = 16, WP_LINES = 17, WP_TOTALS = 18 /* Cnt2 */, WP_PAR = 24 /* pp::PW_* counters, 8 words */ };
+
+// the automaton's table, uploaded once per context
+inline void ensure_pp_table(opusfe_ctx* ctx) {
+    if (ctx->d_pp_table) return;
+    const pp::Table& t = pp::table();
+    if (!t.ok) throw HipError{hipErrorUnknown, "parse_par.h: the grammar table derivation is inconsistent"};
+    HIP_TRY(hipMalloc((void**)&ctx->d_pp_table, t.blob.size() * 4));
+    HIP_TRY(hipMemcpy(ctx->d_pp_table, t.blob.data(), t.blob.size() * 4, hipMemcpyHostToDevice));
+    ctx->pp_states = t.n_states; ctx->pp_start = t.start;
+}
 
 inline void run_parser(opusfe_ctx* ctx, opusfe_unit* u) {
     hipStream_t st = ctx->stream;
     TempList tmp(ctx);
     const uint32_t n_segs = (uint32_t)u->n_segs, n_tok = (uint32_t)u->n_tokens;
     u->parsed = true;
-    u->n_nodes = u->n_defs = 0;
+    u->n_nodes = u->n_defs = 0; u->n_seg_sequential = 0;
     if (n_segs == 0) { u->status = OPUSFE_OK; return; }
-    const uint64_t sparse_cap = 2ull * n_tok + 8ull * n_segs + 8;
-    const uint64_t frame_cap = 2ull * n_tok + 16ull * n_segs + 16;
-    if (sparse_cap >= 0xFFFFFFF0ull) { u->status = OPUSFE_ERR_ARG; ctx->msg = "unit has too many tokens for 32-bit node indices: shard it"; return; }
-    opusfe_node* sparse = tmp.get<opusfe_node>(sparse_cap);
-    PFrame* frames = tmp.get<PFrame>(frame_cap);
+    ensure_pp_table(ctx);
     u->d_seg_info = dev_alloc_t<uint32_t>(ctx, (uint64_t)n_segs * SI_WORDS);
     Cnt2* cnt = tmp.get<Cnt2>(n_segs);
     Cnt2* scan_tmp = tmp.get<Cnt2>((n_segs + SCAN_TILE - 1) / SCAN_TILE + 1);
     uint32_t init[4] = {0xFFFFFFFFu, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(ctx->d_status + WP_FIRST_ERR, init, sizeof init, hipMemcpyHostToDevice, st));
-    uint32_t* order = tmp.get<uint32_t>(n_segs);
-    uint32_t* order_hist = tmp.get<uint32_t>(ORDER_CLASSES);
-    HIP_TRY(hipMemsetAsync(order_hist, 0, ORDER_CLASSES * sizeof(uint32_t), st));
-    LAUNCH(ctx, "order_hist", k_order_hist, grid_for(n_segs, 256), 256, u->d_seg_start, n_segs, n_tok, order_hist);
-    LAUNCH(ctx, "order_scan", k_order_scan, 1, 64, order_hist);
-    LAUNCH(ctx, "order_scatter", k_order_scatter, grid_for(n_segs, 256), 256, u->d_seg_start, n_segs, n_tok, order_hist, order);
-    LAUNCH(ctx, "parse_segments", k_parse_segments, grid_for((uint64_t)n_segs * UNIT_LANES, 64), 64, u->d_tokens, n_tok, u->d_seg_start, n_segs, sparse, frames,
-           u->d_seg_info, ctx->d_status, ctx->d_status + WP_FIRST_ERR, (const uint32_t*)order);
-#ifdef OPUSFE_PARSE_PROF
-    {
-        unsigned long long h[128];
-        HIP_TRY(hipStreamSynchronize(st));
-        HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_parse_prof), sizeof h));
-        unsigned long long z[128] = {0};
-        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_parse_prof), z, sizeof z));
-        double tot = 0; for (int i = 0; i < 64; i++) tot += (double)h[i];
-        fprintf(stderr, "parser cycle accounting per state (index into enum PState): share, steps, cycles per step\n");
-        for (int i = 0; i < 64; i++) if (h[64 + i]) fprintf(stderr, "  state %2d  %5.1f%%  %12llu steps  %8.0f cycles/step\n", i, 100.0 * h[i] / tot, h[64 + i], 16.0 * (double)h[i] / (double)h[64 + i]);
+    HIP_TRY(hipMemsetAsync(ctx->d_status + WP_PAR, 0, pp::PW_WORDS * sizeof(uint32_t), st));
+    uint32_t* decl_list = tmp.get<uint32_t>(n_segs);
+    pp::Rec16* prec = nullptr;       // pp::PRec per token
+    if (ctx->parser_mode == 1) {
+        LAUNCH(ctx, "pp_all_sequential", pp::k_pp_all_sequential, grid_for(n_segs, 256), 256, u->d_seg_start, n_segs, n_tok, u->d_seg_info, ctx->d_status + WP_PAR, decl_list);
+    } else {
+        // pass 1: one lane per segment runs the grammar automaton (largest segments first: lanes of a wave then have similar lengths)
+        uint32_t* order = tmp.get<uint32_t>(n_segs);
+        uint32_t* order_hist = tmp.get<uint32_t>(ORDER_CLASSES);
+        HIP_TRY(hipMemsetAsync(order_hist, 0, ORDER_CLASSES * sizeof(uint32_t), st));
+        LAUNCH(ctx, "order_hist", k_order_hist, grid_for(n_segs, 256), 256, u->d_seg_start, n_segs, n_tok, order_hist);
+        LAUNCH(ctx, "order_scan", k_order_scan, 1, 64, order_hist);
+        LAUNCH(ctx, "order_scatter", k_order_scatter, grid_for(n_segs, 256), 256, u->d_seg_start, n_segs, n_tok, order_hist, order);
+        prec = tmp.get<pp::Rec16>((uint64_t)n_tok + 1);
+        pp::RolesArgs A{};
+        A.tok = u->d_tokens; A.n_tokens = n_tok; A.seg_start = u->d_seg_start; A.n_segs = n_segs; A.order = order;
+        A.table = ctx->d_pp_table; A.n_states = ctx->pp_states; A.start = ctx->pp_start;
+        A.prec = prec; A.stack = tmp.get<pp::StackEnt>((uint64_t)n_tok / 2 + n_segs + 2);
+        A.seg_info = u->d_seg_info; A.work = ctx->d_status + WP_PAR; A.decl_list = decl_list;
+        LAUNCH(ctx, "pp_roles", pp::k_pp_roles, grid_for(n_segs, 256), 256, A);
     }
+    auto count_and_scan = [&] {
+        LAUNCH(ctx, "ast_counts", k_ast_counts, grid_for(n_segs, 256), 256, u->d_seg_info, n_segs, cnt);
+        prof_begin(ctx, "ast_scan");
+        device_scan<true>(cnt, cnt, n_segs, OpAddCnt2(), Cnt2{0, 0}, scan_tmp, (Cnt2*)(ctx->d_status + WP_TOTALS), st);
+        prof_end(ctx);
+        HIP_TRY(hipMemcpyAsync(ctx->h_status, ctx->d_status, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        prof_collect(ctx);
+    };
+    count_and_scan();
+    // pass 2 (only when something was declined: syntax errors, the few constructs parse_par.h leaves out): SegParser on those segments
+    const uint32_t n_decl = ctx->h_status[WP_PAR + pp::PW_DECLINED];
+    opusfe_node* sparse = nullptr;
+    u->n_seg_sequential = n_decl;
+    if (n_decl) {
+        uint64_t sparse_cap, frame_cap;
+        memcpy(&sparse_cap, ctx->h_status + WP_PAR + pp::PW_SPARSE, 8); memcpy(&frame_cap, ctx->h_status + WP_PAR + pp::PW_FRAMES, 8);
+        if (sparse_cap >= 0xFFFFFFF0ull || frame_cap >= 0xFFFFFFF0ull) { u->status = OPUSFE_ERR_ARG; ctx->msg = "unit has too many tokens for 32-bit node indices: shard it"; return; }
+        sparse = tmp.get<opusfe_node>(sparse_cap + 8);
+        PFrame* frames = tmp.get<PFrame>(frame_cap + 16);
+        LAUNCH(ctx, "parse_segments", k_parse_segments, grid_for((uint64_t)n_decl * UNIT_LANES, 64), 64, u->d_tokens, n_tok, u->d_seg_start, n_segs, sparse, frames,
+               u->d_seg_info, ctx->d_status, ctx->d_status + WP_FIRST_ERR, (const uint32_t*)decl_list, n_decl);
+#ifdef OPUSFE_PARSE_PROF
+        {
+            unsigned long long h[128];
+            HIP_TRY(hipStreamSynchronize(st));
+            HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_parse_prof), sizeof h));
+            unsigned long long z[128] = {0};
+            HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_parse_prof), z, sizeof z));
+            double tot = 0; for (int i = 0; i < 64; i++) tot += (double)h[i];
+            fprintf(stderr, "parser cycle accounting per state (index into enum PState): share, steps, cycles per step\n");
+            for (int i = 0; i < 64; i++) if (h[64 + i]) fprintf(stderr, "  state %2d  %5.1f%%  %12llu steps  %8.0f cycles/step\n", i, 100.0 * h[i] / tot, h[64 + i], 16.0 * (double)h[i] / (double)h[64 + i]);
+        }
 #endif
-    LAUNCH(ctx, "ast_counts", k_ast_counts, grid_for(n_segs, 256), 256, u->d_seg_info, n_segs, cnt);
-    prof_begin(ctx, "ast_scan");
-    device_scan<true>(cnt, cnt, n_segs, OpAddCnt2(), Cnt2{0, 0}, scan_tmp, (Cnt2*)(ctx->d_status + WP_TOTALS), st);
-    prof_end(ctx);
-    HIP_TRY(hipMemcpyAsync(ctx->h_status, ctx->d_status, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    prof_collect(ctx);
+        count_and_scan();
+    }
     const uint32_t dev_status = ctx->h_status[0];
     const uint32_t first_err = ctx->h_status[WP_FIRST_ERR];
     if (first_err != 0xFFFFFFFFu || dev_status != DS_OK) u->n_nodes = u->n_defs = 0;   // no AST: the counts must not promise arrays that do not exist
@@ -889,9 +931,15 @@ inline void run_parser(opusfe_ctx* ctx, opusfe_unit* u) {
     u->dev_status = DS_OK;
     u->d_nodes = dev_alloc_t<opusfe_node>(ctx, u->n_nodes);
     u->d_def_nodes = dev_alloc_t<uint32_t>(ctx, u->n_defs);
-    unsigned grid = (unsigned)((n_segs + 3) / 4);
-    if (grid > 8192) grid = 8192;
-    LAUNCH(ctx, "ast_compact", k_ast_compact, grid, 256, sparse, u->d_seg_start, n_segs, u->d_seg_info, cnt, u->d_nodes, u->d_def_nodes);
+    // pass 3: every node is written once, at its final place
+    if (n_decl < n_segs)
+        LAUNCH(ctx, "pp_build", pp::k_pp_build, grid_for(n_tok, 256), 256, u->d_tokens, n_tok, u->d_seg_start, n_segs, (const pp::Rec16*)prec, (const uint32_t*)u->d_seg_info,
+               (const pp::NodeBase*)cnt, u->d_nodes, u->d_def_nodes);
+    if (n_decl) {
+        unsigned grid = (unsigned)((n_decl + 3) / 4);
+        if (grid > 8192) grid = 8192;
+        LAUNCH(ctx, "ast_compact", k_ast_compact, grid, 256, sparse, (const uint32_t*)decl_list, n_decl, u->d_seg_info, cnt, u->d_nodes, u->d_def_nodes);
+    }
     HIP_TRY(hipStreamSynchronize(st));
     prof_collect(ctx);
     u->status = OPUSFE_OK;

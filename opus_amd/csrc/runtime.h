@@ -37,6 +37,8 @@ struct opusfe_ctx {
     // IR result sizes per AST node (variables, instructions, blocks, local types, call arguments) that lower.h run_lower sizes
     // its arrays with: generous defaults, then what the previous unit on this context needed (+4 %)
     double ir_ratio[5] = {1.35, 1.65, 0.40, 0.30, 0.25};
+    // parse_par.h: the automaton's table on this device (uploaded on first use); parser_mode 1 = SegParser alone (opusfe_set_parser_mode)
+    uint32_t* d_pp_table = nullptr; uint32_t pp_states = 0, pp_start = 0; int parser_mode = 0;
     uint32_t* d_static_scratch = nullptr;   // this device's address of api.hip `scratch` (hipGetSymbolAddress at opusfe_create)
     // opusfe_parse_batch: worker contexts (own stream and allocator each) owned by this context; units they created
     // are released before the context is destroyed

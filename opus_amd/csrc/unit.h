@@ -18,6 +18,7 @@ struct opusfe_unit {
     opusfe_node* d_nodes = nullptr; uint64_t node_cap = 0;     // sparse: segment s owns [node_base(s), +count)
     uint32_t* d_seg_info = nullptr;                            // per segment: node_base, node_count, first_def, def_count, err..., 8 words
     uint64_t n_nodes = 0, n_defs = 0, n_funcs = 0;
+    uint64_t n_seg_sequential = 0;                             // segments parsed by SegParser (the rest by parse_par.h)
     uint32_t* d_parents = nullptr;                             // OPUSFE_A_PARENTS, built on first request
     uint32_t* d_def_nodes = nullptr;                           // definition index -> root node
     uint8_t* d_headers = nullptr; uint64_t n_headers = 0;      // definition headers (opusfe_unit_headers)

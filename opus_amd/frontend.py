@@ -75,6 +75,8 @@ def lib():
         L.opusfe_lower.argtypes = [vp, vp]
         L.opusfe_unit_status.argtypes = [vp]
         L.opusfe_lowering_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
+        L.opusfe_parsing_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
+        L.opusfe_set_parser_mode.argtypes = [vp, i]
         L.opusfe_memory_held.argtypes = [vp, C.POINTER(u64)]
         L.opusfe_unit_resync_passes.argtypes = [vp, C.POINTER(u32)]
         L.opusfe_get_counts.argtypes = [vp, C.POINTER(Counts)]
@@ -156,6 +158,12 @@ class Unit:
             raise OpusfeError(rc, self.ctx.message())
         self.status = rc
         return rc
+
+    def parsing_stats(self):
+        """(top-level segments parsed by the data-parallel parser, segments parsed by the sequential machine)"""
+        a, b = C.c_uint64(), C.c_uint64()
+        lib().opusfe_parsing_stats(self.handle, C.byref(a), C.byref(b))
+        return a.value, b.value
 
     def lowering_stats(self):
         """(functions lowered by the node-parallel kernels, functions lowered by the sequential machine)"""
@@ -325,6 +333,12 @@ class Context:
 
     def shard_free(self, shard):
         lib().opusfe_shard_free(shard)
+
+    def set_parser_mode(self, mode):
+        """0: data-parallel parser with the sequential machine as fallback (default); 1: the sequential machine alone"""
+        rc = lib().opusfe_set_parser_mode(self.handle, int(mode))
+        if rc != OK:
+            raise OpusfeError(rc, "opusfe_set_parser_mode")
 
     def set_profiling(self, on=True):
         lib().opusfe_set_profiling(self.handle, int(on))

@@ -113,24 +113,50 @@ void emu_lex(EmuUnit& E, int force_dents) {
     E.u.status = status[0] == DS_OK ? OPUSFE_OK : status[0] >= DS_INTERNAL_CAPACITY ? OPUSFE_ERR_INTERNAL : OPUSFE_UNSUPPORTED;
 }
 
+template <class T> T* exact(size_t n) { return (T*)calloc(n ? n : 1, sizeof(T)); }   // exact-size heap blocks: ASan sees overruns
+
 void emu_parse(EmuUnit& E) {
     opusfe_unit& u = E.u;
     const uint32_t n_segs = (uint32_t)u.n_segs, n_tok = (uint32_t)u.n_tokens;
     u.parsed = true; u.n_nodes = u.n_defs = 0;
     if (n_segs == 0) { if (u.status == OPUSFE_OK || E.status[0] == DS_OK) u.status = E.status[0] == DS_OK ? OPUSFE_OK : OPUSFE_UNSUPPORTED; return; }
-    // exact-size scratch so that AddressSanitizer sees every overrun
-    std::vector<opusfe_node> sparse(2ull * n_tok + 8ull * n_segs + 8);
-    std::vector<PFrame> frames(2ull * n_tok + 16ull * n_segs + 16);
+    // product sequencing of parse.h run_parser: the data-parallel parser (parse_par.h) first, SegParser on what it declines.
+    // EMU_PARSER_SEQ=1 sends every segment to SegParser (opusfe_set_parser_mode(ctx, 1)).
     E.seg_info.assign((size_t)n_segs * SI_WORDS, 0);
     uint32_t first_err = 0xFFFFFFFFu;
-    emu_launch(k_parse_segments, grid_for(n_segs, 64), 64, u.h_tokens.data(), n_tok, E.seg_start.data(), n_segs, sparse.data(), frames.data(),
-               E.seg_info.data(), E.status, &first_err, (const uint32_t*)nullptr);
+    uint32_t work[pp::PW_WORDS + 2] = {0};
+    std::vector<uint32_t> decl_list(n_segs);
+    pp::Rec16* prec = exact<pp::Rec16>((size_t)n_tok + 1);
+    pp::StackEnt* pstack = exact<pp::StackEnt>((size_t)n_tok / 2 + n_segs + 2);
+    const pp::Table& PT = pp::table();
+    if (!PT.ok) { fprintf(stderr, "emu: the grammar table derivation is inconsistent\n"); abort(); }
+    if (getenv("EMU_PARSER_SEQ")) emu_launch(pp::k_pp_all_sequential, grid_for(n_segs, 256), 256, (const uint32_t*)E.seg_start.data(), n_segs, n_tok, E.seg_info.data(), work, decl_list.data());
+    else {
+        pp::RolesArgs A{};
+        A.tok = u.h_tokens.data(); A.n_tokens = n_tok; A.seg_start = E.seg_start.data(); A.n_segs = n_segs; A.order = nullptr;
+        A.table = PT.blob.data(); A.n_states = PT.n_states; A.start = PT.start; A.prec = prec; A.stack = pstack;
+        A.seg_info = E.seg_info.data(); A.work = work; A.decl_list = decl_list.data();
+        emu_launch(pp::k_pp_roles, grid_for(n_segs, 256), 256, A);
+    }
+    const uint32_t n_decl = work[pp::PW_DECLINED];
+    u.n_seg_sequential = n_decl;
+    if (getenv("EMU_REQUIRE_PP") && n_decl) { fprintf(stderr, "emu: %u of %u segments declined by the data-parallel parser\n", n_decl, n_segs); free(prec); free(pstack); u.status = OPUSFE_ERR_INTERNAL; return; }
+    uint64_t sparse_cap = 0, frame_cap = 0;
+    memcpy(&sparse_cap, work + pp::PW_SPARSE, 8); memcpy(&frame_cap, work + pp::PW_FRAMES, 8);
+    // exact-size scratch so that AddressSanitizer sees every overrun
+    std::vector<opusfe_node> sparse(sparse_cap + 8);
+    std::vector<PFrame> frames(frame_cap + 16);
+    if (n_decl)
+        emu_launch(k_parse_segments, grid_for(n_decl, 64), 64, u.h_tokens.data(), n_tok, E.seg_start.data(), n_segs, sparse.data(), frames.data(),
+                   E.seg_info.data(), E.status, &first_err, (const uint32_t*)decl_list.data(), n_decl);
     if (getenv("EMU_VERBOSE")) for (uint32_t s = 0; s < n_segs; s++) { uint32_t k = E.seg_info[(size_t)s * SI_WORDS + SI_ERR_KIND]; if (k != OPUSFE_NONE && (k & 0x200u)) fprintf(stderr, "segment %u of %u: internal condition %u (first error segment %u)\n", s, n_segs, k & 0xFF, first_err); }
+    if (getenv("EMU_VERBOSE")) fprintf(stderr, "parser: %u of %u segments by SegParser\n", n_decl, n_segs);
     std::vector<Cnt2> cnt(n_segs);
     emu_launch(k_ast_counts, grid_for(n_segs, 256), 256, E.seg_info.data(), n_segs, cnt.data());
     Cnt2 run{0, 0};
     for (uint32_t s = 0; s < n_segs; s++) { Cnt2 c = cnt[s]; cnt[s] = run; run = OpAddCnt2()(run, c); }
     u.n_nodes = run.nodes; u.n_defs = run.defs;
+    struct FreeOnExit { void* a; void* b; ~FreeOnExit() { free(a); free(b); } } free_on_exit{prec, pstack};
     const uint32_t dev_status = E.status[0];
     if (first_err != 0xFFFFFFFFu) {
         const uint32_t* si = E.seg_info.data() + (size_t)first_err * SI_WORDS;
@@ -151,14 +177,21 @@ void emu_parse(EmuUnit& E) {
         return;
     }
     if (dev_status != DS_OK) { u.status = OPUSFE_UNSUPPORTED; u.dev_status = dev_status; return; }
-    u.h_nodes.assign(u.n_nodes, opusfe_node{}); u.h_def_nodes.assign(u.n_defs, 0);
-    emu_launch(k_ast_compact, 2, 256, sparse.data(), E.seg_start.data(), n_segs, E.seg_info.data(), cnt.data(), u.h_nodes.data(), u.h_def_nodes.data());
+    {   // exact-size result blocks: a node written outside the counted total is an ASan error
+        opusfe_node* dn = exact<opusfe_node>(u.n_nodes); uint32_t* dd = exact<uint32_t>(u.n_defs);
+        memset(dn, 0xEE, (size_t)u.n_nodes * sizeof(opusfe_node));
+        if (n_decl < n_segs)
+            emu_launch(pp::k_pp_build, grid_for(n_tok, 256), 256, (const opusfe_token*)u.h_tokens.data(), n_tok, (const uint32_t*)E.seg_start.data(), n_segs, (const pp::Rec16*)prec,
+                       (const uint32_t*)E.seg_info.data(), (const pp::NodeBase*)cnt.data(), dn, dd);
+        if (n_decl) emu_launch(k_ast_compact, 2, 256, (const opusfe_node*)sparse.data(), (const uint32_t*)decl_list.data(), n_decl, E.seg_info.data(), (const Cnt2*)cnt.data(), dn, dd);
+        u.h_nodes.assign(dn, dn + u.n_nodes); u.h_def_nodes.assign(dd, dd + u.n_defs);
+        free(dn); free(dd);
+    }
     u.have_h_ast = true;
     u.status = OPUSFE_OK;
 }
 
 
-template <class T> T* exact(size_t n) { return (T*)calloc(n ? n : 1, sizeof(T)); }   // exact-size heap blocks: ASan sees overruns
 
 void emu_lower(EmuUnit& E) {
     opusfe_unit& u = E.u;
