@@ -64,6 +64,105 @@ def stage_of(name):
     return "other"
 
 
+def extra_c2(ctx, opus_amd, O, torch):
+    """BASELINE configs[1]: G(seed=2), 10^6 B, resident in HBM: latency of one pass, and the three dumps against the oracle's"""
+    import hashlib
+    src = O.generate(2, 1_000_000, flags=0)
+    d = torch.empty(len(src) + 64, dtype=torch.uint8, device="cuda")
+    d[:len(src)].copy_(torch.frombuffer(bytearray(src), dtype=torch.uint8))
+    torch.cuda.synchronize()
+
+    def one(keep=False):
+        u = ctx.get_definitions_device(d.data_ptr(), len(src))
+        if u.status == opus_amd.OK:
+            u.compile_source()
+        if keep:
+            return u
+        u.close()
+    for _ in range(3):
+        one()
+    n = 20
+    t0 = time.perf_counter()
+    for _ in range(n):
+        one()
+    dt = (time.perf_counter() - t0) / n
+    u = one(keep=True)
+    sha = lambda t: hashlib.sha1(t.encode("utf-8", errors="surrogateescape")).hexdigest()
+    same = u.status == opus_amd.OK and all(sha(g) == sha(O.dump(src, w)) for g, w in ((u.dump_tokens(), O.TOKENS), (u.dump_ast(), O.AST), (u.dump_ir(), O.IR)))
+    u.close()
+    tcpu, _ = O.time_run(src, lower=True)
+    return {"workload": "C2: G(seed=2), 1000000 B, one source resident in HBM", "us_per_pass": round(dt * 1e6, 1), "mbs": round(len(src) / 1e6 / dt, 2),
+            "dumps_equal_oracle": bool(same), "compared": ["tokens", "ast", "ir"], "cpu_port_mbs": round(len(src) / 1e6 / tcpu, 2), "cpu_cores": 1}
+
+
+def extra_c5(ctx, opus_amd, O, n_files):
+    """BASELINE configs[4] at reduced corpus size: n_files files of 1-64 KB, every 100th with one injected fault, host buffers"""
+    import hashlib
+    import math
+    import random
+    from concurrent.futures import ThreadPoolExecutor
+    rnd = random.Random(5)
+    sizes = [int(math.exp(rnd.uniform(math.log(1024), math.log(65536)))) for _ in range(n_files)]
+    cores = max(1, min(16, os.cpu_count() or 1))
+
+    def make_file(i):
+        s = O.generate(5_000_000 + i, sizes[i], flags=0, threads=1)
+        if i % 100 == 7:
+            s = O.inject(s, i, (i // 100) % 10) or s
+        return s
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        corpus = list(ex.map(make_file, range(n_files)))
+    total = sum(len(f) for f in corpus)
+    res = run_corpus(ctx, opus_amd, corpus)          # warm-up (allocator, worker contexts)
+    t0 = time.perf_counter()
+    res = run_corpus(ctx, opus_amd, corpus)
+    dt = time.perf_counter() - t0
+    # CPU: one oracle worker per hardware thread on a bounded prefix of the same corpus
+    acc, sample = 0, []
+    for f in corpus:
+        if acc >= 6e6 * cores * 1.5:
+            break
+        sample.append(f); acc += len(f)
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        list(ex.map(lambda f: O.time_run(f, lower=True)[1].status, sample))
+    tc = time.perf_counter() - t0
+    # parity on a sample: every faulty file among the first 1000 and every 10th clean one
+    ok, nbad, checked = True, 0, 0
+    for i, f in enumerate(corpus[:1000]):
+        if i % 100 != 7 and i % 10 != 3:
+            continue
+        checked += 1
+        want = O.dump(f, O.ERROR)
+        nbad += want != "Ok\n"
+        got_err, got_ir = res["error_text"](i), None
+        if got_err != want:
+            ok = False
+        elif want == "Ok\n":
+            got_ir = res["ir_text"](i)
+            if hashlib.sha1(got_ir.encode()).digest() != hashlib.sha1(O.dump(f, O.IR).encode()).digest():
+                ok = False
+    res["close"]()
+    return {"workload": f"C5: {n_files} files of 1-64 KB ({total} B), 1 % with one injected syntax fault, host buffers (H2D included)",
+            "path": res["path"], "mbs": round(total / 1e6 / dt, 2), "files_per_s": round(n_files / dt, 1), "files_with_syntax_error": res["n_syntax"],
+            "cpu_port_mbs": round(acc / 1e6 / tc, 2), "cpu_cores": cores, "cpu_sample_files": len(sample),
+            "sample_parity": {"files_checked": checked, "with_syntax_error": nbad, "error_tuples_and_ir_text_match": bool(ok)}}
+
+
+def run_corpus(ctx, opus_amd, corpus):
+    """one pass of the corpus path; returns accessors for the parity sample"""
+    units = ctx.compile_corpus(corpus, lower=True)
+    for uu in units:
+        if uu.status not in (opus_amd.OK, opus_amd.SYNTAX):
+            raise SystemExit(f"corpus file failed: status {uu.status}: {ctx.message()}")
+
+    def close():
+        for uu in units:
+            uu.close()
+    return {"path": "opusfe_parse_batch: one unit per file on 8 worker contexts", "n_syntax": sum(uu.status == opus_amd.SYNTAX for uu in units),
+            "error_text": lambda i: units[i].dump_error(), "ir_text": lambda i: units[i].dump_ir(), "close": close}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -79,6 +178,8 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo lets several ranks share one GPU (rehearsal only)")
     ap.add_argument("--cpu-sample-bytes", type=float, default=48e6)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the c2 / c5 legs of the default N=1 run")
+    ap.add_argument("--extra-files", type=int, default=6000, help="files of the c5 leg of the default N=1 run")
     ap.add_argument("--gen-flags", type=int, default=1, help="generator flags (bit 0: inject the three depth-1000 regions of BASELINE configs[2]); diagnostics only")
     args = ap.parse_args()
     import torch
@@ -327,6 +428,10 @@ def main():
             parity = {"files_checked": len(check), "files_with_syntax_error": nerr, "error_tuples_and_ir_text_match": ok}
             cpu = {"value": round(acc / 1e6 / tc, 3), "unit": "MB/s", "cores": cores, "kind": "port",
                    "sample": f"{len(sample_files)} files ({int(acc)} bytes) of the same corpus, one oracle worker per hardware thread ({cores} threads), statuses {sorted(set(res))}"}
+        # ---- the small-input regimes on the same line (BASELINE configs[1] and configs[4]), bounded to a few seconds each ----
+        extra = None
+        if world == 1 and workload == "c3" and not args.no_cpu and not args.no_extra and args.stage == "ir":
+            extra = {"c2": extra_c2(ctx, opus_amd, O, torch), "c5": extra_c5(ctx, opus_amd, O, args.extra_files)}
         # ---- algorithmic bytes: S + 16 T + 24 N + 24 I + 8 V with N = nodes of the REFERENCE's tree ----
         N_ref = int(round(N * node_ratio)) if node_ratio else N
         alg = {"lex": S + 16 * T, "parse": 16 * T + 24 * N_ref, "lower": 24 * N_ref + 24 * I + 8 * V, "other": S}
@@ -374,7 +479,7 @@ def main():
                "hbm_gbs_whole_path": round(world * total_alg / (dt / args.steps) / 1e9, 2),
                "hbm_frac_whole_path": round(total_alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 5),
                "hbm_held_bytes": held, "lowering_functions": lowering or None, "sharded_totals": sharded_totals,
-               "roofline": roofline, "cpu_baseline": cpu, "parity_check": parity if cpu is not None else None,
+               "roofline": roofline, "cpu_baseline": cpu, "parity_check": parity if cpu is not None else None, "extra": extra,
                "kernels": [{"name": n, "ms_per_step": round(ms / args.steps, 4), "launches_per_step": l / args.steps} for n, ms, l in kstats[:24]],
                "gen_seconds": round(gen_s, 1)}
     ctx.close()

@@ -192,7 +192,13 @@ int opusfe_copy_tokens(opusfe_unit* unit, opusfe_token* dst, uint64_t cap, uint6
 /* ---- flat result arrays: what a host backend reads instead of IrGenerator's fields
    (generate_ir.rs:58-98 `variables`, `bbs`, `function`; llvm.rs:355-420 walks exactly these) ----
    Ids: variables and basic blocks are numbered per function from 0 (dst/a/b and Jump/Branch/Phi targets are those local
-   numbers; add var_base / bb_base of the function for the global arrays); type ids index OPUSFE_A_TYPES directly. */
+   numbers; add var_base / bb_base of the function for the global arrays); type ids index OPUSFE_A_TYPES directly.
+   LAYOUT: OPUSFE_A_VARIABLES / _BB_OFFSETS / _INSTRS / _CALL_ARGS and the function-local part of OPUSFE_A_TYPES are DENSE BUT
+   UNORDERED: every function takes its place with an atomic add when its sizes are known, so the order of the functions inside
+   these arrays (hence every *_base, and the ids of function-local types) is the order in which they finished.  It differs from
+   run to run and between the first attempt and the exact-size retry.  Only what is reached through a function's bases is
+   stable: the function's own records, its local numbering, and OPUSFE_A_FUNCTIONS itself (definition order).  Do not hash,
+   cache or diff the raw arrays; compare per function (opus_amd/ir_view.py does). */
 typedef struct opusfe_function_ir {      /* one per Definition::Function / extern, in definition order; n_bbs == 0: extern */
     uint32_t def_node;                   /* root node of the definition */
     uint32_t func;                       /* index into OPUSFE_A_SIGNATURES */
@@ -216,7 +222,10 @@ typedef struct opusfe_global { uint32_t def_node, type_id, is_const, name_tok; }
 /* kind and span, plus what the message of compile.rs:816-915 prints besides the span: `name` = token index of the variable /
    field / function name (0x80000000 | token kind for a builtin operator symbol, 0xFFFFFFFF = none); `nargs` = number of argument
    types of a function identifier (compile.rs:115-122), the first four of them in t[]; for the typed kinds t[0], t[1] are the one
-   or two types (expected, found / from, to / left, right); type ids index OPUSFE_A_TYPES */
+   or two types (expected, found / from, to / left, right); type ids index OPUSFE_A_TYPES.  A function identifier with more than four
+   argument types is followed by CONTINUATION records (kind == OPUSFE_SEM_CONTINUATION): the eight words behind `kind` are the next
+   eight argument type ids (0xFFFFFFFF = unused).  They are not diagnostics: opusfe_semantic_error_count does not count them. */
+#define OPUSFE_SEM_CONTINUATION 0x100u
 typedef struct opusfe_semantic_error { uint32_t kind /* compile.rs:124-152 variant index */, low, len, name, nargs, t[4]; } opusfe_semantic_error;
 
 enum {

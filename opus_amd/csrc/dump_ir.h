@@ -147,7 +147,7 @@ inline std::string dump_semantic_errors(const opusfe_unit* u) {
     const IrResult* R = (const IrResult*)u->ir;
     std::string out;
     if (!R) return out;
-    for (const SemErr& e : R->errs) { out += NAMES[e.kind]; out += ' '; out += std::to_string(e.low); out += ' '; out += std::to_string(e.len); out += '\n'; }
+    for (const SemErr& e : R->errs) { if (e.kind == SE_Continuation) continue; out += NAMES[e.kind]; out += ' '; out += std::to_string(e.low); out += ' '; out += std::to_string(e.len); out += '\n'; }
     return out;
 }
 

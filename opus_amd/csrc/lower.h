@@ -155,7 +155,7 @@ struct Lowerer {
     MACHINE_STATE uint32_t* lname; MACHINE_STATE uint32_t* lvar; MACHINE_STATE uint32_t nlocals, lcap;
     MACHINE_STATE uint32_t* lstack; MACHINE_STATE uint32_t nstack;
     MACHINE_STATE LFrame* frames; MACHINE_STATE uint32_t sp, fcap;
-    MACHINE_STATE SemErr* errs; MACHINE_STATE uint32_t nerrs, ecap;
+    MACHINE_STATE SemErr* errs; MACHINE_STATE uint32_t nerrs, ecap, ncont /* continuation records among nerrs */;
     // generate_ir.rs:75-97 state
     MACHINE_STATE uint32_t bb_index, break_head, loop_begin;
     MACHINE_STATE uint32_t dev_status;
@@ -558,7 +558,13 @@ struct Lowerer {
         const uint32_t slot = nf.slot;
 #define ARG_T(i) (types_in ? uni(gld(types_in + (i))) : vtype(argv.get(i)))
 #define FN_IDENT() einfo(einfo_key(name), n, n > 0 ? ARG_T(0) : OPUSFE_NONE, n > 1 ? ARG_T(1) : OPUSFE_NONE, n > 2 ? ARG_T(2) : OPUSFE_NONE, n > 3 ? ARG_T(3) : OPUSFE_NONE)
-        if (!nf.has) { FN_IDENT(); report(SE_UndefinedFunction, sp_low, sp_high); return FN_NONE; }
+        // a function identifier prints ALL its argument types (compile.rs:115-122, 300-320): the record holds four, the rest follow in
+        // continuation records (kind SE_Continuation: eight type ids in the words behind `kind`), which are no diagnostics of their own
+#define FN_REPORT(kind_) do { FN_IDENT(); report(kind_, sp_low, sp_high); \
+            for (uint32_t q_ = 4; q_ < n; q_ += 8) { SemErr ce_; ce_.kind = SE_Continuation; uint32_t* w_ = &ce_.low; \
+                for (uint32_t j_ = 0; j_ < 8; j_++) w_[j_] = q_ + j_ < n ? ARG_T(q_ + j_) : OPUSFE_NONE; \
+                if (nerrs < ecap) gst(errs + nerrs, ce_); else internal(); nerrs++; ncont++; } } while (0)
+        if (!nf.has) { FN_REPORT(SE_UndefinedFunction); return FN_NONE; }
         if (n > 64) { unsupported(); return FN_NONE; }
         uint32_t total = 0; candidate(name, slot, 0, &total);
         uint32_t first = FN_NONE; uint64_t ignorable = ~0ull;
@@ -572,7 +578,7 @@ struct Lowerer {
                 if ((ignorable >> i) & 1) if (!T().types_match_allow_generic(t2, t1)) ignorable &= ~(1ull << i);
             }
         }
-        if (first == FN_NONE) { FN_IDENT(); report(SE_NoOverloadForFunction, sp_low, sp_high); return FN_NONE; }
+        if (first == FN_NONE) { FN_REPORT(SE_NoOverloadForFunction); return FN_NONE; }
         for (uint32_t c = 0; c < total; c++) {
             uint32_t f = candidate(name, slot, c, &total);
             if (f == FN_NONE || !candidate_ok(f, argv, types_in, n)) continue;
@@ -585,9 +591,9 @@ struct Lowerer {
             }
             if (all) return f;
         }
-        FN_IDENT();
-        report(SE_AmbiguousOverload, sp_low, sp_high);
+        FN_REPORT(SE_AmbiguousOverload);
         return FN_NONE;
+#undef FN_REPORT
 #undef FN_IDENT
 #undef ARG_T
     }
@@ -1377,7 +1383,7 @@ __global__ MACHINE_ATTR(OPUSFE_LOWER_WAVES) __launch_bounds__(64) void k_lower_f
     L.lname = B.lname + lb; L.lvar = B.lvar + lb; L.nlocals = 0; L.lcap = (uint32_t)lower_cap(CAP_LOCALS, nn);
     L.lstack = B.lstack + lb; L.nstack = 0;
     L.frames = B.frames + lower_base(CAP_FRAMES, sb_n, sb_f); L.sp = 0; L.fcap = (uint32_t)lower_cap(CAP_FRAMES, nn);
-    L.errs = B.errs + lower_base(CAP_ERRS, sb_n, sb_f); L.nerrs = 0; L.ecap = (uint32_t)lower_cap(CAP_ERRS, nn); L.einfo_clear();
+    L.errs = B.errs + lower_base(CAP_ERRS, sb_n, sb_f); L.nerrs = 0; L.ncont = 0; L.ecap = (uint32_t)lower_cap(CAP_ERRS, nn); L.einfo_clear();
     L.bb_index = 0; L.break_head = OPUSFE_NONE; L.loop_begin = OPUSFE_NONE; L.dev_status = DS_OK;
     L.rv = 0; L.rl = false; L.rdiv = false; L.sym_locals = false;
     for (uint32_t j = lane; j < (LDS_VARS + 31) / 32; j += UNIT_LANES) L.lds.vnamed[j] = 0;
@@ -1402,7 +1408,7 @@ __global__ MACHINE_ATTR(OPUSFE_LOWER_WAVES) __launch_bounds__(64) void k_lower_f
     r.n_errs = L.nerrs < L.ecap ? L.nerrs : L.ecap; r.status = L.dev_status;
     out[fidx] = r;
     if (L.dev_status != DS_OK) atomicMax(status, L.dev_status);      // status = {max lane status, number of semantic errors}
-    if (L.nerrs) atomicAdd(status + 1, L.nerrs);
+    if (L.nerrs - L.ncont) atomicAdd(status + 1, L.nerrs - L.ncont);
 }
 
 // Place of a sequentially lowered function in the dense arrays (same bump allocation as the node-parallel path,
@@ -1453,7 +1459,13 @@ __global__ __launch_bounds__(256) void k_ir_compact(const FuncIr* __restrict__ f
         const uint32_t* sc = B.cargs + lower_base(CAP_CARGS, sb_n, sb_f);
         for (uint32_t j = lane; j < r.n_cargs; j += 64) O.cargs[r.carg_base + j] = sc[j];
         const SemErr* se = B.errs + lower_base(CAP_ERRS, sb_n, sb_f);
-        for (uint32_t j = lane; j < r.n_errs; j += 64) { SemErr e = se[j]; for (int q = 0; q < 4; q++) if (e.t[q] != OPUSFE_NONE) e.t[q] = REMAP_TYPE(e.t[q]); O.errs[r.err_base + j] = e; }
+        for (uint32_t j = lane; j < r.n_errs; j += 64) {
+            SemErr e = se[j];
+            uint32_t* w = e.kind == SE_Continuation ? &e.low : e.t;      // a continuation record is eight type ids
+            const int nw = e.kind == SE_Continuation ? 8 : 4;
+            for (int q = 0; q < nw; q++) if (w[q] != OPUSFE_NONE) w[q] = REMAP_TYPE(w[q]);
+            O.errs[r.err_base + j] = e;
+        }
         const uint64_t ib = lower_base(CAP_INSTRS, sb_n, sb_f);
         for (uint32_t j = lane; j < r.n_instrs; j += 64) {
             opusfe_instr in = B.instrs[ib + j];
@@ -1627,7 +1639,12 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
     HIP_TRY(hipStreamSynchronize(st));
     prof_collect(ctx);
     R->n_funcs = n_funcs; R->n_globals = n_globals; R->n_gtypes = n_gtypes;
-    static const bool seq_only = getenv("OPUSFE_LOWER_SEQ") != nullptr;     // debugging aid: everything through the sequential machine
+    // Diagnostic switches exist only in a -DOPUSFE_DIAG build (tools/par_*.sh): the shipped library has one behaviour.
+#ifdef OPUSFE_DIAG
+    static const bool seq_only = getenv("OPUSFE_LOWER_SEQ") != nullptr;     // everything through the sequential machine
+#else
+    constexpr bool seq_only = false;
+#endif
     const uint32_t big_nodes = seq_only ? 0u : ctx->h_status[WL_FBTOT], big_funcs = seq_only ? 0u : ctx->h_status[WL_FBTOT + 1];
     if (ctx->h_status[WL_FINERR] != 0) {   // frontend.rs:145: semantic errors while finalizing -> no IR
         R->n_sem_errors = ctx->h_status[WL_FINERR];
@@ -1686,9 +1703,11 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
         par::ParArgs PA{};
         PA.def_nodes = u->d_def_nodes; PA.n_defs = n_defs; PA.n_nodes = n_nodes; PA.def_excl = def_excl; PA.undefined_flag = undefined_flag; PA.user_syms = user_syms;
         PA.pp_base = pp_base; PA.out = R->d_funcs; PA.status = ctx->d_status + WL_STATUS;
+#ifdef OPUSFE_DIAG
         { static const char* sp = getenv("OPUSFE_PAR_STOP"); PA.stop_phase = sp ? (uint32_t)atoi(sp) : 0u; }
         { static const char* sr = getenv("OPUSFE_PAR_ROUNDS"); PA.stop_rounds = sr ? (uint32_t)atoi(sr) : 0u; }
         { static const char* cl = getenv("OPUSFE_PAR_CLIMB"); PA.climb = cl ? (uint32_t)atoi(cl) : 0u; }
+#endif
         PA.counters = counters; PA.overflow = (uint32_t*)(counters + par::CTR_COUNT); PA.err_counter = (uint32_t*)(counters + par::CTR_COUNT + 1);
         PA.cap_vars = cap[0]; PA.cap_instrs = cap[1]; PA.cap_bbs = cap[2]; PA.cap_types = cap[3]; PA.cap_cargs = cap[4]; PA.cap_errs = cap[5];
         PA.vars = R->d_vars; PA.instrs = R->d_instrs; PA.bb_offsets = R->d_bb_offsets; PA.cargs = R->d_cargs; PA.types_out = R->d_types;
@@ -1696,6 +1715,12 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
         // The sequential machine on the functions flagged in `flag` (sparse regions laid out by `idx`), then their places in the
         // dense arrays and the compaction into them; all on stream `ms`.
         TempList tmp2(ctx);       // the machine's sparse regions live for one attempt
+        // Declared behind the temporaries, so destroyed before them: if anything below throws while the second stream still runs the
+        // machine on tmp2's blocks (and writes R's arrays), both streams are drained before a block returns to the allocator.
+        struct ForkGuard {
+            opusfe_ctx* c; bool armed;
+            ~ForkGuard() { if (armed) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamSynchronize(c->stream); } }
+        } fork_guard{ctx, false};
         auto machine_pass = [&](hipStream_t ms, const uint32_t* flag, const FbIdx* idx, uint32_t nodes_total, uint32_t funcs_total, bool timed) -> bool {
             LowerBuffers B{};
             B.type_sparse_base = n_gtypes;
@@ -1735,12 +1760,17 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
         // the functions that are too large for the node-parallel path start at once, next to it
         HIP_TRY(hipEventRecord(ctx->ev_fork, st));
         HIP_TRY(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+        fork_guard.armed = true;
         if (big_funcs) { if (!machine_pass(ctx->stream2, big_flag, big_idx, big_nodes, big_funcs, false)) { HIP_TRY(hipStreamSynchronize(ctx->stream2)); return; } }
         {
             // One launch per half-octave size class (scan.h order_class_of_size): the LDS a workgroup reserves is sized for the largest
             // function of its class, so at most a third of it is unused.  Functions of 2048 nodes and more, and the ones the fast path
             // declines, go through the sequential machine.  OPUSFE_PAR_SHAPE=a,b,c overrides the thread counts of the three shapes.
+#ifdef OPUSFE_DIAG
             static const char* shape_env = getenv("OPUSFE_PAR_SHAPE");
+#else
+            constexpr const char* shape_env = nullptr;
+#endif
             uint32_t ts = 64, tm = 256, tl = 512;      // (only with OPUSFE_PAR_SHAPE)
             if (shape_env) sscanf(shape_env, "%u,%u,%u", &ts, &tm, &tl);
             static const char* const NAMES[12] = {"lower_par_64", "lower_par_96", "lower_par_128", "lower_par_192", "lower_par_256", "lower_par_384", "lower_par_512",
@@ -1771,7 +1801,11 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
                         best_waves = std::max(best_waves, resident[w]);
                     }
                     uint32_t w = 1;
-                    static const uint32_t slack = getenv("OPUSFE_PAR_SLACK") ? (uint32_t)atoi(getenv("OPUSFE_PAR_SLACK")) : 1u;      // (diagnostics)
+#ifdef OPUSFE_DIAG
+                    static const uint32_t slack = getenv("OPUSFE_PAR_SLACK") ? (uint32_t)atoi(getenv("OPUSFE_PAR_SLACK")) : 1u;
+#else
+                    constexpr uint32_t slack = 1u;
+#endif
                     while (w < 16 && resident[w] + slack < best_waves) w++;
                     threads = 64 * w;
                 }
@@ -1787,6 +1821,7 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
         }
         HIP_TRY(hipEventRecord(ctx->ev_join, ctx->stream2));
         HIP_TRY(hipStreamWaitEvent(st, ctx->ev_join, 0));
+        fork_guard.armed = false;      // from here on everything on `st` is ordered behind the second stream
         // the functions it declined
         LAUNCH(ctx, "fb_mark", k_fb_mark, grid_for(n_defs, 256), 256, R->d_funcs, n_funcs, u->d_def_nodes, n_defs, n_nodes, def_excl, u->d_nodes, fb_flag, fbx);
         prof_begin(ctx, "fb_scan");

@@ -2,7 +2,8 @@
 //
 // One workgroup lowers one function with ONE LANE PER AST NODE (strided); all per-node state lives in LDS.
 //
-//   structure   parent / subtree end / depth of every node of the function (nodes are in pre-order)
+//   structure   parent / subtree size / depth / pre-order rank of every node of the function (nodes arrive in the parser's
+//               creation order, not pre-order: none of this is index arithmetic)
 //   names       every local definition (arguments, `var`, `for` variables) goes to a small table; every name use finds
 //               its definition by (definition point <= use < end of the defining block): lookups are structural,
 //               no scope stack is walked (generate_ir.rs:176-185, 857-893)
@@ -1281,11 +1282,9 @@ __device__ __forceinline__ void lower_function(Fn& f) {
         f.cnt[2 * i] = 0; f.cnt[2 * i + 1] = 0; f.tail[2 * i] = TAIL_NONE; f.tail[2 * i + 1] = TAIL_NONE;
         if (f.A.undefined_flag[f.dn + i]) fallback(f);                                // UndefinedType somewhere in the function
     }
-    PAR_SYNC();
-    if (failed(f)) return;
+    if (par_sync_or(failed(f))) return;      // (uniform exit: every wave sees the same answer)
     for (uint32_t i = tid; i < nn; i += T) { uint32_t guard = 0; for (uint32_t c = f.fc[i]; c != NONE16 && guard <= nn; c = f.nx[c], guard++) f.pa[c] = (uint16_t)i; if (guard > nn) fallback(f); }
-    PAR_SYNC();
-    if (failed(f)) return;
+    if (par_sync_or(failed(f))) return;      // (uniform exit: every wave sees the same answer)
     if (f.A.stop_phase == 1) { fallback(f); return; }
     // Subtree sizes, depths and "dead" marks by one walk up the ancestor chain per node (the nodes arrive in creation order, not
     // pre-order, so none of this is index arithmetic).  Level-synchronous fixpoints did the same in height-of-the-tree rounds of
@@ -1303,8 +1302,7 @@ __device__ __forceinline__ void lower_function(Fn& f) {
         f.pe[i] = (uint16_t)depth;
         if (dead) f.st[i] = ST_DEAD;
     }
-    PAR_SYNC();
-    if (failed(f)) return;
+    if (par_sync_or(failed(f))) return;      // (uniform exit: every wave sees the same answer)
     if (f.A.stop_phase == 2) { fallback(f); return; }
     // every parent hands its children their offset from its own rank (1 + the sizes of the children before them)
     for (uint32_t p = tid; p < nn; p += T) {
@@ -1429,8 +1427,7 @@ __device__ __forceinline__ void lower_function(Fn& f) {
             if (loop != NONE16 && k == S_Break) lds_or(&f.st[loop], (uint32_t)ST_HASBREAK);
         }
     }
-    PAR_SYNC();
-    if (failed(f)) return;
+    if (par_sync_or(failed(f))) return;      // (uniform exit: every wave sees the same answer)
     {   // shadowing (generate_ir.rs:255,410,1009) and redefinition of an argument (Q17): the sequential machine handles those
         const uint32_t nd = f.misc[MI_NDEFS];
         for (uint32_t a = tid; a < nd; a += T) {
@@ -1506,8 +1503,7 @@ __device__ __forceinline__ void lower_function(Fn& f) {
         if (k == E_Operator && !(f.st[i] & ST_DEAD)) { const uint8_t sym = sym_of_op(SUB(f, i)); if ((f.user_syms >> sym) & 1) f.cg[i] = 2; }
         if (k == S_For) f.cg[i] = 3;
     }
-    PAR_SYNC();
-    if (failed(f)) return;
+    if (par_sync_or(failed(f))) return;      // (uniform exit: every wave sees the same answer)
     if (f.A.stop_phase == 5) { fallback(f); return; }
     // ---- nodes by kind (kind_class): the sweeps below go through the nodes in this order; nodes with nothing to lower are left out ----
     for (uint32_t k = tid; k < KC_COUNT; k += T) f.misc[MI_KHIST + k] = 0;

@@ -579,7 +579,8 @@ enum SErrKind : uint32_t { SE_ParseError, SE_UndefinedVariable, SE_ShadowedName,
     SE_AmbiguousFunctionReference, SE_UnexpectedType, SE_InvalidType, SE_InvalidOperandType, SE_InvalidOperandTypes, SE_FunctionMightNotReturn,
     SE_BreakOutsideLoop, SE_ContinueOutsideLoop, SE_InvalidLvalue, SE_ImmutableLvalue, SE_ArrayPointerToNonArray, SE_InvalidCast, SE_UndefinedType,
     SE_FieldAccessOnNonRecord, SE_FieldDoesNotExist, SE_CallOfNonFunction, SE_ReferenceToBuiltinFunction, SE_AttemptToCallOrIndexConstant,
-    SE_InvalidNumberOfArgs, SE_InvalidConstantExpression };
+    SE_InvalidNumberOfArgs, SE_InvalidConstantExpression,
+    SE_Continuation = 0x100 /* not a diagnostic: argument types 5.. of the function identifier of the record before it */ };
 
 // Contents of a type id as finalize_definition of the definition at node `at_def` sees them (compile.rs:1055-1062,
 // Q14): a `type` placeholder holds Type::Error until its own definition has been finalized, and an alias of an

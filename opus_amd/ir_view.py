@@ -11,6 +11,7 @@ from decimal import Decimal
 
 import numpy as np
 
+SEM_CONTINUATION = 0x100
 (A_SOURCE, A_TOKENS, A_VAL64, A_STRINGS, A_NODES, A_DEFINITIONS, A_SIGNATURES, A_GLOBALS, A_TYPES, A_NODE_TYPES, A_FUNCTIONS,
  A_VARIABLES, A_BB_OFFSETS, A_INSTRS, A_CALL_ARGS, A_SEM_ERRORS, A_PARENTS) = range(17)
 
@@ -211,7 +212,20 @@ class IrView:
         self.nodes, self.definitions = get(A_NODES), get(A_DEFINITIONS)
         self.signatures, self.globals, self.types, self.node_types = get(A_SIGNATURES), get(A_GLOBALS), get(A_TYPES), get(A_NODE_TYPES)
         self.functions, self.variables, self.bb_offsets = get(A_FUNCTIONS), get(A_VARIABLES), get(A_BB_OFFSETS)
-        self.instrs, self.call_args, self.sem_errors = get(A_INSTRS), get(A_CALL_ARGS), get(A_SEM_ERRORS)
+        self.instrs, self.call_args = get(A_INSTRS), get(A_CALL_ARGS)
+        # OPUSFE_A_SEM_ERRORS: the diagnostics in report order; a function identifier with more than four argument types
+        # (compile.rs:115-122) is followed by continuation records (kind 0x100: eight type ids behind `kind`)
+        raw = get(A_SEM_ERRORS)
+        keep = raw["kind"] != SEM_CONTINUATION
+        self.sem_errors = raw[keep]
+        self.sem_error_arg_types = []          # per diagnostic: every argument type id of its function identifier
+        words = raw.view(np.uint32).reshape(len(raw), 9) if len(raw) else np.zeros((0, 9), np.uint32)
+        for k in range(len(raw)):
+            if keep[k]:
+                n = int(raw[k]["nargs"])
+                self.sem_error_arg_types.append([int(x) for x in raw[k]["t"][:min(n, 4)]])
+            elif self.sem_error_arg_types:
+                self.sem_error_arg_types[-1] += [int(x) for x in words[k][1:9] if int(x) != 0xFFFFFFFF]
 
     def __len__(self):
         return len(self.functions)

@@ -6,7 +6,7 @@ semantic error kinds.  Those whose message needs nothing beyond the span are ren
 (``semantic_message``); those that print types, names or function identifiers (UnexpectedType, NoOverloadForFunction, ...,
 compile.rs:820-899 with TypePrinter / FunctionIdentifierPrinter, compile.rs:200-320) from the payload of the diagnostic record
 (``opusfe_semantic_error``: name, nargs, t[4]) and the unit's type arrays (``semantic_message_of_record``).  A function
-identifier with more than four argument types is not rendered (the record carries four).
+identifier prints all its argument types: the record carries four, continuation records the rest (ir_view.sem_error_arg_types).
 PARITY UNPINNED: the reference ships no expected outputs; tests/test_render.py holds strings derived by hand from the cited
 lines.  Pure host formatting: nothing here runs or replaces the GPU path.
 """
@@ -150,9 +150,11 @@ def _record_name(rec, view) -> str:
     return view.token_name(name)
 
 
-def semantic_message_of_record(rec, view):
-    """message line of compile.rs:816-915 for one opusfe_semantic_error record; `view` = Unit.ir_view() (types, tokens, source).
-    None when the record does not carry enough (a function identifier with more than four argument types)."""
+def semantic_message_of_record(rec, view, arg_types=None):
+    """message line of compile.rs:816-915 for one opusfe_semantic_error record; `view` = Unit.ir_view() (types, tokens, source);
+    `arg_types` = view.sem_error_arg_types[i] for record i (every argument type of a function identifier: the record itself holds
+    four, the rest come from its continuation records).  None when a function identifier has more than four argument types and
+    `arg_types` was not given."""
     kind, low, length = int(rec["kind"]), int(rec["low"]), int(rec["len"])
     plain = semantic_message(kind, view.source[low:low + length].decode("utf-8", errors="replace"))
     if plain is not None:
@@ -162,9 +164,13 @@ def semantic_message_of_record(rec, view):
         return f"shadowed variable: {_record_name(rec, view)}"
     if kind in (3, 4, 5):                                            # UndefinedFunction / NoOverloadForFunction / AmbiguousOverload :824-835
         n = int(rec["nargs"])
-        if n > 4:
+        if arg_types is None:
+            if n > 4:
+                return None
+            arg_types = [int(rec["t"][k]) for k in range(n)]
+        if len(arg_types) != n:
             return None
-        ident = f"{_record_name(rec, view)}[" + " ".join(":" + ty(k) for k in range(n)) + "]"      # FunctionIdentifierPrinter, compile.rs:302-319
+        ident = f"{_record_name(rec, view)}[" + " ".join(":" + view.type_text(t) for t in arg_types) + "]"      # FunctionIdentifierPrinter, compile.rs:302-319
         return ("undefined function: ", "no matching overload for function: ", "call to overloaded function is ambiguous: ")[kind - 3] + ident
     if kind == 7:                                                    # UnexpectedType :840
         return f"invalid type: expected {ty(0)}, found {ty(1)}"
@@ -185,10 +191,19 @@ def semantic_message_of_record(rec, view):
     return None
 
 
-def render_semantic_record(rec, view, filename: str, source: bytes = None, low: int = None) -> str:
+def render_unit_errors(unit, filename: str) -> str:
+    """everything the reference writes to stderr for this unit's errors (the parse error, else every semantic diagnostic in report
+    order): what the oracle's dump 6 restates independently (oracle_dump.cpp dump_rendered_errors)"""
+    if unit.status == 1:
+        return render_parse_error(unit, filename)
+    view = unit.ir_view()
+    return "".join(render_semantic_record(rec, view, filename, arg_types=view.sem_error_arg_types[i]) for i, rec in enumerate(view.sem_errors))
+
+
+def render_semantic_record(rec, view, filename: str, source: bytes = None, low: int = None, arg_types=None) -> str:
     """stderr text of one diagnostic record: message + print_span.  `source` / `low` override the unit's own source and position
     (a multi-file program renders the span inside the file it belongs to)."""
-    msg = semantic_message_of_record(rec, view)
+    msg = semantic_message_of_record(rec, view, arg_types)
     if msg is None:
         msg = f"<{SEMANTIC_NAMES[int(rec['kind'])]}>"
     src = view.source if source is None else source

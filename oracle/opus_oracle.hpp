@@ -188,7 +188,9 @@ enum class SErr : uint8_t { ParseError, UndefinedVariable, ShadowedName, Undefin
     UndefinedType, FieldAccessOnNonRecord, FieldDoesNotExist, CallOfNonFunction,
     ReferenceToBuiltinFunction, AttemptToCallOrIndexConstant, InvalidNumberOfArgs,
     InvalidConstantExpression };
-struct SemError { SErr kind; Span span; };
+// `message`: the line Compiler::print_error writes behind "Error: " (compile.rs:816-915), rendered WHEN the error is reported, as the
+// reference's report_error does (compile.rs:777-780 prints at once: TypePrinter sees the types as they are at that moment)
+struct SemError { SErr kind; Span span; std::string message; };
 
 enum class ValK : uint8_t { None, Integer, Error };
 struct Value { ValK kind = ValK::None; int64_t i = 0; };
@@ -237,7 +239,16 @@ struct Compiler {
     bool types_match(TypeId a, TypeId b) const;
     bool types_match_allow_generic(TypeId a, TypeId b) const;
     bool types_match_default_generic(TypeId a, TypeId b) const;
-    void report_error(SErr kind, Span span) const { errors.push_back({kind, span}); has_errors = true; }
+    // compile.rs:777-780 report_error; one overload per payload shape of compile.rs:124-152
+    void report(SErr kind, Span span, std::string message) const { errors.push_back({kind, span, std::move(message)}); has_errors = true; }
+    std::string span_text(Span s) const { return std::string(src_base + s.low, s.len); }
+    void report_error(SErr kind, Span span) const;                         // the kinds whose message prints at most the span text
+    void report_error(SErr kind, Span span, TypeId a) const;               // InvalidType :844, InvalidOperandType :848, FieldAccessOnNonRecord :888, CallOfNonFunction :896
+    void report_error(SErr kind, Span span, TypeId a, TypeId b) const;     // UnexpectedType {expected, found} :840, InvalidCast {from, to} :880
+    void report_operand_types(Span span, Op op, TypeId left, TypeId right) const;                                 // :852
+    void report_shadowed(Span span, std::string_view name) const;                                                // :820
+    void report_function(SErr kind, Span span, std::string_view name, const std::vector<TypeId>& args) const;   // :824-835, FunctionIdentifierPrinter :300-320
+    void report_field_missing(Span span, TypeId typ, std::string_view field) const;                              // :892
     TypeId resolve_type(const PType& t) const;
     void preload_definition(const Definition& d);
     Value make_value(const Expression& e);
@@ -306,5 +317,8 @@ std::string dump_ast(const Unit& u);
 std::string dump_ir(const Unit& u);
 std::string dump_error(const Unit& u);
 std::string dump_semantic_errors(const Unit& u);
+// what the reference writes to stderr for this unit's errors: compile.rs:782-917 print_error + frontend.rs:201-256 print_span
+// (the parse error, else every semantic error in report order); `filename` is what compiler.filenames[i] would print
+std::string dump_rendered_errors(const Unit& u, const std::string& filename);
 
 }  // namespace oracle

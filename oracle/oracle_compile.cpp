@@ -230,7 +230,7 @@ void Compiler::finalize_definition(const Definition& d) {
             if (d.value) {
                 Span span = expression_span(d.value.get());
                 value = make_value(*d.value);
-                if (!type_is_valid(value, typ)) { report_error(SErr::InvalidType, span); value = Value{ValK::Error, 0}; }
+                if (!type_is_valid(value, typ)) { report_error(SErr::InvalidType, span, typ); value = Value{ValK::Error, 0}; }
             }
             size_t id = globals.size();
             globals.emplace_back(typ, value); global_is_constant.push_back(false);
@@ -241,7 +241,7 @@ void Compiler::finalize_definition(const Definition& d) {
             TypeId typ = resolve_type(*d.type);
             Span span = expression_span(d.value.get());
             Value value = make_value(*d.value);
-            if (!type_is_valid(value, typ)) { report_error(SErr::InvalidType, span); value = Value{ValK::Error, 0}; }
+            if (!type_is_valid(value, typ)) { report_error(SErr::InvalidType, span, typ); value = Value{ValK::Error, 0}; }
             size_t id = globals.size();
             globals.emplace_back(typ, value); global_is_constant.push_back(true);
             global_resolution_map[d.name] = id;
@@ -257,10 +257,71 @@ void Compiler::finalize_definition(const Definition& d) {
     }
 }
 
+// ---- report_error + the message lines of print_error (compile.rs:777-780, 816-915) ----
+void Compiler::report_error(SErr kind, Span span) const {
+    std::string m;
+    switch (kind) {
+        case SErr::UndefinedVariable: m = "undefined variable: " + span_text(span); break;                       // :816
+        case SErr::AmbiguousFunctionReference: m = "reference to overloaded function is ambiguous"; break;      // :836
+        case SErr::FunctionMightNotReturn: m = "function might not return"; break;                              // :856
+        case SErr::BreakOutsideLoop: m = "break outside loop"; break;                                           // :860
+        case SErr::ContinueOutsideLoop: m = "continue outside loop"; break;                                     // :864
+        case SErr::InvalidLvalue: m = "invalid lvalue"; break;                                                  // :868
+        case SErr::ImmutableLvalue: m = "lvalue is immutable"; break;                                           // :872
+        case SErr::ArrayPointerToNonArray: m = "attempt to take array reference to non-array lvalue"; break;    // :876
+        case SErr::UndefinedType: m = "undefined type: " + span_text(span); break;                              // :884
+        case SErr::ReferenceToBuiltinFunction: m = "refernce to built-in function"; break;                      // :900 (sic)
+        case SErr::AttemptToCallOrIndexConstant: m = "attempt to call or index constant"; break;                // :904
+        case SErr::InvalidNumberOfArgs: m = "invalid number of indices"; break;                                 // :908
+        case SErr::InvalidConstantExpression: m = "invalid constant expression"; break;                         // :912
+        default: m = "<payload missing>"; break;      // a typed kind reported without its payload: a bug of the restatement, visible in every comparison
+    }
+    report(kind, span, std::move(m));
+}
+void Compiler::report_error(SErr kind, Span span, TypeId a) const {
+    std::string m;
+    switch (kind) {
+        case SErr::InvalidType: m = "invalid type: " + type_to_string(a); break;                                  // :844
+        case SErr::InvalidOperandType: m = "invalid operand type: " + type_to_string(a); break;                   // :848
+        case SErr::FieldAccessOnNonRecord: m = "attempt to set or access field of non-record: " + type_to_string(a); break;   // :888
+        case SErr::CallOfNonFunction: m = "cannot call value of type " + type_to_string(a); break;                // :896
+        default: m = "<payload mismatch>"; break;
+    }
+    report(kind, span, std::move(m));
+}
+void Compiler::report_error(SErr kind, Span span, TypeId a, TypeId b) const {
+    std::string m;
+    switch (kind) {
+        case SErr::UnexpectedType: m = "invalid type: expected " + type_to_string(a) + ", found " + type_to_string(b); break;   // :840
+        case SErr::InvalidCast: m = "invalid cast: " + type_to_string(a) + " to " + type_to_string(b); break;                   // :880
+        default: m = "<payload mismatch>"; break;
+    }
+    report(kind, span, std::move(m));
+}
+void Compiler::report_operand_types(Span span, Op op, TypeId left, TypeId right) const {                        // :852
+    report(SErr::InvalidOperandTypes, span, "invalid operand types: " + type_to_string(left) + " " + op_symbol(op) + " " + type_to_string(right));
+}
+void Compiler::report_shadowed(Span span, std::string_view name) const {                                       // :820
+    report(SErr::ShadowedName, span, "shadowed variable: " + std::string(name));
+}
+void Compiler::report_function(SErr kind, Span span, std::string_view name, const std::vector<TypeId>& args) const {
+    // FunctionIdentifierPrinter compile.rs:300-320: name[ :T :T ... ]
+    std::string id = std::string(name) + "[";
+    for (size_t i = 0; i < args.size(); i++) { if (i) id += " "; id += ":" + type_to_string(args[i]); }
+    id += "]";
+    const char* head = kind == SErr::UndefinedFunction ? "undefined function: "                                   // :824
+                     : kind == SErr::NoOverloadForFunction ? "no matching overload for function: "               // :828
+                     : "call to overloaded function is ambiguous: ";                                             // :832
+    report(kind, span, head + id);
+}
+void Compiler::report_field_missing(Span span, TypeId typ, std::string_view field) const {                     // :892
+    report(SErr::FieldDoesNotExist, span, "type " + type_to_string(typ) + " has no field named '" + std::string(field) + "'");
+}
+
 // compile.rs:1083-1139
 FunctionId Compiler::lookup_function(Span span, std::string_view name, const std::vector<TypeId>& argument_types) const {
     auto it = name_resolution_map.find(name);
-    if (it == name_resolution_map.end()) { report_error(SErr::UndefinedFunction, span); return nullptr; }
+    if (it == name_resolution_map.end()) { report_function(SErr::UndefinedFunction, span, name, argument_types); return nullptr; }
     std::vector<FunctionId> candidates;
     for (FunctionId f : it->second) {
         if (f->arguments.size() != argument_types.size()) continue;
@@ -269,7 +330,7 @@ FunctionId Compiler::lookup_function(Span span, std::string_view name, const std
             if (!can_autocast(argument_types[i], f->arguments[i]).has_value()) { all = false; break; }
         if (all) candidates.push_back(f);
     }
-    if (candidates.empty()) { report_error(SErr::NoOverloadForFunction, span); return nullptr; }
+    if (candidates.empty()) { report_function(SErr::NoOverloadForFunction, span, name, argument_types); return nullptr; }
     FunctionId candidate1 = candidates[0];
     std::vector<bool> ignorable(argument_types.size(), true);
     for (FunctionId c : candidates)
@@ -283,7 +344,7 @@ FunctionId Compiler::lookup_function(Span span, std::string_view name, const std
         }
         if (all) return f;
     }
-    report_error(SErr::AmbiguousOverload, span);
+    report_function(SErr::AmbiguousOverload, span, name, argument_types);
     return nullptr;
 }
 

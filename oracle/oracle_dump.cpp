@@ -94,6 +94,43 @@ static std::string rust_debug_bytes_as_str(const uint8_t* p, size_t n) {
     out += "\"";
     return out;
 }
+// String::from_utf8_lossy alone (parse.rs:113-116 prints a String token through it): valid sequences verbatim, U+FFFD per maximal invalid subpart
+static std::string utf8_lossy(const uint8_t* p, size_t n) {
+    std::string out;
+    size_t i = 0;
+    while (i < n) {
+        const uint8_t b0 = p[i];
+        if (b0 < 0x80) { out += (char)b0; i++; continue; }
+        size_t need = 0; uint8_t lo = 0x80, hi = 0xBF;
+        if (b0 >= 0xC2 && b0 <= 0xDF) need = 1;
+        else if (b0 == 0xE0) { need = 2; lo = 0xA0; }
+        else if ((b0 >= 0xE1 && b0 <= 0xEC) || b0 == 0xEE || b0 == 0xEF) need = 2;
+        else if (b0 == 0xED) { need = 2; hi = 0x9F; }
+        else if (b0 == 0xF0) { need = 3; lo = 0x90; }
+        else if (b0 >= 0xF1 && b0 <= 0xF3) need = 3;
+        else if (b0 == 0xF4) { need = 3; hi = 0x8F; }
+        else { out += "\xEF\xBF\xBD"; i++; continue; }
+        size_t k = 1; bool ok = true;
+        for (; k <= need; k++) {
+            if (i + k >= n) { ok = false; break; }
+            const uint8_t b = p[i + k], l = k == 1 ? lo : 0x80, h = k == 1 ? hi : 0xBF;
+            if (b < l || b > h) { ok = false; break; }
+        }
+        if (!ok) { out += "\xEF\xBF\xBD"; i += k; continue; }
+        out.append((const char*)p + i, need + 1);
+        i += need + 1;
+    }
+    return out;
+}
+static size_t utf8_len(uint8_t b0) { return b0 < 0x80 ? 1 : b0 >= 0xF0 ? 4 : b0 >= 0xE0 ? 3 : b0 >= 0xC0 ? 2 : 1; }
+static std::string utf8_encode(uint32_t c) {      // char Display
+    std::string s;
+    if (c < 0x80) s += (char)c;
+    else if (c < 0x800) { s += (char)(0xC0 | (c >> 6)); s += (char)(0x80 | (c & 0x3F)); }
+    else if (c < 0x10000) { s += (char)(0xE0 | (c >> 12)); s += (char)(0x80 | ((c >> 6) & 0x3F)); s += (char)(0x80 | (c & 0x3F)); }
+    else { s += (char)(0xF0 | (c >> 18)); s += (char)(0x80 | ((c >> 12) & 0x3F)); s += (char)(0x80 | ((c >> 6) & 0x3F)); s += (char)(0x80 | (c & 0x3F)); }
+    return s;
+}
 static std::string rust_debug_str(std::string_view s) { return rust_debug_bytes_as_str((const uint8_t*)s.data(), s.size()); }
 static std::string bytes_debug(const std::vector<uint8_t>& b) {
     std::string s = "[";
@@ -154,6 +191,76 @@ std::string dump_error(const Unit& u) {
 std::string dump_semantic_errors(const Unit& u) {
     std::string out;
     for (auto& e : u.compiler->errors) out += std::string(SERR_NAMES[(int)e.kind]) + " " + std::to_string(e.span.low) + " " + std::to_string(e.span.len) + "\n";
+    return out;
+}
+
+// ---- error rendering: what the reference writes to stderr ----
+// parse.rs:69-158 impl Display for Token
+static std::string token_display(const Token& t) {
+    static const char* TEXT[] = {"(", ")", "[", "]", "{", "}", ":", "=", "==", "<", ">", "<=", ">=", "+", "-", "*", "/", "%", "@", "\xC2\xAF" /* U+00AF */, ".", ",", "?",
+        nullptr, nullptr, nullptr, nullptr, "<indent>", "<dedent>", "var", "const", "return", "if", "else", "while", "for", "break", "continue", "extern",
+        "ref", "mut", "refs", "muts", "null", "false", "true", "type", "record", "is", "in", "and", "or", "not", "sizeof", "alignof", "import", "library",
+        "proc", "operator", "<end of file>"};
+    switch (t.kind) {
+        case Tok::Integer:
+            if (!t.has_meta) return std::to_string(t.ival);                                                               // :93-96
+            if (t.size == 0) return std::to_string(t.ival) + (t.is_signed ? "o" : "s");                                 // :98-100
+            return std::to_string(t.ival) + (t.is_signed ? "i" : "n") + std::to_string(t.size);                          // :101
+        case Tok::Float: return f64_display(t.fval) + (t.has_meta ? "f" + std::to_string(t.size) : std::string());       // :105-112
+        case Tok::String: return utf8_lossy(t.bytes.data(), t.bytes.size());                                            // :113-116
+        case Tok::Identifier: return std::string(t.ident);
+        default: return TEXT[(int)t.kind];
+    }
+}
+// the line behind "Error: " for a parse::Error (compile.rs:788-815)
+static std::string parse_error_message(const ParseError& e) {
+    switch (e.kind) {
+        case PErr::UnexpectedCharacter: return "unexpected character: " + utf8_encode(e.ch);
+        case PErr::UnexpectedEndOfFile: return "unexpected end of file";
+        case PErr::InvalidEscapeSequence: return "invalid escape sequence";
+        case PErr::UnexpectedToken: return "unexpected token: " + token_display(e.found);
+        case PErr::ExpectedFoundToken: return "unexpected token: expected " + token_display(e.expected) + ", found " + token_display(e.found);
+        case PErr::ExpectedIdentifier: return "unexpected token: expected name, found " + token_display(e.found);
+        default: return "invalid numeric size: " + std::to_string(e.size);
+    }
+}
+static std::string pad4(size_t n) { std::string s = std::to_string(n); while (s.size() < 4) s = " " + s; return s; }      // {:>4}
+// frontend.rs:201-256 print_span, for the one source the span lies in (:204-208 finds it by pointer distance)
+static std::string print_span(const std::string& filename, const std::string& source, Span span) {
+    const char* RED = "\x1b[31;1m"; const char* YEL = "\x1b[33m"; const char* RST = "\x1b[0m";
+    const size_t low = span.low, high = span.low + span.len;
+    std::string out = std::string(YEL) + filename + ":" + RST + "\n";                                                      // :209
+    size_t line_low = 0, line_number = 1, position = 0;
+    while (position < low) {                                                                                              // :216-225 (per character; '\n' is one byte)
+        const bool nl = source[position] == '\n';
+        position += utf8_len((uint8_t)source[position]);
+        if (nl) { line_number++; line_low = position; }
+    }
+    size_t line_high = high;
+    while (line_high < source.size() && source[line_high] != '\n') line_high += utf8_len((uint8_t)source[line_high]);      // :226-232
+    if (line_high > source.size()) line_high = source.size();
+    out += std::string(YEL) + pad4(line_number) + ":" + RST + " ";                                                        // :234
+    for (size_t i = line_low; i < line_high;) {                                                                           // :235-253
+        const size_t L = utf8_len((uint8_t)source[i]);
+        if (i == low) out += RED; else if (i == high) out += RST;
+        const char c = source[i];
+        if (c == '\t') out += "    ";
+        else if (c == '\n') {
+            line_number++;
+            out += std::string("\n") + YEL + pad4(line_number) + ":" + RST + " ";
+            if (i >= low && i < high) out += RED;
+        } else out.append(source, i, L);
+        i += L;
+    }
+    out += std::string(RST) + "\n";                                                                                       // :254
+    return out;
+}
+std::string dump_rendered_errors(const Unit& u, const std::string& filename) {
+    const std::string head = "\x1b[31;1mError:\x1b[0m ";                                                                 // compile.rs:786
+    if (u.unsupported) return "Unsupported\n";
+    if (u.has_parse_error) return head + parse_error_message(u.parse_error) + "\n" + print_span(filename, u.source, u.parse_error.span);
+    std::string out;
+    for (auto& e : u.compiler->errors) out += head + e.message + "\n" + print_span(filename, u.source, e.span);
     return out;
 }
 
@@ -376,7 +483,7 @@ static char* dup_string(const std::string& s) {
     return p;
 }
 
-// what: 0 tokens, 1 ast, 2 ir, 3 error, 4 semantic errors
+// what: 0 tokens, 1 ast, 2 ir, 3 error, 4 semantic errors, 5 lexer alone, 6 the stderr text of print_error + print_span (file name "input.opus")
 char* oracle_dump(const char* src, uint64_t len, int what, uint64_t* out_len) {
     if (what == 5) {   // lexer alone
         oracle::Unit u;
@@ -387,7 +494,7 @@ char* oracle_dump(const char* src, uint64_t len, int what, uint64_t* out_len) {
         if (out_len) *out_len = s.size();
         return dup_string(s);
     }
-    auto u = oracle::run(src, len, what == 2 || what == 4);
+    auto u = oracle::run(src, len, what == 2 || what == 4 || what == 6);
     std::string s;
     switch (what) {
         case 0: s = oracle::dump_tokens(*u); break;
@@ -395,6 +502,7 @@ char* oracle_dump(const char* src, uint64_t len, int what, uint64_t* out_len) {
         case 2: s = oracle::dump_ir(*u); break;
         case 3: s = oracle::dump_error(*u); break;
         case 4: s = oracle::dump_semantic_errors(*u); break;
+        case 6: s = oracle::dump_rendered_errors(*u, "input.opus"); break;
     }
     if (out_len) *out_len = s.size();
     return dup_string(s);

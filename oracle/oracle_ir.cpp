@@ -89,7 +89,7 @@ struct IrGenerator {
             Instruction i = ins(IK::Cast, r, variable); i.cast = *cast_type; push(i);
             return r;
         }
-        compiler.report_error(SErr::UnexpectedType, sp);
+        compiler.report_error(SErr::UnexpectedType, sp, expected_type, found_type);
         return generate_error();
     }
 
@@ -109,7 +109,7 @@ struct IrGenerator {
             case SK::VariableDefinition: {
                 VariableId v = generate_ir_from_expression(*st.a, nullptr);
                 TypeId typ = variables[v].typ;
-                if (contains_local(st.name)) compiler.report_error(SErr::ShadowedName, sspan);
+                if (contains_local(st.name)) compiler.report_shadowed(sspan, st.name);
                 else {
                     VariableId nv = new_variable(compiler.type_mut(typ), false);
                     push(ins(IK::Allocate, nv));
@@ -181,7 +181,7 @@ struct IrGenerator {
                 size_t scope = begin_scope();
                 TypeId pointer_type = st.type ? compiler.type_mut(compiler.resolve_type(*st.type)) : compiler.type_primitive(PrimitiveType::Generic);
                 VariableId iteration_variable;
-                if (contains_local(st.name)) { compiler.report_error(SErr::ShadowedName, sspan); iteration_variable = generate_error(); }
+                if (contains_local(st.name)) { compiler.report_shadowed(sspan, st.name); iteration_variable = generate_error(); }
                 else {
                     iteration_variable = new_variable(pointer_type, false);
                     push(ins(IK::Allocate, iteration_variable));
@@ -309,7 +309,7 @@ struct IrGenerator {
                                 push(ins(IK::Equals, v, l, r));
                                 return v;
                             }
-                            compiler.report_error(SErr::InvalidOperandTypes, espan);
+                            compiler.report_operand_types(espan, op, lt, rt);
                             return generate_error();
                         }
                         case Op::And: case Op::Or: {
@@ -322,7 +322,7 @@ struct IrGenerator {
                             VariableId then_var = generate_ir_from_expression(*e.b, compiler.type_bool());
                             TypeId then_type = variables[then_var].typ;
                             if (!compiler.types_match(then_type, compiler.type_bool())) {
-                                compiler.report_error(SErr::InvalidOperandType, compiler.expression_span(e.b.get()));
+                                compiler.report_error(SErr::InvalidOperandType, compiler.expression_span(e.b.get()), then_type);
                                 return generate_error();
                             }
                             size_t then_end = bb_index;
@@ -374,7 +374,7 @@ struct IrGenerator {
                     Instruction i = ins(IK::Cast, nv, v); i.cast = *ct; push(i);
                     return nv;
                 }
-                compiler.report_error(SErr::InvalidCast, espan);
+                compiler.report_error(SErr::InvalidCast, espan, old_type, typ);
                 return generate_error();
             }
             case EK::Reference: return generate_pointer_from_expression(*e.a, PointerType::Reference);
@@ -399,7 +399,7 @@ struct IrGenerator {
                         throw Unsupported{"negate of <integer> not preceded by an Integer instruction (reference: unreachable!())", espan.low};
                     }
                     case TyK::Error: return generate_error();
-                    default: compiler.report_error(SErr::InvalidOperandType, espan); return generate_error();
+                    default: compiler.report_error(SErr::InvalidOperandType, espan, subtype); return generate_error();
                 }
             }
             case EK::Sizeof: case EK::Alignof: {
@@ -434,7 +434,7 @@ struct IrGenerator {
             compiler.report_error(SErr::ArrayPointerToNonArray, sp); return generate_error();
         }
         if (typ->kind == TyK::Error) return generate_error();
-        compiler.report_error(SErr::InvalidOperandType, sp);
+        compiler.report_error(SErr::InvalidOperandType, sp, typ);
         return generate_error();
     }
 
@@ -492,7 +492,7 @@ struct IrGenerator {
                 TypeId result_type;
                 if (pt2 == PointerType::Array) result_type = compiler.type_refs(subtype);
                 else if (pt2 == PointerType::ArrayMutable) result_type = compiler.type_muts(subtype);
-                else { compiler.report_error(SErr::InvalidOperandType, indexee_span); return {generate_error(), true}; }
+                else { compiler.report_error(SErr::InvalidOperandType, indexee_span, indexee_type); return {generate_error(), true}; }
                 VariableId rv = new_variable(result_type, true);
                 push(ins(IK::IndexPointer, rv, indexee, index));
                 var = try_cast_pointer(rv, pt, indexee_span);
@@ -526,7 +526,7 @@ struct IrGenerator {
                 break;
             }
             default:
-                compiler.report_error(SErr::InvalidOperandType, indexee_span);
+                compiler.report_error(SErr::InvalidOperandType, indexee_span, indexee_type);
                 var = generate_error();
         }
         return {var, is_lvalue};
@@ -562,7 +562,7 @@ struct IrGenerator {
                 break;
             }
             case EK::VariableDefinition: {
-                if (contains_local(e.name)) { compiler.report_error(SErr::ShadowedName, sp); var = generate_error(); }
+                if (contains_local(e.name)) { compiler.report_shadowed(sp, e.name); var = generate_error(); }
                 else {
                     TypeId typ = compiler.resolve_type(*e.type);
                     VariableId v = new_variable(compiler.type_mut(typ), false);
@@ -654,18 +654,18 @@ struct IrGenerator {
                 Instruction i = ins(IK::Field, rv, rec); i.field = field_name; push(i);
                 return rv;
             }
-            compiler.report_error(SErr::FieldDoesNotExist, sp); return generate_error();
+            compiler.report_field_missing(sp, typ, field_name); return generate_error();
         }
         if (typ->kind == TyK::String) {
             size_t idx; TypeId ft;
             if (field_name == "data") { idx = 0; ft = compiler.type_refs(compiler.type_primitive(PrimitiveType::Natural8)); }
             else if (field_name == "length") { idx = 1; ft = compiler.type_primitive(PrimitiveType::Size); }
-            else { compiler.report_error(SErr::FieldDoesNotExist, sp); return generate_error(); }
+            else { compiler.report_field_missing(sp, typ, field_name); return generate_error(); }
             VariableId rv = new_variable(compiler.type_pointer(pt, ft), true);
             Instruction i = ins(IK::BuiltinField, rv, rec); i.i1 = idx; push(i);
             return rv;
         }
-        compiler.report_error(SErr::FieldAccessOnNonRecord, sp);
+        compiler.report_error(SErr::FieldAccessOnNonRecord, sp, typ);
         return generate_error();
     }
 
@@ -679,7 +679,7 @@ struct IrGenerator {
             VariableId nv = new_variable(typ, true);
             push(ins(IK::Load, nv, variable));
             if (typ->kind == TyK::Function) return Lookup{nv, &typ->args, typ->ret, false};
-            compiler.report_error(SErr::CallOfNonFunction, sp);
+            compiler.report_error(SErr::CallOfNonFunction, sp, typ);
             return std::nullopt;
         }
         if (FunctionId f = compiler.lookup_function(sp, name, argument_types)) {

@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_SO = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
 GEN_SO = os.path.join(ROOT, "tools", "_build", "libopusgen.so")
 
-TOKENS, AST, IR, ERROR, SEM, LEX = 0, 1, 2, 3, 4, 5
+TOKENS, AST, IR, ERROR, SEM, LEX, RENDERED = 0, 1, 2, 3, 4, 5, 6
 
 
 class Counts(C.Structure):

@@ -90,3 +90,19 @@ def test_kats2_ir_and_diagnostics(case):
     assert O.dump(src, O.SEM).splitlines() == case["errors"]
     if case["ast_contains"]:
         assert case["ast_contains"] in O.dump(src, O.AST)
+
+
+# ---- round 3: hand-derived TOKEN + AST + SPAN cases (tests/golden/make_kats3.py) ----
+with open(os.path.join(HERE, "golden", "kats3.json")) as f:
+    KATS3 = json.load(f)["cases"]
+
+
+@pytest.mark.parametrize("case", KATS3, ids=[c["name"] for c in KATS3])
+def test_kats3_tokens_ast_spans_and_error_tuples(case):
+    src = case["src"].encode()
+    if "tokens" in case:
+        assert O.dump(src, O.TOKENS) == case["tokens"]
+    if "ast" in case:
+        assert O.dump(src, O.AST) == case["ast"]
+    assert O.dump(src, O.ERROR) == case.get("error", "Ok\n")
+

@@ -120,3 +120,26 @@ def test_resync_pass_limit_is_unsupported_not_wrong(fe):
     assert u.status == 0 and u.resync_passes() == 16 and u.dump_ast() == O.dump(src(16), O.AST)
     assert u.compile_source() == 0 and u.dump_ir() == O.dump(src(16), O.IR)
     assert fe.get_definitions(src(17)).status == 2
+
+
+with open(os.path.join(HERE, "golden", "kats3.json")) as f:
+    KATS3 = json.load(f)["cases"]
+
+
+@pytest.mark.parametrize("case", KATS3, ids=[c["name"] for c in KATS3])
+def test_kats3_gpu_against_the_hand_derived_text(fe, case):
+    """the HIP path against the hand-derived token / AST / span text directly (no oracle in between), on both parsers"""
+    src = case["src"].encode()
+    for mode in (0, 1):
+        fe.set_parser_mode(mode)
+        try:
+            u = fe.get_definitions(src)
+            if "tokens" in case:
+                assert u.dump_tokens() == case["tokens"]
+            if "ast" in case:
+                assert u.dump_ast() == case["ast"]
+            assert u.dump_error() == case.get("error", "Ok\n")
+            u.close()
+        finally:
+            fe.set_parser_mode(0)
+

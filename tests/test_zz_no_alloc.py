@@ -36,7 +36,9 @@ def test_static_entry_point_matches_the_allocating_one(fe):
         d = torch.frombuffer(bytearray(src) + bytearray(16), dtype=torch.uint8).cuda()
         torch.cuda.synchronize()
         want = fe.shard_ctx(d.data_ptr(), len(src))
+        held = fe.memory_held()
         fe.shard_ctx_static(d.data_ptr(), len(src), out.data_ptr() + 4 * k)
+        assert fe.memory_held() == held, "the static entry point took memory from the context's allocator"
         stream.synchronize()
         got = int(out[k].item()) & 0xFFFFFFFF
         assert got == want, (k, hex(got), hex(want))
@@ -51,3 +53,23 @@ def test_static_entry_point_rejects_ranges_beyond_its_scratch(fe):
     with pytest.raises(opus_amd.OpusfeError) as e:
         fe.shard_ctx_static(d.data_ptr(), (1 << 30) + 1, out.data_ptr())     # rejected before anything is launched
     assert e.value.code == opus_amd.frontend.ERR_ARG and "1 GiB" in str(e.value)
+
+
+def test_static_entry_point_on_a_context_that_never_allocated():
+    """the property the entry point exists for: a fresh context (no allocating call before it) serves it, and holds no device
+    memory afterwards"""
+    import opus_amd
+    src = b'f() null\n\tvar t = "a;b" ; comment "\n' * 300 + b'"tail'
+    d = torch.frombuffer(bytearray(src) + bytearray(16), dtype=torch.uint8).cuda()
+    out = torch.zeros(1, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    c = opus_amd.Context(0)
+    try:
+        assert c.memory_held() == 0
+        c.shard_ctx_static(d.data_ptr(), len(src), out.data_ptr())
+        torch.cuda.ExternalStream(c.stream()).synchronize()
+        assert c.memory_held() == 0
+        assert (int(out[0].item()) & 0xFFFFFFFF) == ctx_fn_cpu(src)
+    finally:
+        c.close()
+

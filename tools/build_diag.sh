@@ -1,0 +1,8 @@
+#!/bin/bash
+# Builds opus_amd/_build/libopusfe_diag.so with -DOPUSFE_DIAG: the diagnostic switches of run_lower (OPUSFE_PAR_STOP, OPUSFE_PAR_ROUNDS,
+# OPUSFE_PAR_CLIMB, OPUSFE_PAR_SHAPE, OPUSFE_PAR_SLACK, OPUSFE_LOWER_SEQ) exist only in this build; the tools/par_*.sh scripts load it
+# through OPUSFE_LIB.  The shipped libopusfe.so reads none of them.
+set -e
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -pthread -DOPUSFE_DIAG -I $ROOT/include -shared -o $ROOT/opus_amd/_build/libopusfe_diag.so $ROOT/opus_amd/csrc/api.hip
+echo $ROOT/opus_amd/_build/libopusfe_diag.so

@@ -1,4 +1,6 @@
 #!/bin/bash
+# needs the diagnostic build: run tools/build_diag.sh first; the switches below do nothing in the shipped library
+export OPUSFE_LIB=${OPUSFE_LIB:-$(cd "$(dirname "$0")/.." && pwd)/opus_amd/_build/libopusfe_diag.so}
 # Cumulative cost of the phases of the node-parallel lowering (lower_par.h): runs bench.py with OPUSFE_PAR_STOP=n
 # (the kernel leaves after phase n; everything then falls back to the sequential machine) and prints the kernel times.
 BYTES=${1:-256e6}

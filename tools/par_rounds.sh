@@ -1,4 +1,6 @@
 #!/bin/bash
+# needs the diagnostic build: run tools/build_diag.sh first; the switches below do nothing in the shipped library
+export OPUSFE_LIB=${OPUSFE_LIB:-$(cd "$(dirname "$0")/.." && pwd)/opus_amd/_build/libopusfe_diag.so}
 # time of the node-parallel lowering kernels when the type fixpoint is cut after n rounds (then stop before the scans)
 BYTES=${1:-256e6}
 for r in 1 2 4 8 12 16 24 32 48 64 0; do

@@ -1,4 +1,6 @@
 #!/bin/bash
+# needs the diagnostic build: run tools/build_diag.sh first; the switches below do nothing in the shipped library
+export OPUSFE_LIB=${OPUSFE_LIB:-$(cd "$(dirname "$0")/.." && pwd)/opus_amd/_build/libopusfe_diag.so}
 # lowering kernel times for several workgroup shapes (threads for the S,M,L size classes)
 BYTES=${1:-256e6}
 for sh in 64,128,256 64,256,512 64,128,512 128,256,512 64,64,128 64,64,256; do
