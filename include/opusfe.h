@@ -137,6 +137,12 @@ int opusfe_shard_lex(opusfe_ctx* ctx, const uint8_t* d_src, uint64_t len, uint32
                      uint64_t* n_tokens, uint64_t* tail_kinds);
 int opusfe_shard_net_depth(opusfe_shard* shard, uint64_t prev_kinds, int64_t* net);
 int opusfe_shard_boundary(opusfe_shard* shard, int64_t depth_in, uint64_t* pos);
+/* the whole fixed-size carry of a shard in one call (context function, token count, tail / head token kinds, net bracket depth,
+   first top-level segment start, length, look-back flag: uint64_t carry[8]), computed speculatively for the common entry
+   (context N, depth 0): what ONE all-gather of 64 bytes per rank exchanges.  Every rank can verify every rank's
+   speculation from the gathered carries alone; only when it fails is the dependent chain above needed.  `*out` as for
+   opusfe_shard_lex.  No counterpart in the reference. */
+int opusfe_shard_carry(opusfe_ctx* ctx, const uint8_t* d_src, uint64_t len, uint64_t* carry, opusfe_shard** out);
 void opusfe_shard_free(opusfe_shard* shard);
 /* own (+) hdr: a new parsed unit whose definition order is hdr's definitions that start before byte `split_pos` of hdr's
    source, then own's, then the rest of hdr's; arrays concatenated and re-based on the GPU (no second parse of `own`).
@@ -181,9 +187,14 @@ int opusfe_memory_held(opusfe_ctx* ctx, uint64_t* bytes);
 
 /* ---- results ---- */
 /* number of resync passes opusfe_parse took for this unit (0 for well-formed input).  A byte-range shard of a
-   larger source that needed one cannot be combined with its neighbours: behind the resync point the reference's lexer
-   contexts differ from the ones the shard carries were computed with (opus_amd/shard.py reports OPUSFE_UNSUPPORTED). */
+   larger source that needed one combines with its neighbours only if the lexer is back in code context at depth 0 at its end
+   (opusfe_unit_end_state); else opus_amd/shard.py reports OPUSFE_UNSUPPORTED. */
 int opusfe_unit_resync_passes(const opusfe_unit* unit, uint32_t* n);
+/* the lexer state behind the unit's last byte as the reference's lexer has it (parse.rs:364-391) after every resync pass: context
+   (0 code, 1-4 inside a string, 5 comment) and the bracket counter `ignore_dents`.  A byte-range shard that needed a resync pass
+   composes with its right neighbour exactly when this is (0 or 5, 0): the reference then lexes the neighbour's bytes as the shard
+   carries assumed (opus_amd/shard.py). */
+int opusfe_unit_end_state(const opusfe_unit* unit, uint32_t* ctx_state, int32_t* depth);
 int opusfe_unit_status(const opusfe_unit* unit);           /* OPUSFE_OK / _SYNTAX / _UNSUPPORTED ... of the unit */
 int opusfe_get_counts(const opusfe_unit* unit, opusfe_counts* out);
 int opusfe_get_error(const opusfe_unit* unit, opusfe_error* out);

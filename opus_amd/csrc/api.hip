@@ -29,7 +29,7 @@ using namespace opusfe;
 namespace {
 
 // status / totals block layout (uint32 words) inside ctx->d_status
-enum { W_STATUS = 0, W_UNSUP_POS = 1, W_LEXTOT = 4 /* Cnt3: 4 words */, W_FINTOK = 8, W_NSEG = 9, W_PARSE = 16, W_LOWER = 32 };
+enum { W_STATUS = 0, W_UNSUP_POS = 1, W_LEXTOT = 4 /* Cnt3: 4 words */, W_FINTOK = 8, W_NSEG = 9, W_ENDFN = 10, W_ENDDEPTH = 11, W_PARSE = 16, W_LOWER = 32 };
 
 int fail(opusfe_ctx* ctx, int code, const std::string& msg) { if (ctx) ctx->msg = msg; return code; }
 
@@ -88,7 +88,7 @@ void run_lexer(opusfe_ctx* ctx, opusfe_unit* u, int force_dents) {
         Cnt3* tile_cnt = tmp.get<Cnt3>(ntiles);
         Cnt3* scan_tmp = tmp.get<Cnt3>((ntiles + SCAN_TILE - 1) / SCAN_TILE + 1);
         LAUNCH(ctx, "lex_ctx_chunk", k_ctx_chunk, ntiles, LEX_THREADS, src, n, chunk_fn, tile_fn, rs);
-        LAUNCH(ctx, "lex_ctx_tiles", k_ctx_tiles, 1, SCAN_THREADS, tile_fn, tile_state, (uint32_t)ntiles, (uint32_t)CS_N, (uint32_t*)nullptr);
+        LAUNCH(ctx, "lex_ctx_tiles", k_ctx_tiles, 1, SCAN_THREADS, tile_fn, tile_state, (uint32_t)ntiles, (uint32_t)CS_N, ctx->d_status + W_ENDFN);
         LAUNCH(ctx, "lex_count", k_lex_count, ntiles, LEX_THREADS, src, n, chunk_fn, tile_state, chunk_state, chunk_cnt, chunk_str, tile_cnt, status, rs);
         prof_begin(ctx, "scan_cnt3");
         device_scan<true>(tile_cnt, tile_cnt, ntiles, OpAddCnt3(), Cnt3{0, 0, 0, 0}, scan_tmp, (Cnt3*)(ctx->d_status + W_LEXTOT), st);
@@ -116,6 +116,7 @@ void run_lexer(opusfe_ctx* ctx, opusfe_unit* u, int force_dents) {
         prof_begin(ctx, "scan_depth");
         device_scan<false>(depth, depth, T, OpAddI32(), (int32_t)0, (int32_t*)scan_tmp32, (int32_t*)nullptr, st);
         prof_end(ctx);
+        HIP_TRY(hipMemcpyAsync(ctx->d_status + W_ENDDEPTH, depth + (T - 1), 4, hipMemcpyDeviceToDevice, st));      // (opusfe_unit_end_state)
     }
     LAUNCH(ctx, "tok_gap", k_gap, grid_for(G, 256), 256, src, n, raw, T, depth, gapval, (int32_t)0);
     prof_begin(ctx, "scan_indent");
@@ -139,6 +140,8 @@ void run_lexer(opusfe_ctx* ctx, opusfe_unit* u, int force_dents) {
     }
     fetch_status(ctx);
     u->n_segs = T > 0 ? ctx->h_status[W_NSEG] : 0;
+    u->end_ctx_state = ntiles > 0 ? ctx_apply(ctx->h_status[W_ENDFN], CS_N) : (uint32_t)CS_N;
+    u->end_depth = T > 0 ? (int32_t)ctx->h_status[W_ENDDEPTH] : 0;
     u->dev_status = ctx->h_status[W_STATUS];
     u->unsup_pos = ctx->h_status[W_UNSUP_POS];
     u->status = status_to_code(u->dev_status);
@@ -264,10 +267,19 @@ int opusfe_shard_ctx_static(opusfe_ctx* ctx, const uint8_t* d_src, uint64_t len,
 }
 
 // raw (dent-free) tokens of a shard whose first byte is in context `start_state`; *n_tokens and the kinds of its last
-// (up to 8) tokens, most recent in the low byte, T_EndOfFile where there is none
+// (up to 8) tokens, most recent in the low byte, T_EndOfFile where there is none.  fn_out / head_kinds (may be null): the composed
+// context function of the bytes, and the kinds of the FIRST (up to 8) tokens, first token in the low byte.
+static int shard_lex_impl(opusfe_ctx* ctx, const uint8_t* d_src, uint64_t len, uint32_t start_state, opusfe_shard** out, uint64_t* n_tokens, uint64_t* tail_kinds,
+                          uint32_t* fn_out, uint64_t* head_kinds);
 int opusfe_shard_lex(opusfe_ctx* ctx, const uint8_t* d_src, uint64_t len, uint32_t start_state, opusfe_shard** out, uint64_t* n_tokens, uint64_t* tail_kinds) {
+    return shard_lex_impl(ctx, d_src, len, start_state, out, n_tokens, tail_kinds, nullptr, nullptr);
+}
+static int shard_lex_impl(opusfe_ctx* ctx, const uint8_t* d_src, uint64_t len, uint32_t start_state, opusfe_shard** out, uint64_t* n_tokens, uint64_t* tail_kinds,
+                          uint32_t* fn_out, uint64_t* head_kinds) {
     if (!out || !n_tokens || !tail_kinds || (len && !d_src) || len > MAX_LEN || start_state > CS_C) return OPUSFE_ERR_ARG;
     *out = nullptr;
+    if (fn_out) *fn_out = CTX_IDENTITY;
+    if (head_kinds) *head_kinds = TK_NO_PREV;
     return guarded(ctx, [&] {
         opusfe_shard* s = new opusfe_shard();
         s->ctx = ctx; s->d_src = d_src; s->len = (uint32_t)len; s->raw = nullptr; s->T = 0;
@@ -291,10 +303,11 @@ int opusfe_shard_lex(opusfe_ctx* ctx, const uint8_t* d_src, uint64_t len, uint32
         Cnt3* scan_tmp = tmp.get<Cnt3>((ntiles + SCAN_TILE - 1) / SCAN_TILE + 1);
         uint32_t* status = ctx->d_status + W_STATUS;
         LAUNCH(ctx, "lex_ctx_chunk", k_ctx_chunk, ntiles, LEX_THREADS, d_src, n, chunk_fn, tile_fn, Resync{nullptr, 0});
-        LAUNCH(ctx, "lex_ctx_tiles", k_ctx_tiles, 1, SCAN_THREADS, tile_fn, tile_state, (uint32_t)ntiles, start_state, (uint32_t*)nullptr);
+        LAUNCH(ctx, "lex_ctx_tiles", k_ctx_tiles, 1, SCAN_THREADS, tile_fn, tile_state, (uint32_t)ntiles, start_state, ctx->d_status + 60);
         LAUNCH(ctx, "lex_count", k_lex_count, ntiles, LEX_THREADS, d_src, n, chunk_fn, tile_state, chunk_state, chunk_cnt, chunk_str, tile_cnt, status, Resync{nullptr, 0});
         device_scan<true>(tile_cnt, tile_cnt, ntiles, OpAddCnt3(), Cnt3{0, 0, 0, 0}, scan_tmp, (Cnt3*)(ctx->d_status + W_LEXTOT), st);
         fetch_status(ctx);
+        if (fn_out) *fn_out = ctx->h_status[60];
         const uint32_t T = ctx->h_status[W_LEXTOT], nval = ctx->h_status[W_LEXTOT + 1], nstr = ctx->h_status[W_LEXTOT + 2];
         s->T = T;
         s->raw = dev_alloc_t<opusfe_token>(ctx, T);
@@ -305,10 +318,16 @@ int opusfe_shard_lex(opusfe_ctx* ctx, const uint8_t* d_src, uint64_t len, uint32
         s->depth = dev_alloc_t<int32_t>(ctx, G); s->gapval = dev_alloc_t<uint32_t>(ctx, G); s->prev = dev_alloc_t<uint32_t>(ctx, G);
         s->scan_tmp = dev_alloc_t<uint32_t>(ctx, (G + SCAN_TILE - 1) / SCAN_TILE + 2);
         // kinds of the last tokens
-        opusfe_token tail[8];
+        opusfe_token tail[8], head[8];
         const uint32_t nt = T < 8 ? T : 8;
         if (nt) HIP_TRY(hipMemcpyAsync(tail, s->raw + (T - nt), nt * sizeof(opusfe_token), hipMemcpyDeviceToHost, st));
+        if (nt && head_kinds) HIP_TRY(hipMemcpyAsync(head, s->raw, nt * sizeof(opusfe_token), hipMemcpyDeviceToHost, st));
         sync_stream(ctx);
+        if (head_kinds) {
+            uint64_t hk = TK_NO_PREV;
+            for (uint32_t j = 0; j < nt; j++) hk = (hk & ~(0xFFull << (8 * j))) | ((uint64_t)head[j].kind << (8 * j));
+            *head_kinds = hk;
+        }
         uint64_t kinds = TK_NO_PREV;
         for (uint32_t j = 0; j < nt; j++) {
             uint8_t k = tail[nt - 1 - j].kind;
@@ -356,6 +375,28 @@ int opusfe_shard_boundary(opusfe_shard* s, int64_t depth_in, uint64_t* pos) {
         if (ctx->h_status[62] != 0xFFFFFFFFu) *pos = ctx->h_status[62];
         return (int)OPUSFE_OK;
     });
+}
+
+// Everything a shard contributes to the ONE carry all-gather of a huge source, computed SPECULATIVELY for the
+// common entry of a shard that starts behind a '\n': lexer context N, bracket depth 0, no `record {` look-back across the cut.
+//   carry[0] composed context function of the bytes        [1] number of raw tokens      [2] kinds of the last 8 tokens
+//   carry[3] kinds of the first 8 tokens                   [4] net bracket depth          [5] first provable top-level segment start
+//   carry[6] len                                           [7] bit 0: a brace among the first tokens (its depth delta looks back over the cut)
+// Once every rank holds every carry, each can check the speculation of ALL ranks (entry state of rank q = fold of carry[0] of the
+// ranks before it; entry depth = sum of carry[4]; no look-back flag) and they all reach the same verdict without another
+// exchange; if it fails the host falls back to the dependent chain (opusfe_shard_lex with the true state, _net_depth, _boundary).
+// The shard handle stays valid for that chain.  No counterpart in the reference.
+int opusfe_shard_carry(opusfe_ctx* ctx, const uint8_t* d_src, uint64_t len, uint64_t* carry, opusfe_shard** out) {
+    if (!ctx || !carry || !out) return OPUSFE_ERR_ARG;
+    uint32_t fn = CTX_IDENTITY; uint64_t ntok = 0, tail = TK_NO_PREV, head = TK_NO_PREV, cut = ~0ull; int64_t net = 0;
+    int rc = shard_lex_impl(ctx, d_src, len, CS_N, out, &ntok, &tail, &fn, &head);
+    if (rc == OPUSFE_OK) rc = opusfe_shard_net_depth(*out, TK_NO_PREV, &net);
+    if (rc == OPUSFE_OK) rc = opusfe_shard_boundary(*out, 0, &cut);
+    if (rc != OPUSFE_OK) return rc;
+    uint64_t sensitive = 0;
+    for (uint32_t j = 0; j < 8 && j < ntok; j++) { const uint8_t k = (uint8_t)(head >> (8 * j)); if (k == T_LeftBrace || k == T_RightBrace) sensitive = 1; }
+    carry[0] = fn; carry[1] = ntok; carry[2] = tail; carry[3] = head; carry[4] = (uint64_t)net; carry[5] = cut; carry[6] = len; carry[7] = sensitive;
+    return OPUSFE_OK;
 }
 
 void opusfe_shard_free(opusfe_shard* s) {
@@ -726,6 +767,12 @@ int opusfe_memory_held(opusfe_ctx* ctx, uint64_t* bytes) {
 int opusfe_unit_resync_passes(const opusfe_unit* u, uint32_t* n) {
     if (!u || !n) return OPUSFE_ERR_ARG;
     *n = (uint32_t)u->resync.size();
+    return OPUSFE_OK;
+}
+
+int opusfe_unit_end_state(const opusfe_unit* u, uint32_t* ctx_state, int32_t* depth) {
+    if (!u || !ctx_state || !depth) return OPUSFE_ERR_ARG;
+    *ctx_state = u->end_ctx_state; *depth = u->end_depth;
     return OPUSFE_OK;
 }
 

@@ -26,6 +26,7 @@ struct opusfe_unit {
     bool has_error = false; opusfe_error error{}; uint32_t err_seg = 0;
     uint32_t unsup_pos = 0xFFFFFFFFu;                          // first byte the reference cannot be followed on (lexer)
     std::vector<uint32_t> resync;                              // sorted resync points found by earlier passes (lex.h Resync)
+    uint32_t end_ctx_state = 0; int32_t end_depth = 0;         // lexer context and bracket depth behind the last byte (opusfe_unit_end_state)
     // IR
     bool lowered = false;
     void* ir = nullptr;                                        // opusfe::IrResult (lower.h)
