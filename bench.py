@@ -12,8 +12,8 @@ Workload (config.workload):
         generator G (tools/gen), with the three depth-1000 regions injected.
   N>1 ("c4", default): BASELINE.json configs[3] — ONE logical source of N x --bytes cut at ARBITRARY byte positions
         (rank r holds bytes [r*B+12345, (r+1)*B+12345): cuts fall inside lines, strings and blocks); the ranks
-        exchange lexer-context / token-tail / bracket-depth / cut carries, the prefix halo and the definition
-        headers by all-gather (opus_amd/shard.py) and each lowers the definitions it owns.  Weak scaling:
+        exchange ONE all-gather of 64-byte carries (lexer context function, token tails, bracket depth, cut), the head and
+        prefix halos point to point, and the definition headers by all-gather (opus_amd/shard.py); each lowers the definitions it owns.  Weak scaling:
         `value` = N x --bytes / max-over-ranks time.  `--workload c3` at N>1 gives independent sources per rank
         (no collective at all).
 
@@ -252,18 +252,29 @@ def main():
     gather = None
     if workload == "c4" and world > 1:
         from opus_amd import shard, sharding
-        raw_gather = sharding.make_gather(dist, torch.device("cuda", local_rank))
-        shard_times = {"comm_s": 0.0, "header_reparse_s": 0.0, "header_bytes": 0}
+        shard_times = {"comm_s": 0.0, "header_reparse_s": 0.0, "header_bytes": 0, "fast": 0, "slow": 0}
 
-        def gather(name, values):          # (host time of the exchange steps, waiting for the slowest rank included)
-            t = time.perf_counter()
-            r = raw_gather(name, values)
-            shard_times["comm_s"] += time.perf_counter() - t
-            return r
+        class TimedComm(sharding.DistComm):      # (host time of the exchange steps, waiting for the slowest rank included)
+            def _timed(self, f, *a):
+                t = time.perf_counter()
+                r = f(*a)
+                shard_times["comm_s"] += time.perf_counter() - t
+                return r
+
+            def gather(self, name, values):
+                return self._timed(super().gather, name, values)
+
+            def gather_sized(self, name, values, sizes):
+                return self._timed(super().gather_sized, name, values, sizes)
+
+            def p2p(self, name, sends, recvs, ranks):
+                return self._timed(super().p2p, name, sends, recvs, ranks)
+        gather = TimedComm(dist, torch.device("cuda", local_rank))
 
     def step_c4():
         st = shard.RankState(ctx, d_src[:n_local], rank, world)
         shard.plan([st], gather)
+        shard_times["fast" if st.speculation_held else "slow"] += 1
         res = shard.compile_sharded([st], gather, lower=(args.stage == "ir"))[0]
         if res["status"] != opus_amd.OK:
             raise SystemExit(f"rank {rank}: sharded hot path failed: status {res['status']} (first bad rank {res['first_bad_rank']}): {ctx.message()}")
@@ -353,6 +364,27 @@ def main():
         sharded_totals["comm_ms"] = round(_sh7.all_reduce_sum(counts["comm_ms_x1000"], dist) / 1000.0 / world, 3)
         sharded_totals["header_reparse_ms"] = round(_sh7.all_reduce_sum(counts["header_reparse_ms_x1000"], dist) / 1000.0 / world, 3)
         sharded_totals["header_bytes_rank0"] = shard_times["header_bytes"]
+        # exchange steps per pass: all-gathers and point-to-point messages of rank 0 (ONE carry all-gather when every shard
+        # starts in code context at depth 0 — `single_all_gather_passes` counts the passes where that held)
+        # the exchanges alone (no waiting for a slower rank): every pattern of one pass repeated behind a barrier, with the sizes of the last pass
+        hb = max(1, shard_times["header_bytes"] // max(1, world - 1))
+        probe_t = torch.zeros(hb, dtype=torch.uint8, device="cuda")
+        halo = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+        reps, acc = 5, 0.0
+        for _ in range(reps):
+            dist.barrier()
+            t = time.perf_counter()
+            sharding.DistComm.gather(gather, "probe", [(1, 2, 3, 4, 5, 6, 7, 8)])
+            sharding.DistComm.gather(gather, "probe", [(0, hb)])
+            sharding.DistComm.gather_sized(gather, "probe", [probe_t], [hb] * world)
+            sharding.DistComm.p2p(gather, "heads", [[(rank - 1, halo)] if rank > 0 else []], [[(rank + 1, None)] if rank + 1 < world else []], [rank])
+            sharding.DistComm.p2p(gather, "prefixes", [[(rank - 1, halo)] if rank > 0 else []], [[(rank + 1, 4096)] if rank + 1 < world else []], [rank])
+            acc += time.perf_counter() - t
+        counts["exchange_only_ms_x1000"] = int(1e6 * acc / reps)
+        sharded_totals["exchange_only_ms"] = round(_sh7.all_reduce_sum(counts["exchange_only_ms_x1000"], dist) / 1000.0 / world, 3)
+        sharded_totals["collectives_per_pass"] = round((gather.collectives - 3 * reps) / steps_run, 2)
+        sharded_totals["p2p_messages_per_pass_rank0"] = round((gather.p2p_messages - (2 * reps if rank > 0 else 0)) / steps_run, 2)
+        sharded_totals["single_all_gather_passes"], sharded_totals["dependent_chain_passes"] = shard_times["fast"], shard_times["slow"]
     if dist is not None:
         from opus_amd import sharding as _sh
         dt = _sh.all_reduce_max(dt, dist)
@@ -466,7 +498,7 @@ def main():
             shd = "none" if world == 1 else "independent shards, no collective"
         elif workload == "c4":
             wl = f"C4: ONE synthetic source of {world * nbytes} B cut at arbitrary bytes over {world} GPUs ({nbytes} B each), carries by all-gather, generator G(seed={args.seed})"
-            shd = "byte-range shards; all-gather of ctx/tail/depth/cut carries, prefix halo, definition headers"
+            shd = "byte-range shards; ONE all-gather of the 64-byte carries, head / prefix halos point to point, (status, length) + definition headers by all-gather"
         else:
             wl = f"C5: corpus of {args.files} independent files of 1-64 KB ({total_bytes_all} B), 1 % with one injected syntax fault, dealt to {world} GPU(s) by cumulative bytes; host buffers (H2D included)"
             shd = "files by cumulative bytes, no collective"

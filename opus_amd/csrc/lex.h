@@ -60,7 +60,11 @@ struct OpCtx { __host__ __device__ uint32_t operator()(uint32_t a, uint32_t b) c
 // behind it; parse.rs:563-581: an invalid float suffix swallows two characters, whatever they are).  If the parser then
 // drops that Err token (Q6/Q7) the bytes behind it are code.  The host finds such a position R from a first pass
 // (api.hip parse_with_resync) and lexes again with R in this list: at R the context is N and a token starts.
-struct Resync { const uint32_t* pos; uint32_t n; };
+// Group mode (a corpus of independent files packed into one buffer, BASELINE config 5; api.hip opusfe_parse_group): the same list
+// holds the START of every file (pos[0] == 0, every start a multiple of LEX_CHUNK, '\n' between the files) — a file start is exactly
+// "context N and a token boundary" — with `files` set; `fstatus` then receives the unsupported-input records per file (2 words each).
+struct Resync { const uint32_t* pos; uint32_t n; uint32_t files; uint32_t* fstatus; };
+constexpr uint32_t FILE_MIX = 0x9E3779B1u;   // identifier hashes of file f are shifted by f * FILE_MIX (odd: distinct files never share a hash for one name)
 constexpr uint32_t CTX_RESET = 0;   // every state -> N
 // smallest listed position >= p, else 0xFFFFFFFF
 __host__ __device__ __forceinline__ uint32_t rs_next(const Resync& rs, uint32_t p) {
@@ -69,6 +73,12 @@ __host__ __device__ __forceinline__ uint32_t rs_next(const Resync& rs, uint32_t 
     return lo < rs.n ? rs.pos[lo] : 0xFFFFFFFFu;
 }
 __host__ __device__ __forceinline__ bool rs_has(const Resync& rs, uint32_t p) { return rs.n != 0 && rs_next(rs, p) == p; }
+// index of the last listed position <= p (group mode: the file that byte p belongs to; pos[0] == 0)
+__host__ __device__ __forceinline__ uint32_t pos_file(const uint32_t* pos, uint32_t n, uint32_t p) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) { uint32_t mid = (lo + hi) / 2; if (pos[mid] <= p) lo = mid + 1; else hi = mid; }
+    return lo ? lo - 1 : 0;
+}
 
 __global__ __launch_bounds__(LEX_THREADS) void k_ctx_chunk(const uint8_t* __restrict__ src, uint32_t n, uint32_t* __restrict__ chunk_fn, uint32_t* __restrict__ tile_fn, Resync rs) {
     __shared__ uint32_t lds[4];
@@ -498,7 +508,7 @@ __device__ __forceinline__ void lex_chunk(const uint8_t* __restrict__ s, uint32_
         if (nr == cbeg) { state = CS_N; forced = true; }
         // the invalid-float-suffix error swallows two characters (parse.rs:563-581): a chunk that starts inside them, in code
         // context, starts inside that Err token, which ends at the resync point
-        else if (state == CS_N && nr != 0xFFFFFFFFu && nr - cbeg <= 8 && lx_inside_suffix_error(s, n, cbeg, nr)) { pos = nr < cend ? nr : cend; forced = true; }
+        else if (!rs.files && state == CS_N && nr != 0xFFFFFFFFu && nr - cbeg <= 8 && lx_inside_suffix_error(s, n, cbeg, nr)) { pos = nr < cend ? nr : cend; forced = true; }
         // (a) as below, but a resync point ends the string: context N and a token boundary at pos (> cbeg: no look-back)
         while (state != CS_N && pos < cend) {
             if (pos == nr) { state = CS_N; break; }
@@ -570,6 +580,7 @@ __global__ LEX_ATTR __launch_bounds__(LEX_THREADS) void k_lex_count(const uint8_
     Cnt3 c{0, 0, 0, 0};
     if (live) {
         uint32_t cbeg = (uint32_t)base, cend = (uint32_t)((base + LEX_CHUNK < n) ? base + LEX_CHUNK : n);
+        if (rs.files) status = rs.fstatus + 2 * pos_file(rs.pos, rs.n, cbeg);      // group mode: unsupported inputs are recorded per file
         lex_chunk(src, n, cbeg, cend, state, status, rs, [&](uint32_t pos) {
             LexTok t;
             lex_one(src, n, pos, t, nullptr, status, rs);
@@ -604,6 +615,8 @@ __global__ LEX_ATTR __launch_bounds__(LEX_THREADS) void k_lex_emit(const uint8_t
     uint32_t cbeg = (uint32_t)base, cend = (uint32_t)((base + LEX_CHUNK < n) ? base + LEX_CHUNK : n);
     uint32_t state = chunk_state[chunk];
     uint32_t ti = off.tok, vi = off.val, si = off.str;
+    uint32_t mix = 0;
+    if (rs.files) { const uint32_t f = pos_file(rs.pos, rs.n, cbeg); status = rs.fstatus + 2 * f; mix = f * FILE_MIX; }
     lex_chunk(src, n, cbeg, cend, state, status, rs, [&](uint32_t pos) {
         LexTok t;
         lex_one(src, n, pos, t, strpool + si, status, rs);
@@ -612,7 +625,7 @@ __global__ LEX_ATTR __launch_bounds__(LEX_THREADS) void k_lex_emit(const uint8_t
         if (t.kind == T_Error) { o.low = pos; o.payload = vi; }
         else if (t.kind == T_String) o.payload = si;
         else if (t.nval) o.payload = vi;
-        else o.payload = t.payload;
+        else o.payload = t.kind == T_Identifier ? t.payload + mix : t.payload;
         if (t.nval >= 1) val64[vi] = t.v0;
         if (t.nval >= 2) val64[vi + 1] = t.v1;
         vi += t.nval; si += t.strbytes;
@@ -640,10 +653,39 @@ __device__ __forceinline__ bool tk_record_open(const opusfe_token* __restrict__ 
     return false;
 }
 
-__global__ void k_tok_delta(const opusfe_token* __restrict__ raw, uint32_t T, int32_t* __restrict__ delta, int force_dents, uint64_t prev_kinds) {
+// Group mode tables of the token-level passes: file of every raw token, first raw token of every file (NONE: the file has none),
+// bracket depth in front of every file (the running sum is taken over the whole group; a file counts from its own start).
+struct FileTok { const uint32_t* start; const uint32_t* len; uint32_t n; const uint32_t* fid; const uint32_t* first_tok; const int32_t* base; };
+enum : uint32_t { FF_EMPTY = 1u, FF_INDENTED = 2u, FF_ENDSTATE = 4u, FF_TAILF = 8u, FF_UNSUP = 16u, FF_RESYNC = 32u, FF_INTERNAL = 64u, FF_OPDEF = 128u,
+                  FF_FINERR = 256u, FF_SYNTAX = 512u,
+                  FF_SINGLE = FF_EMPTY | FF_INDENTED | FF_ENDSTATE | FF_TAILF | FF_UNSUP | FF_RESYNC | FF_INTERNAL | FF_OPDEF | FF_FINERR };
+
+__global__ void k_tok_file(const opusfe_token* __restrict__ raw, uint32_t T, const uint32_t* __restrict__ start, uint32_t n_files, uint32_t* __restrict__ fid,
+                           uint32_t* __restrict__ first_tok, uint32_t* __restrict__ flags) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= T) return;
+    const opusfe_token t = raw[k];
+    const uint32_t f = pos_file(start, n_files, t.low);
+    fid[k] = f;
+    if (k == 0 || pos_file(start, n_files, raw[k - 1].low) != f) first_tok[f] = k;
+    if (t.kind == T_Error && (t.flags & OPUSFE_TF_RESYNC)) atomicOr(&flags[f], (uint32_t)FF_RESYNC);
+}
+__global__ void k_file_base(const int32_t* __restrict__ depth_incl, const uint32_t* __restrict__ first_tok, uint32_t n_files, int32_t* __restrict__ base) {
+    uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_files) return;
+    const uint32_t k = first_tok[f];
+    base[f] = (k == OPUSFE_NONE || k == 0) ? 0 : depth_incl[k - 1];
+}
+
+__global__ void k_tok_delta(const opusfe_token* __restrict__ raw, uint32_t T, int32_t* __restrict__ delta, int force_dents, uint64_t prev_kinds, FileTok ft) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= T) return;
     int32_t d = 0;
+    if (ft.n) {      // the look-back never leaves the token's file
+        const uint32_t lo = ft.first_tok[ft.fid[k]];
+        raw += lo; k -= lo; prev_kinds = TK_NO_PREV;
+        delta += lo;
+    }
     if (!force_dents) {
         uint8_t kd = raw[k].kind;
         if (kd == T_LeftParenthesis) d = 1;
@@ -663,23 +705,35 @@ __global__ void k_tok_delta(const opusfe_token* __restrict__ raw, uint32_t T, in
 // For gap k (before raw token k; k == T is the gap before end of file): value | 1<<31 when the gap
 // is dent-sensitive and crosses a line (or is the very first gap / the EOF gap).
 __global__ void k_gap(const uint8_t* __restrict__ src, uint32_t n, const opusfe_token* __restrict__ raw, uint32_t T,
-                      const int32_t* __restrict__ depth_incl, uint32_t* __restrict__ gapval, int32_t depth_in) {
+                      const int32_t* __restrict__ depth_incl, uint32_t* __restrict__ gapval, int32_t depth_in, FileTok ft) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k > T) return;
-    bool sens = (k == 0 ? depth_in : depth_incl[k - 1] + depth_in) == 0;
+    // group mode: a gap belongs to the file of the token behind it (the gap behind the last token to the last file); the first gap
+    // of a file starts at the file's first byte and is measured like the first line of a source (parse.rs:429)
+    int32_t before = k == 0 ? 0 : depth_incl[k - 1];
+    bool first = false;
+    uint32_t fstart = 0;
+    if (ft.n && T > 0) {
+        const uint32_t f = ft.fid[k < T ? k : T - 1];
+        before -= ft.base[f];
+        first = k < T && ft.first_tok[f] == k;
+        fstart = ft.start[f];
+    }
+    bool sens = before + depth_in == 0;
     uint32_t out = 0;
     if (sens) {
         if (k == T) out = 0x80000000u;                       // EOF: -(indent) (parse.rs:461-464)
         else {
             uint32_t gbeg = k == 0 ? 0 : raw[k - 1].low + raw[k - 1].len;
+            if (first) gbeg = fstart;
             uint32_t gend = raw[k].low;
             if (raw[k].kind == T_Error) gend = raw[k].low;
             uint32_t p = gend;
             bool nl = false;
             while (p > gbeg) { if (src[p - 1] == '\n') { nl = true; break; } p--; }
-            if (nl || gbeg == 0) {
-                // p = position just after the last '\n' (or 0): count leading TABs (parse.rs:438-444)
-                uint32_t q = nl ? p : 0, tabs = 0;
+            if (nl || gbeg == 0 || first) {
+                // p = position just after the last '\n' (or the start of the source): count leading TABs (parse.rs:438-444)
+                uint32_t q = nl ? p : gbeg, tabs = 0;
                 while (q < gend && src[q] == '\t') { tabs++; q++; }
                 out = 0x80000000u | tabs;
             }
@@ -689,9 +743,30 @@ __global__ void k_gap(const uint8_t* __restrict__ src, uint32_t n, const opusfe_
 }
 
 // count[k] = |delta| + 1
-__global__ void k_dent_count(const uint32_t* __restrict__ gapval, const uint32_t* __restrict__ prev_excl, uint32_t T, uint32_t* __restrict__ cnt) {
+// Group mode: the gap in front of the first token of file B (and the gap behind the last token) also ENDS file A = the file of the
+// token before it: A's dedents back to column 0 (only in dent-sensitive mode, Q8) and A's EndOfFile token, both at A's last byte;
+// then B's first line (indents from column 0).
+struct FileClose { bool closes; uint32_t nclose, tabs, end_a; };
+__device__ __forceinline__ FileClose file_close(const FileTok& ft, uint32_t k, uint32_t T, const uint32_t* __restrict__ gapval, const uint32_t* __restrict__ prev_excl,
+                                                const int32_t* __restrict__ depth_incl) {
+    FileClose c{false, 0, 0, 0};
+    if (!ft.n || k == 0 || T == 0) return c;
+    if (k < T && ft.first_tok[ft.fid[k]] != k) return c;
+    const uint32_t a = ft.fid[k - 1];
+    c.closes = true;
+    const bool a_sens = depth_incl[k - 1] - ft.base[a] == 0;
+    c.nclose = a_sens ? (prev_excl[k] & 0x7FFFFFFFu) : 0u;
+    c.tabs = k < T ? (gapval[k] & 0x7FFFFFFFu) : 0u;
+    c.end_a = ft.start[a] + ft.len[a];
+    return c;
+}
+
+__global__ void k_dent_count(const uint32_t* __restrict__ gapval, const uint32_t* __restrict__ prev_excl, uint32_t T, uint32_t* __restrict__ cnt, FileTok ft,
+                             const int32_t* __restrict__ depth_incl) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k > T) return;
+    const FileClose fc = file_close(ft, k, T, gapval, prev_excl, depth_incl);
+    if (fc.closes) { cnt[k] = fc.nclose + 1u + (k < T ? fc.tabs + 1u : 0u); return; }
     uint32_t g = gapval[k];
     int32_t d = 0;
     if (g >> 31) d = (int32_t)(g & 0x7FFFFFFFu) - (int32_t)(prev_excl[k] & 0x7FFFFFFFu);
@@ -700,9 +775,26 @@ __global__ void k_dent_count(const uint32_t* __restrict__ gapval, const uint32_t
 
 __global__ void k_final(const opusfe_token* __restrict__ raw, uint32_t T, uint32_t n, const uint32_t* __restrict__ gapval,
                         const uint32_t* __restrict__ prev_excl, const uint32_t* __restrict__ out_off, opusfe_token* __restrict__ tokens,
-                        uint32_t* __restrict__ seg_flag) {
+                        uint32_t* __restrict__ seg_flag, FileTok ft, const int32_t* __restrict__ depth_incl, uint32_t* __restrict__ file_tok_begin) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k > T) return;
+    const FileClose fc = file_close(ft, k, T, gapval, prev_excl, depth_incl);
+    if (fc.closes) {
+        uint32_t o = out_off[k];
+        opusfe_token t; t.flags = 0; t.aux = 0; t.len = 0; t.payload = 0; t.low = fc.end_a;
+        t.kind = T_Dedent;
+        for (uint32_t i = 0; i < fc.nclose; i++) tokens[o++] = t;
+        t.kind = T_EndOfFile; tokens[o++] = t;
+        if (k < T) {
+            file_tok_begin[ft.fid[k]] = o;                  // the file's slice of the final stream starts behind its predecessor's EndOfFile
+            t.kind = T_Indent; t.low = raw[k].low;
+            for (uint32_t i = 0; i < fc.tabs; i++) tokens[o++] = t;
+            tokens[o] = raw[k];
+            seg_flag[k] = 1;                                // a file starts a segment, whatever its first token is
+        } else seg_flag[k] = 0;
+        return;
+    }
+    if (ft.n && k == 0 && T > 0) file_tok_begin[ft.fid[0]] = 0;
     uint32_t g = gapval[k];
     int32_t d = 0;
     if (g >> 31) d = (int32_t)(g & 0x7FFFFFFFu) - (int32_t)(prev_excl[k] & 0x7FFFFFFFu);

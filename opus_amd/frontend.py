@@ -68,6 +68,8 @@ def lib():
         L.opusfe_shard_lex.argtypes = [vp, vp, u64, u32, C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]
         L.opusfe_shard_net_depth.argtypes = [vp, u64, C.POINTER(C.c_int64)]
         L.opusfe_shard_boundary.argtypes = [vp, C.c_int64, C.POINTER(u64)]
+        L.opusfe_shard_carry.argtypes = [vp, vp, u64, C.POINTER(u64), C.POINTER(vp)]
+        L.opusfe_unit_end_state.argtypes = [vp, C.POINTER(u32), C.POINTER(C.c_int32)]
         L.opusfe_shard_free.argtypes = [vp]
         L.opusfe_unit_headers.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
         L.opusfe_unit_join.argtypes = [vp, vp, vp, u64, C.POINTER(vp)]
@@ -150,6 +152,12 @@ class Unit:
         n = C.c_uint32()
         lib().opusfe_unit_resync_passes(self.handle, C.byref(n))
         return n.value
+
+    def end_state(self):
+        """(lexer context, bracket depth) behind the unit's last byte, as the reference's lexer has them after every resync pass"""
+        st, d = C.c_uint32(), C.c_int32()
+        lib().opusfe_unit_end_state(self.handle, C.byref(st), C.byref(d))
+        return st.value, d.value
 
     def compile_source(self):
         """frontend.rs:140-187, IR part.  Returns the status (OK / SEMANTIC / UNSUPPORTED)."""
@@ -330,6 +338,15 @@ class Context:
         if rc != OK:
             raise OpusfeError(rc, self.message())
         return None if pos.value == 0xFFFFFFFFFFFFFFFF else pos.value
+
+    def shard_carry(self, d_ptr, length):
+        """opusfe_shard_carry: (shard handle, the eight words of the fixed-size carry) computed for the common entry (context N, depth 0)"""
+        h = C.c_void_p()
+        carry = (C.c_uint64 * 8)()
+        rc = lib().opusfe_shard_carry(self.handle, C.c_void_p(d_ptr), length, carry, C.byref(h))
+        if rc != OK:
+            raise OpusfeError(rc, self.message())
+        return h, [int(x) for x in carry]
 
     def shard_free(self, shard):
         lib().opusfe_shard_free(shard)

@@ -76,7 +76,9 @@ def test_carry_folds_are_associative_and_match_the_device_encoding():
         assert prev == tail(kinds)
 
 
-def test_two_rank_gloo_variable_size_gather(tmp_path):
+def test_two_rank_gloo_comm_gathers_and_point_to_point(tmp_path):
+    """sharding.DistComm over gloo, world 2: the fixed-size integer all-gather (u64 words included), the sized byte all-gather, and
+    the point-to-point transfers of known and unknown size (a head longer than the first message included)"""
     script = tmp_path / "g.py"
     script.write_text(textwrap.dedent(f"""
         import sys
@@ -85,15 +87,25 @@ def test_two_rank_gloo_variable_size_gather(tmp_path):
         from opus_amd import sharding
         dist.init_process_group("gloo")
         r, w = dist.get_rank(), dist.get_world_size()
-        gather = sharding.make_gather(dist, torch.device("cpu"))
-        objs = gather("o", [(r, "x" * r)])
-        assert objs == [(q, "x" * q) for q in range(w)], objs
+        comm = sharding.DistComm(dist, torch.device("cpu"))
+        rows = comm.gather("carry", [(r, 0x3B3B3B3B3B3B3B3B, (1 << 64) - 1, -5)])
+        assert rows == [(q, 0x3B3B3B3B3B3B3B3B, -1, -5) for q in range(w)], rows          # u64 words travel as two's complement
+        assert comm.gather("one", [7 + r]) == [7, 8]
         t = torch.full((10 + 1000 * r,), 7 + r, dtype=torch.uint8)
-        got = gather("t", [t])
+        got = comm.gather_sized("t", [t], [10 + 1000 * q for q in range(w)])
         assert [g.numel() for g in got] == [10 + 1000 * q for q in range(w)]
         assert all(int(g[0]) == 7 + q and int(g[-1]) == 7 + q for q, g in enumerate(got))
-        empty = gather("e", [torch.empty(0, dtype=torch.uint8)])
-        assert all(g.numel() == 0 for g in empty)
+        assert comm.collectives == 3
+        # heads: rank 1 -> rank 0, size unknown to the receiver; once short, once longer than the first message
+        for n in (5, sharding.HEAD_CAP + 123, 0):
+            payload = (torch.arange(n, dtype=torch.int64) % 251).to(torch.uint8)
+            got = comm.p2p("heads", [[(0, payload)] if r == 1 else []], [[(1, None)] if r == 0 else []], [r])
+            if r == 0:
+                assert torch.equal(got[0][0].cpu(), payload), n
+        # prefixes: known sizes, both directions at once
+        mine = torch.full((100 + r,), r, dtype=torch.uint8)
+        got = comm.p2p("prefixes", [[(1 - r, mine)]], [[(1 - r, 100 + (1 - r))]], [r])
+        assert got[0][0].numel() == 100 + (1 - r) and int(got[0][0][0]) == 1 - r
         dist.barrier()
         if r == 0: print("OK")
     """))
@@ -102,3 +114,20 @@ def test_two_rank_gloo_variable_size_gather(tmp_path):
                           "--master-port", "29612", str(script)], capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "OK" in out.stdout
+
+
+def test_speculation_check_is_a_pure_function_of_the_gathered_carries():
+    """every rank must reach the same verdict from the same carries: entry context by folding the context functions, entry depth
+    by summing the nets, and the look-back flag of every rank but the first"""
+    from opus_amd import shard
+    ident, quote = shard.CTX_IDENTITY, 1 | (0 << 3) | (1 << 6) | (4 << 9) | (1 << 12) | (5 << 15)      # lex.h CTX_QUOTE
+    ok = [[ident, 10, 0, 0, 0, 5, 100, 0], [ident, 10, 0, 0, 0, 5, 100, 0], [ident, 3, 0, 0, 0, 2, 50, 0]]
+    assert shard.speculation_holds(ok)
+    first_flag = [row[:] for row in ok]; first_flag[0][7] = 1
+    assert shard.speculation_holds(first_flag)                      # nothing lies before rank 0
+    for q, (col, val) in ((1, (7, 1)), (0, (4, 1)), (0, (0, quote)), (1, (4, (1 << 64) - 1))):
+        bad = [row[:] for row in ok]
+        bad[q][col] = val
+        assert not shard.speculation_holds(bad), (q, col)
+    both = [row[:] for row in ok]; both[0][4] = 1; both[1][4] = (1 << 64) - 1      # +1 then -1: rank 1 starts at depth 1, rank 2 at 0
+    assert not shard.speculation_holds(both)
