@@ -20,7 +20,8 @@ Workload (config.workload):
   "c5" (--workload c5): BASELINE.json configs[4] — a corpus of independent files (sizes log-uniform in [1 KB, 64 KB],
         G(seed=5e6+i), every 100th file with one injected syntax fault), dealt to the ranks by cumulative bytes, NO collective;
         --files sets the corpus size (default 6000 files, about 90 MB, so that the default run finishes in minutes; the
-        configuration names 100000).  The files are host buffers (opusfe_parse_batch): the rate includes their H2D copies.
+        configuration names 100000).  The files are host buffers handed to opusfe_parse_group (ONE packed pass for the whole
+        list: one launch per stage, not per file): the rate includes packing them and the H2D copy.
 
 Extra objects on the JSON line:
   roofline     — the dominant kernel (largest share of HIP-event time, measured by the library on its own
@@ -113,7 +114,7 @@ def extra_c5(ctx, opus_amd, O, n_files):
     with ThreadPoolExecutor(max_workers=cores) as ex:
         corpus = list(ex.map(make_file, range(n_files)))
     total = sum(len(f) for f in corpus)
-    res = run_corpus(ctx, opus_amd, corpus)          # warm-up (allocator, worker contexts)
+    run_corpus(ctx, opus_amd, corpus)["close"]()          # warm-up (allocator)
     t0 = time.perf_counter()
     res = run_corpus(ctx, opus_amd, corpus)
     dt = time.perf_counter() - t0
@@ -145,22 +146,22 @@ def extra_c5(ctx, opus_amd, O, n_files):
     res["close"]()
     return {"workload": f"C5: {n_files} files of 1-64 KB ({total} B), 1 % with one injected syntax fault, host buffers (H2D included)",
             "path": res["path"], "mbs": round(total / 1e6 / dt, 2), "files_per_s": round(n_files / dt, 1), "files_with_syntax_error": res["n_syntax"],
+            "files_on_packed_path": res["n_packed"], "files_on_single_path": res["n_single"],
             "cpu_port_mbs": round(acc / 1e6 / tc, 2), "cpu_cores": cores, "cpu_sample_files": len(sample),
             "sample_parity": {"files_checked": checked, "with_syntax_error": nbad, "error_tuples_and_ir_text_match": bool(ok)}}
 
 
 def run_corpus(ctx, opus_amd, corpus):
-    """one pass of the corpus path; returns accessors for the parity sample"""
-    units = ctx.compile_corpus(corpus, lower=True)
-    for uu in units:
-        if uu.status not in (opus_amd.OK, opus_amd.SYNTAX):
-            raise SystemExit(f"corpus file failed: status {uu.status}: {ctx.message()}")
-
-    def close():
-        for uu in units:
-            uu.close()
-    return {"path": "opusfe_parse_batch: one unit per file on 8 worker contexts", "n_syntax": sum(uu.status == opus_amd.SYNTAX for uu in units),
-            "error_text": lambda i: units[i].dump_error(), "ir_text": lambda i: units[i].dump_ir(), "close": close}
+    """one pass of the corpus path (opusfe_parse_group: the whole list as one packed pass); returns accessors for the parity sample"""
+    g = ctx.compile_group(corpus, lower=True)
+    statuses = g.statuses()
+    for st in statuses:
+        if st not in (opus_amd.OK, opus_amd.SYNTAX):
+            raise SystemExit(f"corpus file failed: status {st}: {ctx.message()}")
+    n_packed, n_single, n_syntax = g.stats()
+    return {"path": "opusfe_parse_group: all files packed into one unit, one launch per stage; irregular files alone through the single-source pipeline",
+            "n_syntax": n_syntax, "n_packed": n_packed, "n_single": n_single,
+            "error_text": lambda i: g.dump_error(i), "ir_text": lambda i: g.dump_ir(i), "close": g.close}
 
 
 def main():
@@ -291,17 +292,16 @@ def main():
     lowering = {}
 
     def step_c5():
-        units = ctx.compile_corpus(corpus, lower=(args.stage == "ir"))
-        tot = {}
+        g = ctx.compile_group(corpus, lower=(args.stage == "ir"))
         nbad = 0
-        for uu in units:
-            if uu.status not in (opus_amd.OK, opus_amd.SYNTAX):
-                raise SystemExit(f"rank {rank}: corpus file failed: status {uu.status}: {ctx.message()}")
-            nbad += uu.status == opus_amd.SYNTAX
-            for k, v in uu.counts().items():
-                tot[k] = tot.get(k, 0) + v
-            uu.close()
-        tot["files"], tot["files_with_syntax_error"] = len(units), nbad
+        for st in g.statuses():
+            if st not in (opus_amd.OK, opus_amd.SYNTAX):
+                raise SystemExit(f"rank {rank}: corpus file failed: status {st}: {ctx.message()}")
+            nbad += st == opus_amd.SYNTAX
+        n_packed, n_single, _ = g.stats()
+        tot = dict(g.unit().counts())          # the packed unit (files on the single-file path are not in these totals)
+        tot["files"], tot["files_with_syntax_error"], tot["files_on_packed_path"], tot["files_on_single_path"] = len(corpus), nbad, n_packed, n_single
+        g.close()
         return tot
 
     def step():
@@ -446,17 +446,17 @@ def main():
             tc = time.perf_counter() - t0c
             # checker: the first files (every faulty one among them) must give the oracle's error line / IR text
             check = sample_files[:200]
-            units = ctx.compile_corpus(check, lower=(args.stage == "ir"))
+            g = ctx.compile_group(check, lower=(args.stage == "ir"))
             ok, nerr = True, 0
-            for f, uu in zip(check, units):
+            for i, f in enumerate(check):
                 want_err = O.dump(f, O.ERROR)
                 nerr += want_err != "Ok\n"
-                if uu.dump_error() != want_err:
+                if g.dump_error(i) != want_err:
                     ok = False
                 elif want_err == "Ok\n" and args.stage == "ir":
-                    if uu.status != opus_amd.OK or hashlib.sha1(uu.dump_ir().encode()).digest() != hashlib.sha1(O.dump(f, O.IR).encode()).digest():
+                    if g.status(i) != opus_amd.OK or hashlib.sha1(g.dump_ir(i).encode()).digest() != hashlib.sha1(O.dump(f, O.IR).encode()).digest():
                         ok = False
-                uu.close()
+            g.close()
             parity = {"files_checked": len(check), "files_with_syntax_error": nerr, "error_tuples_and_ir_text_match": ok}
             cpu = {"value": round(acc / 1e6 / tc, 3), "unit": "MB/s", "cores": cores, "kind": "port",
                    "sample": f"{len(sample_files)} files ({int(acc)} bytes) of the same corpus, one oracle worker per hardware thread ({cores} threads), statuses {sorted(set(res))}"}

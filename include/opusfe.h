@@ -120,6 +120,42 @@ int opusfe_lex(opusfe_ctx* ctx, const uint8_t* src, uint64_t len, int force_dent
 int opusfe_parse_batch(opusfe_ctx* ctx, uint32_t n, const uint8_t* const* srcs, const uint64_t* lens, int lower,
                        opusfe_unit** units, int* statuses);
 
+/* The same corpus as ONE packed pass (BASELINE config 5, thousands of small files).  Replaces, per file, the
+   same reference run as opusfe_parse_batch (frontend.rs:23-118 without imports: read_to_string + Compiler::parse_source +
+   generate_ir per definition) — every file stays its own universe of names — but the files travel through the kernels together:
+   they are packed into one buffer (file f at a 64-byte aligned start, '\n' bytes in between) and every stage is one launch for the
+   whole group.  A file the packed pass cannot answer for exactly (empty, first line indented, unsupported input, a swallowed
+   lexical error that needs a resync pass, finalize-time semantic errors) is run alone
+   through the single-source pipeline by the same call; it then has a unit of its own (opusfe_group_file_unit).
+   The call fails only on device / argument errors; per-file outcomes are read with opusfe_group_file_status:
+   OPUSFE_OK, OPUSFE_SYNTAX (opusfe_group_file_error), OPUSFE_SEMANTIC, OPUSFE_UNSUPPORTED — the codes the file gets alone.
+   In the packed unit the payload of a token of file f is shifted by f * 0x9E3779B1 where it names something (an Identifier's hash;
+   keyword and punctuation tokens, whose payload is otherwise 0): that is how one name table scopes every name to its file. */
+typedef struct opusfe_group opusfe_group;
+int opusfe_parse_group(opusfe_ctx* ctx, uint32_t n_files, const uint8_t* const* srcs, const uint64_t* lens, int lower, opusfe_group** out);
+/* already packed and resident in HBM: starts[0] == 0, every start a multiple of 64, ascending, file f = [starts[f], starts[f] + lens[f]),
+   at least one byte between two files, every byte between files == '\n'; the buffer must stay valid until opusfe_free_group */
+int opusfe_parse_group_device(opusfe_ctx* ctx, const uint8_t* d_packed, uint64_t packed_len, uint32_t n_files, const uint64_t* starts,
+                              const uint64_t* lens, int lower, opusfe_group** out);
+int opusfe_group_file_status(const opusfe_group* group, uint32_t file);
+/* first syntax error of a file whose status is OPUSFE_SYNTAX; positions relative to the file */
+int opusfe_group_file_error(const opusfe_group* group, uint32_t file, opusfe_error* out);
+/* the packed unit: every array of opusfe_array, positions / token / node indices relative to the packed buffer; owned by the group */
+opusfe_unit* opusfe_group_unit(opusfe_group* group);
+/* the unit of a file that took the single-file path, else NULL; owned by the group */
+opusfe_unit* opusfe_group_file_unit(opusfe_group* group, uint32_t file);
+/* where a file's results lie in the packed unit: ranges[0..1] tokens, [2..3] definitions, [4..5] functions (OPUSFE_A_SIGNATURES and
+   OPUSFE_A_FUNCTIONS), [6..7] globals, [8] byte offset of the file, [9] why the file left the packed pass (bit 0 empty, 1 first line
+   indented, 4 unsupported input, 5 swallowed lexical error, 6 internal capacity, 8 finalize-time error;
+   bit 9: syntax error, a result of the packed pass); the index ranges are zero-length for a file with a unit of its own;
+   definitions / functions / globals only for a file whose status is OPUSFE_OK in a lowered group */
+int opusfe_group_file_ranges(const opusfe_group* group, uint32_t file, uint64_t ranges[10]);
+/* how many files were answered by the packed pass / took the single-file path / have a syntax error */
+int opusfe_group_stats(const opusfe_group* group, uint64_t* n_packed, uint64_t* n_single, uint64_t* n_syntax);
+/* opusfe_dump of ONE file of the group: byte-identical to the dump of the file compiled alone */
+int opusfe_group_dump(opusfe_group* group, uint32_t file, int what, char** out, uint64_t* out_len);
+void opusfe_free_group(opusfe_group* group);
+
 /* ---- one huge source sharded over several GPUs (no reference counterpart: the reference is single-threaded; this is the
    byte-range analogue of its sequential lexer state, parse.rs:364-391, carried across shards) ----
    A shard starts right after a '\n'.  The host chains three tiny exchanges (all_gather over RCCL): context function ->

@@ -73,6 +73,8 @@ void run_lexer(opusfe_ctx* ctx, opusfe_unit* u, int force_dents) {
     uint32_t T = 0, nval = 0, nstr = 0;
     opusfe_token* raw = nullptr;
     Resync rs{nullptr, 0};
+    GroupInfo* const grp = u->group;      // a corpus of files packed into this unit (opusfe_parse_group), else null
+    if (grp) rs = Resync{grp->d_start, grp->n_files, 1u, grp->d_fstatus, grp->d_len};
     if (!u->resync.empty()) {   // a later pass of parse_with_resync
         uint32_t* d = tmp.get<uint32_t>(u->resync.size());
         HIP_TRY(hipMemcpyAsync(d, u->resync.data(), u->resync.size() * 4, hipMemcpyHostToDevice, st));
@@ -111,18 +113,29 @@ void run_lexer(opusfe_ctx* ctx, opusfe_unit* u, int force_dents) {
     uint32_t* seg_flag = tmp.get<uint32_t>(G);
     uint32_t* seg_excl = tmp.get<uint32_t>(G);
     uint32_t* scan_tmp32 = tmp.get<uint32_t>((G + SCAN_TILE - 1) / SCAN_TILE + 1);
+    FileTok ft{};
+    if (grp && T > 0) {
+        // which file every token belongs to, the first token of every file, and (behind the depth scan) the depth in front of every file
+        uint32_t* fid = tmp.get<uint32_t>(T);
+        uint32_t* first_tok = tmp.get<uint32_t>(grp->n_files);
+        int32_t* base = tmp.get<int32_t>(grp->n_files);
+        HIP_TRY(hipMemsetAsync(first_tok, 0xFF, (size_t)grp->n_files * 4, st));
+        LAUNCH(ctx, "tok_file", k_tok_file, grid_for(T, 256), 256, raw, T, grp->d_start, grp->n_files, fid, first_tok, grp->d_flags);
+        ft = FileTok{grp->d_start, grp->d_len, grp->n_files, fid, first_tok, base};
+    }
     if (T > 0) {
-        LAUNCH(ctx, "tok_delta", k_tok_delta, grid_for(T, 256), 256, raw, T, depth, force_dents, (uint64_t)TK_NO_PREV);
+        LAUNCH(ctx, "tok_delta", k_tok_delta, grid_for(T, 256), 256, raw, T, depth, force_dents, (uint64_t)TK_NO_PREV, ft);
         prof_begin(ctx, "scan_depth");
         device_scan<false>(depth, depth, T, OpAddI32(), (int32_t)0, (int32_t*)scan_tmp32, (int32_t*)nullptr, st);
         prof_end(ctx);
         HIP_TRY(hipMemcpyAsync(ctx->d_status + W_ENDDEPTH, depth + (T - 1), 4, hipMemcpyDeviceToDevice, st));      // (opusfe_unit_end_state)
+        if (ft.n) LAUNCH(ctx, "file_base", k_file_base, grid_for(ft.n, 256), 256, (const int32_t*)depth, ft.first_tok, ft.n, (int32_t*)ft.base);
     }
-    LAUNCH(ctx, "tok_gap", k_gap, grid_for(G, 256), 256, src, n, raw, T, depth, gapval, (int32_t)0);
+    LAUNCH(ctx, "tok_gap", k_gap, grid_for(G, 256), 256, src, n, raw, T, depth, gapval, (int32_t)0, ft);
     prof_begin(ctx, "scan_indent");
     device_scan<true>(gapval, prev, G, OpLast(), (uint32_t)0, scan_tmp32, (uint32_t*)nullptr, st);
     prof_end(ctx);
-    LAUNCH(ctx, "tok_dent_count", k_dent_count, grid_for(G, 256), 256, gapval, prev, T, cnt);
+    LAUNCH(ctx, "tok_dent_count", k_dent_count, grid_for(G, 256), 256, gapval, prev, T, cnt, ft, (const int32_t*)depth);
     prof_begin(ctx, "scan_tokoff");
     device_scan<true>(cnt, out_off, G, OpAddU32(), (uint32_t)0, scan_tmp32, ctx->d_status + W_FINTOK, st);
     prof_end(ctx);
@@ -130,7 +143,9 @@ void run_lexer(opusfe_ctx* ctx, opusfe_unit* u, int force_dents) {
     const uint32_t total = ctx->h_status[W_FINTOK];
     u->d_tokens = dev_alloc_t<opusfe_token>(ctx, total);
     u->n_tokens = total;
-    LAUNCH(ctx, "tok_final", k_final, grid_for(G, 256), 256, raw, T, n, gapval, prev, out_off, u->d_tokens, seg_flag);
+    LAUNCH(ctx, "tok_final", k_final, grid_for(G, 256), 256, raw, T, n, gapval, prev, out_off, u->d_tokens, seg_flag, ft, (const int32_t*)depth, grp ? grp->d_tok_begin : (uint32_t*)nullptr);
+    if (grp && ft.n)      // what only the lexer can see of a file that needs the single-file path
+        LAUNCH(ctx, "file_lex_flags", k_file_lex_flags, grid_for(grp->n_files, 256), 256, ft.first_tok, (const uint32_t*)gapval, grp->n_files, (const uint32_t*)grp->d_fstatus, grp->d_flags);
     if (T > 0) {
         prof_begin(ctx, "scan_seg");
         device_scan<true>(seg_flag, seg_excl, T, OpAddU32(), (uint32_t)0, scan_tmp32, ctx->d_status + W_NSEG, st);
@@ -347,7 +362,7 @@ int opusfe_shard_net_depth(opusfe_shard* s, uint64_t prev_kinds, int64_t* net) {
         *net = 0;
         if (s->T == 0) return (int)OPUSFE_OK;
         hipStream_t st = ctx->stream;
-        LAUNCH(ctx, "tok_delta", k_tok_delta, grid_for(s->T, 256), 256, s->raw, s->T, s->depth, 0, prev_kinds);
+        LAUNCH(ctx, "tok_delta", k_tok_delta, grid_for(s->T, 256), 256, s->raw, s->T, s->depth, 0, prev_kinds, FileTok{});
         device_scan<false>(s->depth, s->depth, s->T, OpAddI32(), (int32_t)0, (int32_t*)s->scan_tmp, (int32_t*)(ctx->d_status + 61), st);
         HIP_TRY(hipMemcpyAsync(ctx->h_status + 61, ctx->d_status + 61, 4, hipMemcpyDeviceToHost, st));
         sync_stream(ctx);
@@ -366,7 +381,7 @@ int opusfe_shard_boundary(opusfe_shard* s, int64_t depth_in, uint64_t* pos) {
         if (s->T == 0) return (int)OPUSFE_OK;
         hipStream_t st = ctx->stream;
         const uint64_t G = (uint64_t)s->T + 1;
-        LAUNCH(ctx, "tok_gap", k_gap, grid_for(G, 256), 256, s->d_src, s->len, s->raw, s->T, s->depth, s->gapval, (int32_t)depth_in);
+        LAUNCH(ctx, "tok_gap", k_gap, grid_for(G, 256), 256, s->d_src, s->len, s->raw, s->T, s->depth, s->gapval, (int32_t)depth_in, FileTok{});
         device_scan<true>(s->gapval, s->prev, G, OpLast(), (uint32_t)0, s->scan_tmp, (uint32_t*)nullptr, st);
         HIP_TRY(hipMemsetAsync(ctx->d_status + 62, 0xFF, 4, st));
         LAUNCH(ctx, "shard_first_segment", k_shard_first_segment, grid_for(s->T, 256), 256, s->raw, s->T, s->gapval, s->prev, ctx->d_status + 62);
@@ -914,6 +929,324 @@ void opusfe_free_unit(opusfe_unit* u) {
     dev_free(ctx, u->d_nodes); dev_free(ctx, u->d_seg_info); dev_free(ctx, u->d_def_nodes); dev_free(ctx, u->d_headers); dev_free(ctx, u->d_parents);
     free_ir(ctx, u);
     delete u;
+}
+
+}  // extern "C"
+
+// ---- a corpus of independent files as ONE packed unit (BASELINE config 5) ---------------------------------------
+// Every file is its own compilation universe, like one run of the reference (frontend.rs:52-55).  opusfe_parse_batch gives every
+// file a pipeline of its own: ~40 launches and half a dozen host synchronisations per file, latency-bound whatever the GPU.  Here
+// the files are packed into one buffer (every file starts on a 64-byte boundary, '\n' in between) and go through the single-source
+// kernels TOGETHER: one launch per stage for the whole group.  What keeps the files apart:
+//   lexer     a file start resets the context automaton and is a token boundary (lex.h Resync in group mode); every file is lexed
+//             with its own end as the end of the source; Indent / Dedent synthesis, bracket depth and the EndOfFile token are per file
+//   parser    a file starts a top-level segment; the lowest failing segment of a file holds the file's first syntax error
+//   names     the payload of every name token (identifier hash, operator symbol) is shifted by file * FILE_MIX (defs.h) and a symbol
+//             key carries the mix of the function that looks it up (sem.h NameKey), so the name tables of sem.h scope every name to
+//             its file without knowing about files
+//   the rest  a file the packed pass cannot answer for exactly (FF_SINGLE: empty, indented first line, unsupported input, swallowed
+//             lexical errors, finalize-time semantic errors) is compiled alone by the single-source pipeline
+// The result is the packed unit plus a table per file (status, first error, token / definition / function ranges); the files that
+// took the single-file path carry a unit of their own.
+struct opusfe_group {
+    opusfe_ctx* ctx = nullptr;
+    opusfe_unit* unit = nullptr;
+    GroupInfo info;
+    bool lowered = false;
+    std::vector<uint32_t> start, len, flags, tok_begin, first_def, first_func, first_global, err_seg;
+    std::vector<int> status;
+    std::vector<opusfe_error> error;
+    std::vector<opusfe_unit*> single;
+    uint64_t n_single = 0;
+};
+
+namespace {
+
+__global__ void k_group_init(uint32_t* __restrict__ fstatus, uint32_t n_files) {
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < n_files) { fstatus[2 * f] = 0; fstatus[2 * f + 1] = 0xFFFFFFFFu; }
+}
+// line number of the first error of every faulty file: 1 + the '\n' before it, counted from the file's first byte (frontend.rs:213-225)
+__global__ void k_group_err_lines(const uint8_t* __restrict__ src, const uint32_t* __restrict__ lo, const uint32_t* __restrict__ hi, uint32_t n, uint32_t* __restrict__ lines) {
+    const uint32_t i = blockIdx.x;
+    if (i >= n) return;
+    uint32_t c = 0;
+    for (uint32_t p = lo[i] + threadIdx.x; p < hi[i]; p += blockDim.x) c += src[p] == '\n';
+    if (c) atomicAdd(&lines[i], c);
+}
+
+void group_release(opusfe_group* g) {
+    opusfe_ctx* ctx = g->ctx;
+    for (opusfe_unit* u : g->single) if (u) opusfe_free_unit(u);
+    if (g->unit) { g->unit->group = nullptr; opusfe_free_unit(g->unit); }
+    GroupInfo& I = g->info;
+    dev_free(ctx, I.d_start); dev_free(ctx, I.d_len); dev_free(ctx, I.d_flags); dev_free(ctx, I.d_fstatus); dev_free(ctx, I.d_tok_begin);
+    dev_free(ctx, I.d_err_seg); dev_free(ctx, I.d_first_def); dev_free(ctx, I.d_first_func); dev_free(ctx, I.d_first_global);
+    delete g;
+}
+
+// NONE entries of a "first x of file f" table: the file has none, so its range is empty at the next file's start
+void fill_forward(std::vector<uint32_t>& v, uint32_t end) {
+    uint32_t next = end;
+    for (size_t i = v.size(); i-- > 0;) { if (v[i] == OPUSFE_NONE) v[i] = next; else next = v[i]; }
+    v.push_back(end);
+}
+
+// the packed pass; returns false when the group as a whole has to take the single-file path (a status the packed unit cannot attribute to a file)
+bool group_packed_pass(opusfe_ctx* ctx, opusfe_group* g, int lower) {
+    opusfe_unit* u = g->unit;
+    GroupInfo& I = g->info;
+    const uint32_t F = I.n_files;
+    hipStream_t st = ctx->stream;
+    auto declined = [&](const char* stage) {
+        ctx->msg = std::string("group: the packed pass stopped in the ") + stage + " (status " + std::to_string(u->status) + ", device status " + std::to_string(u->dev_status) + "): every file takes the single-file path. " + ctx->msg;
+        return false;
+    };
+    run_lexer(ctx, u, 0);
+    if (u->status != OPUSFE_OK || u->n_tokens == 0) return declined("lexer");
+    run_parser(ctx, u);
+    if (u->status != OPUSFE_OK) return declined("parser");
+    if (lower) {
+        run_lower(ctx, u);
+        if (u->status != OPUSFE_OK) return declined("lowering");
+        g->lowered = true;
+    }
+    auto pull = [&](std::vector<uint32_t>& v, const uint32_t* d) { v.resize(F); HIP_TRY(hipMemcpyAsync(v.data(), d, (size_t)F * 4, hipMemcpyDeviceToHost, st)); };
+    pull(g->flags, I.d_flags); pull(g->tok_begin, I.d_tok_begin); pull(g->err_seg, I.d_err_seg);
+    if (lower) { pull(g->first_def, I.d_first_def); pull(g->first_func, I.d_first_func); pull(g->first_global, I.d_first_global); }
+    HIP_TRY(hipStreamSynchronize(st));
+    fill_forward(g->tok_begin, (uint32_t)u->n_tokens);
+    if (lower) {
+        const IrResult* R = (const IrResult*)u->ir;
+        fill_forward(g->first_def, (uint32_t)u->n_defs); fill_forward(g->first_func, R ? (uint32_t)R->n_funcs : 0u); fill_forward(g->first_global, R ? (uint32_t)R->n_globals : 0u);
+    }
+    // first syntax error of every faulty file that stays on the packed path (parse.rs:352-360 as data, positions relative to the file)
+    std::vector<uint32_t> bad;
+    for (uint32_t f = 0; f < F; f++) if ((g->flags[f] & FF_SYNTAX) && !(g->flags[f] & FF_SINGLE) && g->err_seg[f] != OPUSFE_NONE) bad.push_back(f);
+    if (!bad.empty()) {
+        std::vector<uint32_t> lo(bad.size()), hi(bad.size()), lines(bad.size(), 0);
+        for (size_t i = 0; i < bad.size(); i++) {
+            const uint32_t f = bad[i];
+            uint32_t si[SI_WORDS];
+            HIP_TRY(hipMemcpy(si, u->d_seg_info + (uint64_t)g->err_seg[f] * SI_WORDS, sizeof si, hipMemcpyDeviceToHost));
+            opusfe_token t{};
+            HIP_TRY(hipMemcpy(&t, u->d_tokens + si[SI_ERR_TOK], sizeof t, hipMemcpyDeviceToHost));
+            opusfe_error e{};
+            e.tok_index = si[SI_ERR_TOK];
+            if (si[SI_ERR_KIND] & 0x100u) {      // a lexical error token the parser consumed: its own span and payload
+                uint64_t v[2];
+                HIP_TRY(hipMemcpy(v, u->d_val64 + t.payload, sizeof v, hipMemcpyDeviceToHost));
+                e.kind = si[SI_ERR_KIND] & 0xFFu; e.low = (uint32_t)v[0]; e.len = (uint32_t)(v[0] >> 32); e.payload = v[1]; e.tok_kind = T_Error;
+            } else { e.kind = si[SI_ERR_KIND]; e.low = si[SI_ERR_LOW]; e.len = si[SI_ERR_LEN]; e.expected = si[SI_ERR_EXPECTED]; e.tok_kind = t.kind; }
+            lo[i] = g->start[f];
+            hi[i] = (uint32_t)std::min<uint64_t>(e.low, (uint64_t)g->start[f] + g->len[f]);
+            if (hi[i] < lo[i]) hi[i] = lo[i];
+            e.low -= g->start[f];
+            g->error[f] = e;
+        }
+        TempList tmp(ctx);
+        uint32_t* d_lo = tmp.get<uint32_t>(bad.size()); uint32_t* d_hi = tmp.get<uint32_t>(bad.size()); uint32_t* d_lines = tmp.get<uint32_t>(bad.size());
+        HIP_TRY(hipMemcpyAsync(d_lo, lo.data(), bad.size() * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_hi, hi.data(), bad.size() * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemsetAsync(d_lines, 0, bad.size() * 4, st));
+        LAUNCH(ctx, "group_err_lines", k_group_err_lines, bad.size(), 256, u->d_src, (const uint32_t*)d_lo, (const uint32_t*)d_hi, (uint32_t)bad.size(), d_lines);
+        HIP_TRY(hipMemcpyAsync(lines.data(), d_lines, bad.size() * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        prof_collect(ctx);
+        for (size_t i = 0; i < bad.size(); i++) g->error[bad[i]].line = 1 + lines[i];
+    }
+    for (uint32_t f = 0; f < F; f++) g->status[f] = (g->flags[f] & FF_SINGLE) ? OPUSFE_ERR_INTERNAL : (g->flags[f] & FF_SYNTAX) ? OPUSFE_SYNTAX : OPUSFE_OK;
+    return true;
+}
+
+int group_run(opusfe_ctx* ctx, opusfe_group* g, const uint8_t* d_packed, uint64_t packed_len, bool own_src, const uint8_t* const* host_srcs, int lower) {
+    GroupInfo& I = g->info;
+    const uint32_t F = I.n_files;
+    hipStream_t st = ctx->stream;
+    I.d_start = dev_alloc_t<uint32_t>(ctx, F); I.d_len = dev_alloc_t<uint32_t>(ctx, F); I.d_flags = dev_alloc_t<uint32_t>(ctx, F);
+    I.d_fstatus = dev_alloc_t<uint32_t>(ctx, 2ull * F); I.d_tok_begin = dev_alloc_t<uint32_t>(ctx, F); I.d_err_seg = dev_alloc_t<uint32_t>(ctx, F);
+    I.d_first_def = dev_alloc_t<uint32_t>(ctx, F); I.d_first_func = dev_alloc_t<uint32_t>(ctx, F); I.d_first_global = dev_alloc_t<uint32_t>(ctx, F);
+    HIP_TRY(hipMemcpyAsync(I.d_start, g->start.data(), (size_t)F * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(I.d_len, g->len.data(), (size_t)F * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(I.d_flags, 0, (size_t)F * 4, st));
+    for (uint32_t* p : {I.d_tok_begin, I.d_err_seg, I.d_first_def, I.d_first_func, I.d_first_global}) HIP_TRY(hipMemsetAsync(p, 0xFF, (size_t)F * 4, st));
+    hipLaunchKernelGGL(k_group_init, dim3(grid_for(F, 256)), dim3(256), 0, st, I.d_fstatus, F);
+    HIP_TRY(hipGetLastError());
+    g->unit = new_unit(ctx, d_packed, packed_len, own_src);
+    g->unit->group = &I;
+    g->status.assign(F, OPUSFE_ERR_INTERNAL); g->error.assign(F, opusfe_error{}); g->single.assign(F, nullptr);
+    const bool packed_ok = group_packed_pass(ctx, g, lower);
+    if (!packed_ok) { g->flags.assign(F, FF_INTERNAL); g->lowered = false; }
+    // the files the packed pass cannot answer for: alone through the single-source pipeline, several at a time (opusfe_parse_batch)
+    std::vector<uint32_t> todo;
+    for (uint32_t f = 0; f < F; f++) if (g->flags[f] & FF_SINGLE) todo.push_back(f);
+    g->n_single = todo.size();
+    if (!todo.empty()) {
+        std::vector<std::vector<uint8_t>> copies;
+        std::vector<const uint8_t*> srcs(todo.size()); std::vector<uint64_t> lens(todo.size());
+        if (!host_srcs) copies.resize(todo.size());
+        for (size_t i = 0; i < todo.size(); i++) {
+            const uint32_t f = todo[i];
+            lens[i] = g->len[f];
+            if (host_srcs) srcs[i] = host_srcs[f];
+            else {
+                copies[i].resize(g->len[f] + 1);
+                if (g->len[f]) HIP_TRY(hipMemcpyAsync(copies[i].data(), d_packed + g->start[f], g->len[f], hipMemcpyDeviceToHost, st));
+                srcs[i] = copies[i].data();
+            }
+        }
+        HIP_TRY(hipStreamSynchronize(st));
+        std::vector<opusfe_unit*> units(todo.size(), nullptr); std::vector<int> rcs(todo.size(), OPUSFE_ERR_INTERNAL);
+        const int rc = opusfe_parse_batch(ctx, (uint32_t)todo.size(), srcs.data(), lens.data(), lower, units.data(), rcs.data());
+        for (size_t i = 0; i < todo.size(); i++) { g->single[todo[i]] = units[i]; g->status[todo[i]] = rcs[i]; }
+        if (rc != OPUSFE_OK) return rc;
+    }
+    return OPUSFE_OK;
+}
+
+bool group_layout_ok(const std::vector<uint32_t>& start, const std::vector<uint32_t>& len, uint64_t packed_len) {
+    if (start.empty() || start[0] != 0) return false;
+    for (size_t f = 0; f < start.size(); f++) {
+        if (start[f] % LEX_CHUNK) return false;
+        const uint64_t end = (uint64_t)start[f] + len[f];
+        const uint64_t next = f + 1 < start.size() ? start[f + 1] : packed_len;
+        if (f + 1 < start.size() ? end >= next : end > next) return false;      // at least one byte of padding between two files
+    }
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int opusfe_parse_group_device(opusfe_ctx* ctx, const uint8_t* d_packed, uint64_t packed_len, uint32_t n_files, const uint64_t* starts, const uint64_t* lens, int lower, opusfe_group** out) {
+    if (!ctx || !out || !n_files || !starts || !lens || !d_packed) return OPUSFE_ERR_ARG;
+    *out = nullptr;
+    if (packed_len > MAX_LEN) return fail(ctx, OPUSFE_ERR_ARG, "group larger than 4 GiB: split it (opusfe positions are 32-bit per unit)");
+    opusfe_group* g = new opusfe_group();
+    g->ctx = ctx; g->info.n_files = n_files;
+    g->start.resize(n_files); g->len.resize(n_files);
+    for (uint32_t f = 0; f < n_files; f++) { g->start[f] = (uint32_t)starts[f]; g->len[f] = (uint32_t)lens[f]; }
+    if (!group_layout_ok(g->start, g->len, packed_len)) { delete g; return fail(ctx, OPUSFE_ERR_ARG, "group layout: starts must be multiples of 64, ascending, with at least one byte ('\\n') between files, starts[0] == 0"); }
+    *out = g;
+    int rc = guarded(ctx, [&] { return group_run(ctx, g, d_packed, packed_len, false, nullptr, lower); });
+    if (rc != OPUSFE_OK && rc != OPUSFE_SYNTAX) { (void)hipStreamSynchronize(ctx->stream); group_release(g); *out = nullptr; }
+    return rc;
+}
+
+int opusfe_parse_group(opusfe_ctx* ctx, uint32_t n_files, const uint8_t* const* srcs, const uint64_t* lens, int lower, opusfe_group** out) {
+    if (!ctx || !out || !n_files || !srcs || !lens) return OPUSFE_ERR_ARG;
+    *out = nullptr;
+    std::vector<uint64_t> starts(n_files);
+    uint64_t total = 0;
+    for (uint32_t f = 0; f < n_files; f++) { starts[f] = total; total = (total + lens[f] + 1 + (LEX_CHUNK - 1)) / LEX_CHUNK * LEX_CHUNK; }
+    if (total > MAX_LEN) return fail(ctx, OPUSFE_ERR_ARG, "group larger than 4 GiB: split it (opusfe positions are 32-bit per unit)");
+    opusfe_group* g = new opusfe_group();
+    g->ctx = ctx; g->info.n_files = n_files;
+    g->start.resize(n_files); g->len.resize(n_files);
+    for (uint32_t f = 0; f < n_files; f++) { g->start[f] = (uint32_t)starts[f]; g->len[f] = (uint32_t)lens[f]; }
+    *out = g;
+    int rc = guarded(ctx, [&] {
+        // pack on the host (one pinned staging buffer), one copy to the device
+        uint8_t* h = nullptr;
+        HIP_TRY(hipHostMalloc((void**)&h, total + 64, hipHostMallocDefault));
+        memset(h, '\n', total + 64);
+        for (uint32_t f = 0; f < n_files; f++) if (lens[f]) memcpy(h + starts[f], srcs[f], lens[f]);
+        uint8_t* d = nullptr;
+        try {
+            d = dev_alloc_t<uint8_t>(ctx, total + 64);
+            HIP_TRY(hipMemcpyAsync(d, h, total + 64, hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+        } catch (...) { (void)hipHostFree(h); if (d) dev_free(ctx, d); throw; }
+        (void)hipHostFree(h);
+        return group_run(ctx, g, d, total, true, srcs, lower);
+    });
+    if (rc != OPUSFE_OK && rc != OPUSFE_SYNTAX) { (void)hipStreamSynchronize(ctx->stream); group_release(g); *out = nullptr; }
+    return rc;
+}
+
+void opusfe_free_group(opusfe_group* g) {
+    if (!g) return;
+    (void)hipSetDevice(g->ctx->device);
+    (void)hipStreamSynchronize(g->ctx->stream);
+    group_release(g);
+}
+
+int opusfe_group_file_status(const opusfe_group* g, uint32_t file) { return g && file < g->info.n_files ? g->status[file] : OPUSFE_ERR_ARG; }
+
+int opusfe_group_file_error(const opusfe_group* g, uint32_t file, opusfe_error* out) {
+    if (!g || !out || file >= g->info.n_files) return OPUSFE_ERR_ARG;
+    if (g->single[file]) return opusfe_get_error(g->single[file], out);
+    if (g->status[file] != OPUSFE_SYNTAX) return OPUSFE_ERR_ARG;
+    *out = g->error[file];
+    return OPUSFE_OK;
+}
+
+/* the packed unit (every flat array of opusfe_array, positions relative to the packed buffer) and where a file's results lie in it:
+   ranges[0..1] tokens, [2..3] definitions, [4..5] functions (signatures / function IR), [6..7] globals, [8] byte offset of the file,
+   [9] the packed pass's flags for the file (defs.h FF_*: why it took the single-file path; FF_SYNTAX).
+   A file that took the single-file path has an empty range here and a unit of its own (opusfe_group_file_unit). */
+opusfe_unit* opusfe_group_unit(opusfe_group* g) { return g ? g->unit : nullptr; }
+opusfe_unit* opusfe_group_file_unit(opusfe_group* g, uint32_t file) { return g && file < g->info.n_files ? g->single[file] : nullptr; }
+int opusfe_group_file_ranges(const opusfe_group* g, uint32_t file, uint64_t* ranges) {
+    if (!g || !ranges || file >= g->info.n_files) return OPUSFE_ERR_ARG;
+    for (int k = 0; k < 10; k++) ranges[k] = 0;
+    ranges[8] = g->start[file]; ranges[9] = g->flags[file];
+    if (g->single[file] || g->tok_begin.size() <= file + 1) return OPUSFE_OK;
+    ranges[0] = g->tok_begin[file]; ranges[1] = g->tok_begin[file + 1];
+    if (g->lowered && g->status[file] == OPUSFE_OK) {
+        ranges[2] = g->first_def[file]; ranges[3] = g->first_def[file + 1]; ranges[4] = g->first_func[file]; ranges[5] = g->first_func[file + 1];
+        ranges[6] = g->first_global[file]; ranges[7] = g->first_global[file + 1];
+    }
+    return OPUSFE_OK;
+}
+
+int opusfe_group_stats(const opusfe_group* g, uint64_t* n_packed, uint64_t* n_single, uint64_t* n_syntax) {
+    if (!g || !n_packed || !n_single || !n_syntax) return OPUSFE_ERR_ARG;
+    *n_single = g->n_single; *n_packed = g->info.n_files - g->n_single; *n_syntax = 0;
+    for (int st : g->status) *n_syntax += st == OPUSFE_SYNTAX;
+    return OPUSFE_OK;
+}
+
+/* canonical text of ONE file of the group, identical to opusfe_dump of the file compiled alone (what: 0 tokens, 1 AST, 2 IR, 3 first-error line, 4 semantic errors) */
+int opusfe_group_dump(opusfe_group* g, uint32_t file, int what, char** out, uint64_t* out_len) {
+    if (!g || !out || file >= g->info.n_files) return OPUSFE_ERR_ARG;
+    *out = nullptr;
+    if (g->single[file]) return opusfe_dump(g->single[file], what, out, out_len);
+    opusfe_unit* u = g->unit;
+    return guarded(g->ctx, [&] {
+        std::string s;
+        ensure_host_lex(u);
+        DumpView w;
+        w.pos_off = g->start[file];
+        w.t0 = g->tok_begin[file]; w.t1 = g->tok_begin[file + 1];
+        const int fst = g->status[file];
+        if (g->lowered && fst == OPUSFE_OK) { w.d0 = g->first_def[file]; w.d1 = g->first_def[file + 1]; w.f0 = g->first_func[file]; w.f1 = g->first_func[file + 1]; w.glob_off = g->first_global[file]; }
+        else { w.d0 = w.d1 = 0; w.f0 = w.f1 = 0; }
+        switch (what) {
+            case 0: s = dump_tokens(u, fst == OPUSFE_SYNTAX ? (uint64_t)g->error[file].tok_index + 1 : ~0ull, w); break;
+            case 1: if (fst != OPUSFE_OK || !g->lowered) { g->ctx->msg = "no AST: the file did not parse (or the group was not lowered: the definition ranges come with the tables)"; return (int)OPUSFE_ERR_ARG; }
+                    ensure_host_ast(u); s = dump_ast(u, w); break;
+            case 2: if (fst == OPUSFE_OK && g->lowered) { ensure_host_ast(u); ensure_host_ir(u); s = dump_ir(u, w); } break;
+            case 4: if (fst == OPUSFE_OK && g->lowered) { ensure_host_ir(u); s = dump_semantic_errors(u, &w); } break;
+            case 3: {
+                if (fst != OPUSFE_SYNTAX) { s = "Ok\n"; break; }
+                HostView v{u, w.pos_off};
+                const opusfe_error& e = g->error[file];
+                const opusfe_token* found = e.tok_index < u->h_tokens.size() ? &u->h_tokens[e.tok_index] : nullptr;
+                fmt_error_body(s, e.kind, e.low, e.len, e.payload, v, found, (int)e.expected);
+                s += " line "; s += std::to_string(e.line); s += '\n';
+                break;
+            }
+            default: return (int)OPUSFE_ERR_ARG;
+        }
+        char* p = (char*)malloc(s.size() + 1);
+        if (!p) return (int)OPUSFE_ERR_OOM;
+        memcpy(p, s.data(), s.size()); p[s.size()] = 0;
+        *out = p;
+        if (out_len) *out_len = s.size();
+        return (int)OPUSFE_OK;
+    });
 }
 
 int opusfe_set_profiling(opusfe_ctx* ctx, int enabled) {

@@ -193,3 +193,20 @@ enum CastKind : uint8_t { CT_None, CT_Pointer, CT_PointerType, CT_Integer, CT_Po
 enum DevStatus : uint32_t { DS_OK = 0, DS_UNSUPPORTED_NONASCII = 1, DS_UNSUPPORTED_FLOAT = 2, DS_UNSUPPORTED_HANG = 3,
                             DS_UNSUPPORTED_RESYNC = 4, DS_UNSUPPORTED_SEMANTIC = 5, DS_INTERNAL_CAPACITY = 16,
                             DS_INTERNAL_SEGMENT = 17 };
+
+// ---- group mode: a corpus of independent files packed into one unit (BASELINE config 5; api.hip opusfe_parse_group) ----
+namespace opusfe {
+// index of the last listed position <= p: the file that byte p belongs to (pos[0] == 0)
+__host__ __device__ inline uint32_t pos_file(const uint32_t* pos, uint32_t n, uint32_t p) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) { uint32_t mid = (lo + hi) / 2; if (pos[mid] <= p) lo = mid + 1; else hi = mid; }
+    return lo ? lo - 1 : 0;
+}
+// identifier hashes of file f are shifted by f * FILE_MIX (odd, so one name never has the same hash in two files of a group): the
+// name tables of the semantic passes then scope every name to its file without knowing about files
+constexpr uint32_t FILE_MIX = 0x9E3779B1u;
+// per-file flags: FF_SYNTAX = the file has a first syntax error (a result, not a problem); FF_SINGLE = reasons why the packed pass
+// cannot answer for the file exactly — it is then run alone through the single-source pipeline
+enum : uint32_t { FF_EMPTY = 1u, FF_INDENTED = 2u, FF_UNSUP = 16u, FF_RESYNC = 32u, FF_INTERNAL = 64u, FF_FINERR = 256u, FF_SYNTAX = 512u,
+                  FF_SINGLE = FF_EMPTY | FF_INDENTED | FF_UNSUP | FF_RESYNC | FF_INTERNAL | FF_FINERR };
+}  // namespace opusfe

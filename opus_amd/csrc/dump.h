@@ -66,8 +66,13 @@ inline void fmt_debug_str(std::string& out, const uint8_t* p, size_t n) {
     out += '"';
 }
 
+// Which part of a unit a dump shows: everything, or (group mode) the slice of one file of a packed corpus with positions and global
+// indices relative to that file, so that the text equals the dump of the file compiled alone.
+struct DumpView { uint32_t pos_off = 0, glob_off = 0; uint64_t t0 = 0, t1 = ~0ull; uint32_t d0 = 0, d1 = 0xFFFFFFFFu, f0 = 0, f1 = 0xFFFFFFFFu; };
+
 struct HostView {
     const opusfe_unit* u;
+    uint32_t pos_off = 0;
     const uint8_t* src() const { return u->h_src.data(); }
     const opusfe_token& tok(uint32_t i) const { return u->h_tokens[i]; }
     uint64_t tok_u64(const opusfe_token& t) const { return (t.flags & OPUSFE_TF_INLINE) ? t.payload : u->h_val64[t.payload]; }
@@ -109,22 +114,23 @@ inline void fmt_token_debug(std::string& out, const HostView& v, const opusfe_to
         case T_Identifier: out += "Identifier("; fmt_debug_str(out, v.src() + t.low, t.len); out += ')'; break;
         case T_Error: {
             uint64_t sp = v.u->h_val64[t.payload], pl = v.u->h_val64[t.payload + 1];
-            out += "Err("; fmt_error_body(out, t.aux, (uint32_t)sp, (uint32_t)(sp >> 32), pl, v, nullptr, 0); out += ')';
+            out += "Err("; fmt_error_body(out, t.aux, (uint32_t)sp - v.pos_off, (uint32_t)(sp >> 32), pl, v, nullptr, 0); out += ')';
             break;
         }
         default: out += TOKEN_NAMES[t.kind];
     }
 }
 
-inline std::string dump_tokens(const opusfe_unit* u, uint64_t limit) {
-    HostView v{u};
+inline std::string dump_tokens(const opusfe_unit* u, uint64_t limit, const DumpView& w = DumpView{}) {
+    HostView v{u, w.pos_off};
     std::string out;
     uint64_t n = u->h_tokens.size() < limit ? u->h_tokens.size() : limit;
-    for (uint64_t i = 0; i < n; i++) {
+    if (w.t1 < n) n = w.t1;
+    for (uint64_t i = w.t0; i < n; i++) {
         const opusfe_token& t = u->h_tokens[i];
         uint64_t end = (uint64_t)t.low + t.len;
         if (t.kind == T_Error && (t.flags & OPUSFE_TF_RESYNC)) { uint64_t sp = u->h_val64[t.payload]; end = (uint32_t)sp + (sp >> 32); }   // the reference resumes right behind the error span; `len` runs to where the context automaton returns to code
-        out += std::to_string(t.low); out += ' '; out += std::to_string(end); out += ' ';
+        out += std::to_string(t.low - w.pos_off); out += ' '; out += std::to_string(end - w.pos_off); out += ' ';
         fmt_token_debug(out, v, t);
         out += '\n';
     }

@@ -48,7 +48,7 @@ struct AstText {
     const opusfe_node& n(uint32_t i) const { return u->h_nodes[i]; }
     void span_line(char cls, uint32_t i) {
         spans += "  "; spans += cls; spans += ' '; spans += kind_name(n(i).kind); spans += ' ';
-        spans += std::to_string(n(i).low); spans += ' '; spans += std::to_string(n(i).high); spans += '\n';
+        spans += std::to_string(n(i).low - v.pos_off); spans += ' '; spans += std::to_string(n(i).high - v.pos_off); spans += '\n';
     }
     void dbg_name(uint32_t tok) { std::string s = name_of_token(v, tok); fmt_debug_str(dbg, (const uint8_t*)s.data(), s.size()); }
     void type(uint32_t i) {
@@ -194,14 +194,15 @@ struct AstText {
             }
             default: dbg += "?"; break;
         }
-        dbg += " @ "; dbg += std::to_string(d.low); dbg += ".."; dbg += std::to_string(d.high); dbg += '\n';
+        dbg += " @ "; dbg += std::to_string(d.low - v.pos_off); dbg += ".."; dbg += std::to_string(d.high - v.pos_off); dbg += '\n';
     }
 };
 
-inline std::string dump_ast(const opusfe_unit* u) {
+inline std::string dump_ast(const opusfe_unit* u, const DumpView& w = DumpView{}) {
     std::string out;
-    AstText a{u, HostView{u}, {}, {}};
-    for (uint32_t d : u->h_def_nodes) {
+    AstText a{u, HostView{u, w.pos_off}, {}, {}};
+    for (size_t k = w.d0; k < u->h_def_nodes.size() && k < w.d1; k++) {
+        const uint32_t d = u->h_def_nodes[k];
         a.dbg.clear(); a.spans.clear();
         a.def(d);
         out += a.dbg;

@@ -65,11 +65,13 @@ struct IrText {
         out += "]: "; type(out, fr.ret);
     }
     static void var(std::string& out, uint32_t x) { out += '%'; out += std::to_string(x); }
+    uint32_t glob_off = 0, f0 = 0, f1 = 0xFFFFFFFFu;      // (DumpView: one file of a packed corpus)
     void text(std::string& out) const {
         static const char* const OPS[] = {"add", "subtract", "multiply", "divide", "modulo", "equals", "lessthan", "greaterthan", "lessthanequals",
                                           "greaterthanequals"};
         static const char* const CASTS[] = {"None", "Pointer", "PointerType", "Integer", "PointerToInteger", "IntegerToPointer", "PointerToArray", "Error"};
-        for (const FuncIr& f : R->funcs) {
+        for (size_t fi = f0; fi < R->funcs.size() && fi < f1; fi++) {
+            const FuncIr& f = R->funcs[fi];
             if (f.n_bbs == 0) continue;   // extern
             function(out, f.func); out += '\n';
             for (uint32_t i = 0; i < f.n_vars; i++) { out += "VAR %"; out += std::to_string(i); out += ": "; type(out, R->vars[f.var_base + i].type_id); out += '\n'; }
@@ -102,8 +104,8 @@ struct IrText {
                         case I_LessThanEquals: case I_GreaterThanEquals:
                             var(out, in.dst); out += " = "; out += OPS[in.opcode - I_Add]; out += ' '; var(out, in.a); out += ", "; var(out, in.b); break;
                         case I_Function: var(out, in.dst); out += " = global $"; function(out, in.c); break;
-                        case I_GlobalVariable: var(out, in.dst); out += " = globalvar %"; out += std::to_string(in.c); break;
-                        case I_GlobalConstant: var(out, in.dst); out += " = globalconst %"; out += std::to_string(in.c); break;
+                        case I_GlobalVariable: var(out, in.dst); out += " = globalvar %"; out += std::to_string(in.c - glob_off); break;
+                        case I_GlobalConstant: var(out, in.dst); out += " = globalconst %"; out += std::to_string(in.c - glob_off); break;
                         case I_Not: var(out, in.dst); out += " = not "; var(out, in.a); break;
                         case I_Negate: var(out, in.dst); out += " = negate "; var(out, in.a); break;
                         case I_Cast:
@@ -129,17 +131,18 @@ struct IrText {
     }
 };
 
-inline std::string dump_ir(const opusfe_unit* u) {
+inline std::string dump_ir(const opusfe_unit* u, const DumpView& w = DumpView{}) {
     const IrResult* R = (const IrResult*)u->ir;
     std::string out;
     if (!R || u->status != OPUSFE_OK) return out;
-    IrText t{u, R, HostView{u}};
+    IrText t{u, R, HostView{u, w.pos_off}};
+    t.glob_off = w.glob_off; t.f0 = w.f0; t.f1 = w.f1;
     t.text(out);
     return out;
 }
 
 // "<Kind> <low> <len>\n" per semantic error raised during IR generation, functions in definition order
-inline std::string dump_semantic_errors(const opusfe_unit* u) {
+inline std::string dump_semantic_errors(const opusfe_unit* u, const DumpView* w = nullptr) {
     static const char* const NAMES[] = {"ParseError", "UndefinedVariable", "ShadowedName", "UndefinedFunction", "NoOverloadForFunction", "AmbiguousOverload",
         "AmbiguousFunctionReference", "UnexpectedType", "InvalidType", "InvalidOperandType", "InvalidOperandTypes", "FunctionMightNotReturn", "BreakOutsideLoop",
         "ContinueOutsideLoop", "InvalidLvalue", "ImmutableLvalue", "ArrayPointerToNonArray", "InvalidCast", "UndefinedType", "FieldAccessOnNonRecord",
@@ -147,6 +150,17 @@ inline std::string dump_semantic_errors(const opusfe_unit* u) {
     const IrResult* R = (const IrResult*)u->ir;
     std::string out;
     if (!R) return out;
+    if (w) {      // one file of a packed corpus: the diagnostics of its functions, positions relative to the file
+        for (size_t fi = w->f0; fi < R->funcs.size() && fi < w->f1; fi++) {
+            const FuncIr& f = R->funcs[fi];
+            for (uint32_t k = 0; k < f.n_errs && (size_t)f.err_base + k < R->errs.size(); k++) {
+                const SemErr& e = R->errs[f.err_base + k];
+                if (e.kind == SE_Continuation) continue;
+                out += NAMES[e.kind]; out += ' '; out += std::to_string(e.low - w->pos_off); out += ' '; out += std::to_string(e.len); out += '\n';
+            }
+        }
+        return out;
+    }
     for (const SemErr& e : R->errs) { if (e.kind == SE_Continuation) continue; out += NAMES[e.kind]; out += ' '; out += std::to_string(e.low); out += ' '; out += std::to_string(e.len); out += '\n'; }
     return out;
 }

@@ -63,8 +63,9 @@ struct OpCtx { __host__ __device__ uint32_t operator()(uint32_t a, uint32_t b) c
 // Group mode (a corpus of independent files packed into one buffer, BASELINE config 5; api.hip opusfe_parse_group): the same list
 // holds the START of every file (pos[0] == 0, every start a multiple of LEX_CHUNK, '\n' between the files) — a file start is exactly
 // "context N and a token boundary" — with `files` set; `fstatus` then receives the unsupported-input records per file (2 words each).
-struct Resync { const uint32_t* pos; uint32_t n; uint32_t files; uint32_t* fstatus; };
-constexpr uint32_t FILE_MIX = 0x9E3779B1u;   // identifier hashes of file f are shifted by f * FILE_MIX (odd: distinct files never share a hash for one name)
+// Every file is lexed with ITS OWN end as the end of the source (`flen`), so end-of-file behaviour (parse.rs:461-464, 574-580, 701, 712) is the file's.
+struct Resync { const uint32_t* pos; uint32_t n; uint32_t files; uint32_t* fstatus; const uint32_t* flen; };
+
 constexpr uint32_t CTX_RESET = 0;   // every state -> N
 // smallest listed position >= p, else 0xFFFFFFFF
 __host__ __device__ __forceinline__ uint32_t rs_next(const Resync& rs, uint32_t p) {
@@ -73,12 +74,7 @@ __host__ __device__ __forceinline__ uint32_t rs_next(const Resync& rs, uint32_t 
     return lo < rs.n ? rs.pos[lo] : 0xFFFFFFFFu;
 }
 __host__ __device__ __forceinline__ bool rs_has(const Resync& rs, uint32_t p) { return rs.n != 0 && rs_next(rs, p) == p; }
-// index of the last listed position <= p (group mode: the file that byte p belongs to; pos[0] == 0)
-__host__ __device__ __forceinline__ uint32_t pos_file(const uint32_t* pos, uint32_t n, uint32_t p) {
-    uint32_t lo = 0, hi = n;
-    while (lo < hi) { uint32_t mid = (lo + hi) / 2; if (pos[mid] <= p) lo = mid + 1; else hi = mid; }
-    return lo ? lo - 1 : 0;
-}
+
 
 __global__ __launch_bounds__(LEX_THREADS) void k_ctx_chunk(const uint8_t* __restrict__ src, uint32_t n, uint32_t* __restrict__ chunk_fn, uint32_t* __restrict__ tile_fn, Resync rs) {
     __shared__ uint32_t lds[4];
@@ -580,8 +576,13 @@ __global__ LEX_ATTR __launch_bounds__(LEX_THREADS) void k_lex_count(const uint8_
     Cnt3 c{0, 0, 0, 0};
     if (live) {
         uint32_t cbeg = (uint32_t)base, cend = (uint32_t)((base + LEX_CHUNK < n) ? base + LEX_CHUNK : n);
-        if (rs.files) status = rs.fstatus + 2 * pos_file(rs.pos, rs.n, cbeg);      // group mode: unsupported inputs are recorded per file
-        lex_chunk(src, n, cbeg, cend, state, status, rs, [&](uint32_t pos) {
+        if (rs.files) {      // group mode: the source ends where the chunk's file ends; unsupported inputs are recorded per file
+            const uint32_t f = pos_file(rs.pos, rs.n, cbeg);
+            status = rs.fstatus + 2 * f;
+            n = rs.pos[f] + rs.flen[f];
+            if (cend > n) cend = n;
+        }
+        if (cbeg < cend) lex_chunk(src, n, cbeg, cend, state, status, rs, [&](uint32_t pos) {
             LexTok t;
             lex_one(src, n, pos, t, nullptr, status, rs);
             c.tok++; c.val += t.nval; c.str += t.strbytes;
@@ -616,8 +617,13 @@ __global__ LEX_ATTR __launch_bounds__(LEX_THREADS) void k_lex_emit(const uint8_t
     uint32_t state = chunk_state[chunk];
     uint32_t ti = off.tok, vi = off.val, si = off.str;
     uint32_t mix = 0;
-    if (rs.files) { const uint32_t f = pos_file(rs.pos, rs.n, cbeg); status = rs.fstatus + 2 * f; mix = f * FILE_MIX; }
-    lex_chunk(src, n, cbeg, cend, state, status, rs, [&](uint32_t pos) {
+    if (rs.files) {
+        const uint32_t f = pos_file(rs.pos, rs.n, cbeg);
+        status = rs.fstatus + 2 * f; mix = f * FILE_MIX;
+        n = rs.pos[f] + rs.flen[f];
+        if (cend > n) cend = n;
+    }
+    if (cbeg < cend) lex_chunk(src, n, cbeg, cend, state, status, rs, [&](uint32_t pos) {
         LexTok t;
         lex_one(src, n, pos, t, strpool + si, status, rs);
         opusfe_token o;
@@ -625,7 +631,7 @@ __global__ LEX_ATTR __launch_bounds__(LEX_THREADS) void k_lex_emit(const uint8_t
         if (t.kind == T_Error) { o.low = pos; o.payload = vi; }
         else if (t.kind == T_String) o.payload = si;
         else if (t.nval) o.payload = vi;
-        else o.payload = t.kind == T_Identifier ? t.payload + mix : t.payload;
+        else o.payload = t.kind == T_Integer ? t.payload : t.payload + mix;      // group mode: names (identifiers, operator symbols) carry their file
         if (t.nval >= 1) val64[vi] = t.v0;
         if (t.nval >= 2) val64[vi + 1] = t.v1;
         vi += t.nval; si += t.strbytes;
@@ -656,9 +662,6 @@ __device__ __forceinline__ bool tk_record_open(const opusfe_token* __restrict__ 
 // Group mode tables of the token-level passes: file of every raw token, first raw token of every file (NONE: the file has none),
 // bracket depth in front of every file (the running sum is taken over the whole group; a file counts from its own start).
 struct FileTok { const uint32_t* start; const uint32_t* len; uint32_t n; const uint32_t* fid; const uint32_t* first_tok; const int32_t* base; };
-enum : uint32_t { FF_EMPTY = 1u, FF_INDENTED = 2u, FF_ENDSTATE = 4u, FF_TAILF = 8u, FF_UNSUP = 16u, FF_RESYNC = 32u, FF_INTERNAL = 64u, FF_OPDEF = 128u,
-                  FF_FINERR = 256u, FF_SYNTAX = 512u,
-                  FF_SINGLE = FF_EMPTY | FF_INDENTED | FF_ENDSTATE | FF_TAILF | FF_UNSUP | FF_RESYNC | FF_INTERNAL | FF_OPDEF | FF_FINERR };
 
 __global__ void k_tok_file(const opusfe_token* __restrict__ raw, uint32_t T, const uint32_t* __restrict__ start, uint32_t n_files, uint32_t* __restrict__ fid,
                            uint32_t* __restrict__ first_tok, uint32_t* __restrict__ flags) {
@@ -834,6 +837,20 @@ __global__ void k_shard_first_segment(const opusfe_token* __restrict__ raw, uint
     uint8_t kd = raw[k].kind;
     if (kd == T_Else || kd == T_Error) return;
     atomicMin(out_pos, raw[k].low);
+}
+
+// Group mode, one lane per file: what only the lexer can see of a file whose packed lexing may differ from lexing it alone (the
+// file then takes the single-file path): no token at all (its EndOfFile token has no gap to live in), an indented first line (its
+// Indent tokens would fall into the previous file's last segment), an input the reference cannot be followed on.
+__global__ void k_file_lex_flags(const uint32_t* __restrict__ first_tok, const uint32_t* __restrict__ gapval, uint32_t n_files,
+                                 const uint32_t* __restrict__ fstatus, uint32_t* __restrict__ flags) {
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_files) return;
+    uint32_t fl = 0;
+    if (first_tok[f] == OPUSFE_NONE) fl |= FF_EMPTY;
+    else if (gapval[first_tok[f]] & 0x7FFFFFFFu) fl |= FF_INDENTED;
+    if (fstatus[2 * f]) fl |= FF_UNSUP;
+    if (fl) atomicOr(&flags[f], fl);
 }
 
 // seg_start[id] = index in the final token stream where segment id starts

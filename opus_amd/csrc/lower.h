@@ -83,7 +83,7 @@ using ::uni;
 __device__ __forceinline__ uint8_t uni(uint8_t v) { return (uint8_t)uni((uint32_t)v); }
 __device__ __forceinline__ uint16_t uni(uint16_t v) { return (uint16_t)uni((uint32_t)v); }
 __device__ __forceinline__ bool uni(bool v) { return uni((uint32_t)v) != 0; }
-__device__ __forceinline__ NameKey uni(NameKey k) { return NameKey{uni(k.tok), uni(k.sym)}; }
+__device__ __forceinline__ NameKey uni(NameKey k) { return NameKey{uni(k.tok), uni(k.sym), uni(k.mix)}; }
 // Arguments of a helper that is not inlined arrive in VGPRs and the compiler has to assume that they differ between
 // lanes (every `if` becomes a compare + exec-mask sequence).  They never do here: say so once at the top of the helper.
 __device__ __forceinline__ LFrame uni(const LFrame& f) {
@@ -161,6 +161,7 @@ struct Lowerer {
     MACHINE_STATE uint32_t dev_status;
     MACHINE_STATE LFrame cur;
     MACHINE_STATE uint32_t rv; MACHINE_STATE bool rl; MACHINE_STATE bool rdiv;
+    MACHINE_STATE uint32_t sym_mix;  // the file mix of this function's symbol keys (sem.h NameKey; 0 outside group mode)
     MACHINE_STATE bool sym_locals;   // some local is named by an operator symbol (`operator +` as a variable name): only then can a symbol key hit a local
 #ifdef OPUSFE_LOWER_PROF
     MACHINE_STATE uint64_t prof[LP_COUNT];
@@ -181,7 +182,7 @@ struct Lowerer {
     __device__ bool neq(NameKey a, NameKey b) const {
         uint8_t sa = name_sym(TokView{}, a), sb = name_sym(TokView{}, b);
         if (sa != sb) return false;
-        if (sa != T_Identifier) return true;
+        if (sa != T_Identifier) return name_mix(TokView{}, a) == name_mix(TokView{}, b);
         const opusfe_token x = TK(a.tok), y = TK(b.tok);
         if (x.len != y.len || x.payload != y.payload) return false;
         if (x.low == y.low) return true;
@@ -622,7 +623,7 @@ struct Lowerer {
                 }
             }
         }
-        return call_variables(sp_low, sp_high, key_sym(sym), Args{nullptr, a0, a1}, n, span_node, same_span);
+        return call_variables(sp_low, sp_high, key_sym(sym, sym_mix), Args{nullptr, a0, a1}, n, span_node, same_span);
     }
     // IrGenerator::lookup_function + get_function_call_variables (generate_ir.rs:1151-1198).
     // argv[0..n) are updated in place by the autocasts; span of argument i = node `span_node` (same for all when
@@ -948,7 +949,7 @@ struct Lowerer {
                 uint32_t off = reserve_cargs(1);
                 gst(cargs + off, rv);
                 uint32_t for_fn, ret_var;
-                Callee cl = call_variables(elow, ehigh, key_sym(T_For), Args{cargs + off, 0, 0}, 1, inode, true);
+                Callee cl = call_variables(elow, ehigh, key_sym(T_For, sym_mix), Args{cargs + off, 0, 0}, 1, inode, true);
                 if (cl.ok) { for_fn = cl.fv; ret_var = cl.out; }
                 else { for_fn = generate_error(); ret_var = generate_error(); }
                 uint32_t iterator_variable = new_var(type_mut(vtype(ret_var)), true);
@@ -971,7 +972,7 @@ struct Lowerer {
                 uint32_t off2 = reserve_cargs(2);
                 gst(cargs + off2, iterator_variable); gst(cargs + off2 + 1, iteration_variable);
                 uint32_t cont_fn, cond;
-                cl = call_variables(elow, ehigh, key_sym(T_Continue), Args{cargs + off2, 0, 0}, 2, inode, true);
+                cl = call_variables(elow, ehigh, key_sym(T_Continue, sym_mix), Args{cargs + off2, 0, 0}, 2, inode, true);
                 if (cl.ok) { cont_fn = cl.fv; cond = cl.out; }
                 else { cont_fn = generate_error(); cond = generate_error(); }
                 push(ins(I_Call, cond, cont_fn, 0, off2, 0, 2));
@@ -1342,7 +1343,7 @@ __global__ void k_sem_user_syms(SemView S, uint64_t* __restrict__ out) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         uint64_t m = 0;
         for (int i = 0; i < 11; i++) {
-            uint32_t s = name_find(S, key_sym(SYMS[i]));
+            uint32_t s = name_find(S, key_sym(SYMS[i], 0));
             if (s == OPUSFE_NONE) continue;
             const NameSlot sl = S.slots[s];
             for (uint32_t j = 0; j < sl.count; j++) if ((S.entries[sl.offset + j].kind_index >> 30) == NK_FUNCTION) { m |= 1ull << SYMS[i]; break; }
@@ -1385,7 +1386,7 @@ __global__ MACHINE_ATTR(OPUSFE_LOWER_WAVES) __launch_bounds__(64) void k_lower_f
     L.frames = B.frames + lower_base(CAP_FRAMES, sb_n, sb_f); L.sp = 0; L.fcap = (uint32_t)lower_cap(CAP_FRAMES, nn);
     L.errs = B.errs + lower_base(CAP_ERRS, sb_n, sb_f); L.nerrs = 0; L.ncont = 0; L.ecap = (uint32_t)lower_cap(CAP_ERRS, nn); L.einfo_clear();
     L.bb_index = 0; L.break_head = OPUSFE_NONE; L.loop_begin = OPUSFE_NONE; L.dev_status = DS_OK;
-    L.rv = 0; L.rl = false; L.rdiv = false; L.sym_locals = false;
+    L.rv = 0; L.rl = false; L.rdiv = false; L.sym_locals = false; L.sym_mix = S.mix_of_def(dn);
     for (uint32_t j = lane; j < (LDS_VARS + 31) / 32; j += UNIT_LANES) L.lds.vnamed[j] = 0;
     // body = last child of the definition
     uint32_t c = S.nodes[dn].first_child;
@@ -1510,7 +1511,7 @@ __global__ void k_err_order(FuncIr* __restrict__ f, uint32_t n, const uint32_t* 
 
 // functions too large for the node-parallel path (known before it runs): the machine starts on them at once, on a second stream
 __global__ void k_fb_mark_size(const uint32_t* __restrict__ def_nodes, uint32_t n_defs, uint32_t n_nodes, const DefCnt* __restrict__ def_excl,
-                               const opusfe_node* __restrict__ nodes, uint32_t limit, uint32_t* __restrict__ fb_flag, FbIdx* __restrict__ fbx) {
+                               const opusfe_node* __restrict__ nodes, uint32_t limit, uint32_t* __restrict__ fb_flag, FbIdx* __restrict__ fbx, const uint8_t* __restrict__ skip) {
     const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= n_defs) return;
     const uint32_t dn = def_nodes[d];
@@ -1518,7 +1519,7 @@ __global__ void k_fb_mark_size(const uint32_t* __restrict__ def_nodes, uint32_t 
     if (k != D_Function && k != D_Extern) return;
     const uint32_t fidx = def_excl[d].funcs;
     const uint32_t nn = (d + 1 < n_defs ? def_nodes[d + 1] : n_nodes) - dn;
-    const bool big = k == D_Function && nn >= limit;
+    const bool big = k == D_Function && nn >= limit && !(skip && skip[d]);
     fb_flag[fidx] = big ? 1u : 0u;
     fbx[fidx] = FbIdx{big ? nn : 0u, big ? 1u : 0u};
 }
@@ -1549,6 +1550,16 @@ inline void free_ir(opusfe_ctx* ctx, opusfe_unit* u) {
 }
 
 enum { WL_STATUS = 32, WL_ERRS = 33, WL_FBTOT = 34 /* FbIdx: 2 */, WL_BODIES = 52, WL_DEFTOT = 36 /* DefCnt: 4 */, WL_GT = 40, WL_FINERR = 41, WL_IRTOT = 44 /* IrCnt: 6 */, WL_SLOTTOT = 50 };
+
+// group mode: first function / global of every file (NONE for a file without definitions)
+__global__ void k_group_file_ranges(const uint32_t* __restrict__ first_def, const DefCnt* __restrict__ def_excl, uint32_t n_files, uint32_t* __restrict__ first_func,
+                                    uint32_t* __restrict__ first_global) {
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_files) return;
+    const uint32_t d = first_def[f];
+    first_func[f] = d == OPUSFE_NONE ? OPUSFE_NONE : def_excl[d].funcs;
+    first_global[f] = d == OPUSFE_NONE ? OPUSFE_NONE : def_excl[d].globals;
+}
 
 inline uint32_t next_pow2(uint64_t v) { uint32_t p = 16; while (p < v) p <<= 1; return p; }
 
@@ -1593,6 +1604,15 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
     uint32_t* def_slot = tmp.get<uint32_t>(n_defs);
     uint32_t* slot_off = tmp.get<uint32_t>(n_slots);
     LAUNCH(ctx, "sem_slots_init", k_sem_slots_init, grid_for(n_slots, 256), 256, slots, n_slots);
+    // group mode: which file every definition belongs to
+    GroupInfo* const grp = u->group;
+    uint32_t* def_file = nullptr; uint8_t* def_skip = nullptr;
+    if (grp) {
+        def_file = tmp.get<uint32_t>(n_defs); def_skip = tmp.get<uint8_t>(n_defs);
+        HIP_TRY(hipMemsetAsync(grp->d_first_def, 0xFF, (size_t)grp->n_files * 4, st));
+        LAUNCH(ctx, "group_first_defs", k_group_first_defs, grid_for(n_defs, 256), 256, u->d_nodes, u->d_def_nodes, n_defs, (const uint32_t*)grp->d_start, grp->n_files, grp->d_first_def, def_file);
+        LAUNCH(ctx, "group_file_ranges", k_group_file_ranges, grid_for(grp->n_files, 256), 256, (const uint32_t*)grp->d_first_def, (const DefCnt*)def_excl, grp->n_files, grp->d_first_func, grp->d_first_global);
+    }
     LAUNCH(ctx, "sem_table_insert", k_sem_table_insert, grid_for(n_defs, 256), 256, u->d_src, u->d_tokens, u->d_nodes, u->d_def_nodes, n_defs, slots, n_slots - 1, def_slot);
     LAUNCH(ctx, "sem_slot_counts", k_sem_slot_counts, grid_for(n_slots, 256), 256, slots, n_slots, slot_off);
     uint32_t* scan_tmp2 = tmp.get<uint32_t>((n_slots + SCAN_TILE - 1) / SCAN_TILE + 2);
@@ -1628,7 +1648,7 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
     FbIdx* big_idx = tmp.get<FbIdx>(n_funcs + 1);
     HIP_TRY(hipMemsetAsync(ctx->d_status + WL_FBTOT, 0, 2 * sizeof(uint32_t), st));
     if (n_funcs) {
-        LAUNCH(ctx, "fb_mark_size", k_fb_mark_size, grid_for(n_defs, 256), 256, u->d_def_nodes, n_defs, n_nodes, def_excl, u->d_nodes, (uint32_t)2048, big_flag, big_idx);
+        LAUNCH(ctx, "fb_mark_size", k_fb_mark_size, grid_for(n_defs, 256), 256, u->d_def_nodes, n_defs, n_nodes, def_excl, u->d_nodes, (uint32_t)2048, big_flag, big_idx, (const uint8_t*)nullptr);
         prof_begin(ctx, "fb_scan");
         device_scan<true>(big_idx, big_idx, n_funcs, OpAddFbIdx(), FbIdx{0, 0}, (FbIdx*)scan_tmp, (FbIdx*)(ctx->d_status + WL_FBTOT), st);
         prof_end(ctx);
@@ -1646,6 +1666,16 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
     constexpr bool seq_only = false;
 #endif
     const uint32_t big_nodes = seq_only ? 0u : ctx->h_status[WL_FBTOT], big_funcs = seq_only ? 0u : ctx->h_status[WL_FBTOT + 1];
+    if (grp) {
+        // finalize-time errors concern their FILE (it takes the single-file path, which answers OPUSFE_SEMANTIC for it); the rest goes on.
+        // Functions of files whose packed result is discarded anyway are not lowered.
+        if (ctx->h_status[WL_FINERR] != 0) {
+            uint32_t* fin_cnt = tmp.get<uint32_t>(n_defs);
+            LAUNCH(ctx, "sem_fin_count", k_sem_fin_count, grid_for(n_defs, 256), 256, u->d_nodes, u->d_def_nodes, n_defs, R->d_tid_of_node, undefined_flag, ph_def, ph_prev, n_nodes, gtypes, fin_cnt);
+            LAUNCH(ctx, "group_finerr", k_group_finerr, grid_for(n_defs, 256), 256, (const uint32_t*)fin_cnt, (const uint32_t*)def_file, n_defs, grp->d_flags);
+        }
+        LAUNCH(ctx, "group_def_mask", k_group_def_mask, grid_for(n_defs, 256), 256, (const uint32_t*)def_file, (const uint32_t*)grp->d_flags, n_defs, (uint32_t)(FF_SINGLE | FF_SYNTAX), def_skip);
+    } else
     if (ctx->h_status[WL_FINERR] != 0) {   // frontend.rs:145: semantic errors while finalizing -> no IR
         R->n_sem_errors = ctx->h_status[WL_FINERR];
         // the diagnostics themselves, in the reference's report order (definitions in file order)
@@ -1674,10 +1704,11 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
     // machine, into sparse regions sized for them alone, and are compacted into the same arrays.  The arrays are sized from
     // the node count (ratios of the previous unit on this context, with head-room); if one is too small the pass raises
     // `overflow`, still counts exactly, and everything runs once more with the exact sizes.
-    SemView S{u->d_src, u->d_tokens, u->d_val64, u->d_nodes, R->d_tid_of_node, gtypes, slots, n_slots - 1, entries, R->d_funcrecs, R->d_globals, n_gtypes};
+    SemView S{u->d_src, u->d_tokens, u->d_val64, u->d_nodes, R->d_tid_of_node, gtypes, slots, n_slots - 1, entries, R->d_funcrecs, R->d_globals, n_gtypes, grp ? (const uint32_t*)grp->d_start : (const uint32_t*)nullptr, grp ? grp->n_files : 0u};
     R->d_funcs = dev_alloc_t<FuncIr>(ctx, n_funcs);
     uint64_t* user_syms = tmp.get<uint64_t>(1);
     LAUNCH(ctx, "sem_user_syms", k_sem_user_syms, 1, 64, S, user_syms);
+    if (grp) LAUNCH(ctx, "group_user_syms", k_group_user_syms, grid_for(n_defs, 256), 256, u->d_nodes, u->d_tokens, u->d_def_nodes, n_defs, (unsigned long long*)user_syms);
     // order[] holds the definitions by size class, largest class first; class c ends at class_end[c] and starts where class c + 1 ends
     unsigned long long* counters = tmp.get<unsigned long long>(par::CTR_COUNT + 2);     // + overflow flag, + error counter
     uint32_t* fb_flag = tmp.get<uint32_t>(n_funcs);
@@ -1699,10 +1730,10 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
         HIP_TRY(hipMemsetAsync(ctx->d_status + WL_STATUS, 0, 2 * sizeof(uint32_t), st));
         HIP_TRY(hipMemsetAsync(ctx->d_status + WL_BODIES, 0, sizeof(uint32_t), st));
         HIP_TRY(hipMemcpyAsync(R->d_types, gtypes, (size_t)n_gtypes * sizeof(TypeRec), hipMemcpyDeviceToDevice, st));
-        LAUNCH(ctx, "par_init", par::k_par_init, grid_for(n_defs, 256), 256, u->d_nodes, u->d_def_nodes, n_defs, def_excl, R->d_funcs, ctx->d_status + WL_BODIES);
+        LAUNCH(ctx, "par_init", par::k_par_init, grid_for(n_defs, 256), 256, u->d_nodes, u->d_def_nodes, n_defs, def_excl, R->d_funcs, ctx->d_status + WL_BODIES, (const uint8_t*)def_skip);
         par::ParArgs PA{};
         PA.def_nodes = u->d_def_nodes; PA.n_defs = n_defs; PA.n_nodes = n_nodes; PA.def_excl = def_excl; PA.undefined_flag = undefined_flag; PA.user_syms = user_syms;
-        PA.pp_base = pp_base; PA.out = R->d_funcs; PA.status = ctx->d_status + WL_STATUS;
+        PA.pp_base = pp_base; PA.out = R->d_funcs; PA.status = ctx->d_status + WL_STATUS; PA.skip = def_skip;
 #ifdef OPUSFE_DIAG
         { static const char* sp = getenv("OPUSFE_PAR_STOP"); PA.stop_phase = sp ? (uint32_t)atoi(sp) : 0u; }
         { static const char* sr = getenv("OPUSFE_PAR_ROUNDS"); PA.stop_rounds = sr ? (uint32_t)atoi(sr) : 0u; }

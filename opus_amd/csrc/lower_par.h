@@ -74,6 +74,7 @@ __host__ __device__ __forceinline__ Desc d_inner(Desc d) {      // nw > 0: the p
 struct ParArgs {
     const uint32_t* def_nodes; uint32_t n_defs, n_nodes; const DefCnt* def_excl; const uint8_t* undefined_flag; const uint64_t* user_syms;
     const uint32_t* list; uint32_t n_list; uint32_t nmax, maxdef; uint32_t pp_base;
+    const uint8_t* skip;      // group mode: definitions of files whose packed result is discarded (syntax error / single-file path): not lowered
     FuncIr* out; uint32_t* status;
     // The dense result arrays, filled in ONE pass: a function that knows its sizes takes its place in each array with an
     // atomic add on `counters` (bump allocation: the layout is dense, its order is the order in which functions finish).
@@ -146,7 +147,7 @@ __device__ __forceinline__ uint32_t lds_and(lds_u32* p, uint32_t v) { return __h
 #endif
 struct Fn {
     SemView S; ParArgs A;
-    uint32_t dn, nn, fidx, nargs; FuncRec F; uint64_t user_syms;
+    uint32_t dn, nn, fidx, nargs; FuncRec F; uint64_t user_syms; uint32_t sym_mix /* file mix of symbol keys (sem.h NameKey) */;
     // LDS
     lds_u64* rt; lds_u64* cnt; lds_u32* kn; lds_u32* st; lds_u32* ref; lds_u32* rvi; lds_u32* pay;
     lds_u16* fc; lds_u16* nx; lds_u16* pa; lds_u16* rk; lds_u16* sz; lds_u16* pe; lds_u16* cg; lds_u16* by_kind; lds_u8* tail;
@@ -654,10 +655,10 @@ __device__ __forceinline__ Desc for_variable_type(Fn& f, uint32_t i) {
     if (tnode != NONE16) return d_ptr(f, PT_Mutable, d_id(TID(f, tnode)));
     Desc at[2]; at[0] = f.rt[cond];
     if (at[0] == DESC_NONE || view(f, at[0]).kind == TY_Error) { fallback(f); return DESC_NONE; }
-    const uint32_t ff = lookup_function(f, key_sym(T_For), at, 1);
+    const uint32_t ff = lookup_function(f, key_sym(T_For, f.sym_mix), at, 1);
     if (failed(f) || ff == FN_NONE || fn_builtin(ff)) { fallback(f); return DESC_NONE; }
     at[0] = d_ptr(f, PT_Mutable, d_id(fn_ret(f, ff))); at[1] = d_id(TP_Generic);
-    const uint32_t cf = lookup_function(f, key_sym(T_Continue), at, 2);
+    const uint32_t cf = lookup_function(f, key_sym(T_Continue, f.sym_mix), at, 2);
     if (failed(f) || cf == FN_NONE || fn_builtin(cf)) { fallback(f); return DESC_NONE; }
     return d_id(fn_arg_type(f, cf, 1));
 }
@@ -760,7 +761,7 @@ template <bool EMIT> __device__ __forceinline__ bool visit(Fn& f, uint32_t i) {
                     const uint32_t tnode = SUB(f, i) ? f.fc[i] : NONE16;
                     Desc at[2]; at[0] = cv.t;
                     if (view(f, cv.t).kind == TY_Error) { fallback(f); return true; }
-                    const uint32_t ff = lookup_function(f, key_sym(T_For), at, 1);
+                    const uint32_t ff = lookup_function(f, key_sym(T_For, f.sym_mix), at, 1);
                     if (failed(f) || ff == FN_NONE || fn_builtin(ff)) { fallback(f); return true; }
                     const uint32_t for_fn = e.newvar(f, d_func(ff), true);
                     e.ins(f, I_Function, for_fn, 0, 0, ff);
@@ -780,7 +781,7 @@ template <bool EMIT> __device__ __forceinline__ bool visit(Fn& f, uint32_t i) {
                     const uint32_t info = own_rv(e.pos, e.v);
                     // the variable is created with its FINAL type: `<unknown>` is retyped in place by the autocast below (Q13)
                     at[0] = iter_t; at[1] = pointer_type;
-                    const uint32_t cf = lookup_function(f, key_sym(T_Continue), at, 2);
+                    const uint32_t cf = lookup_function(f, key_sym(T_Continue, f.sym_mix), at, 2);
                     if (failed(f) || cf == FN_NONE || fn_builtin(cf)) { fallback(f); return true; }
                     if (tnode == NONE16) {
                         pointer_type = d_id(fn_arg_type(f, cf, 1));
@@ -947,7 +948,7 @@ template <bool EMIT> __device__ __forceinline__ bool visit(Fn& f, uint32_t i) {
                 Desc at[2]; uint32_t n;
                 if (is_not) { at[0] = f.rt[r]; n = 1; } else { at[0] = f.rt[l]; at[1] = f.rt[r]; n = 2; }
                 for (uint32_t k = 0; k < n; k++) if (at[k] == DESC_NONE || view(f, at[k]).kind == TY_Error) { fallback(f); return true; }
-                const uint32_t fn = lookup_function(f, key_sym(sym), at, n);
+                const uint32_t fn = lookup_function(f, key_sym(sym, f.sym_mix), at, n);
                 if (failed(f) || fn == FN_NONE) { fallback(f); return true; }
                 uint32_t fv = 0;
                 if (!fn_builtin(fn)) { fv = e.newvar(f, d_func(fn), true); e.ins(f, I_Function, fv, 0, 0, fn); }
@@ -1639,12 +1640,13 @@ __global__ MACHINE_ATTR(OPUSFE_PAR_WAVES) __launch_bounds__(1024) void k_lower_p
     const uint32_t d = A.list ? A.list[slot] : slot;
     const uint32_t dn = A.def_nodes[d];
     if (S.nodes[dn].kind != D_Function) return;
+    if (A.skip && A.skip[d]) return;
     const uint32_t fidx = A.def_excl[d].funcs;
     const uint32_t dn_end = d + 1 < A.n_defs ? A.def_nodes[d + 1] : A.n_nodes;
     const uint32_t nn = dn_end - dn;
     if (nn > A.nmax || nn < 2) return;                       // stays DS_FALLBACK (k_par_init)
     Fn f;
-    f.S = S; f.A = A; f.dn = dn; f.nn = nn; f.fidx = fidx; f.F = S.funcs[fidx]; f.nargs = f.F.nargs; f.user_syms = *A.user_syms;
+    f.S = S; f.A = A; f.dn = dn; f.nn = nn; f.fidx = fidx; f.F = S.funcs[fidx]; f.nargs = f.F.nargs; f.user_syms = *A.user_syms; f.sym_mix = S.mix_of_def(dn);
     f.tid = threadIdx.x; f.nthreads = blockDim.x;
     f.var_base = f.instr_base = f.bb_base = f.type_base = f.carg_base = 0;
     f.n_vars_tot = f.n_instrs_tot = f.n_bbs_tot = f.n_types_tot = f.n_cargs_tot = 0;
@@ -1683,15 +1685,16 @@ __global__ MACHINE_ATTR(OPUSFE_PAR_WAVES) __launch_bounds__(1024) void k_lower_p
 
 // every function starts as "declined": the count pass overwrites the ones it lowers
 __global__ void k_par_init(const opusfe_node* __restrict__ nodes, const uint32_t* __restrict__ def_nodes, uint32_t n_defs, const DefCnt* __restrict__ def_excl, FuncIr* __restrict__ out,
-                           uint32_t* __restrict__ n_bodies) {
+                           uint32_t* __restrict__ n_bodies, const uint8_t* __restrict__ skip) {
     const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= n_defs) return;
     const uint32_t dn = def_nodes[d];
     const uint8_t k = nodes[dn].kind;
     if (k != D_Function && k != D_Extern) return;
-    FuncIr r{}; r.def_node = dn; r.func = def_excl[d].funcs; r.status = k == D_Function ? (uint32_t)DS_FALLBACK : (uint32_t)DS_OK;
+    const bool body = k == D_Function && !(skip && skip[d]);      // (a skipped function is left like an extern: no blocks)
+    FuncIr r{}; r.def_node = dn; r.func = def_excl[d].funcs; r.status = body ? (uint32_t)DS_FALLBACK : (uint32_t)DS_OK;
     out[r.func] = r;
-    if (k == D_Function) atomicAdd(n_bodies, 1u);
+    if (body) atomicAdd(n_bodies, 1u);
 }
 
 }  // namespace par

@@ -727,6 +727,21 @@ __global__ MACHINE_ATTR(OPUSFE_PARSE_WAVES) __launch_bounds__(64) void k_parse_s
     if (P.unsup_pos != OPUSFE_NONE) atomicMin(status + 1, P.unsup_pos);
 }
 
+// Group mode (a corpus of files packed into one unit): a failing segment makes its FILE a syntax-error file — the lowest failing
+// segment of a file holds the file's first error — and contributes no nodes or definitions; the other files go on.
+__global__ void k_group_seg_errors(uint32_t* __restrict__ seg_info, uint32_t n_segs, const uint32_t* __restrict__ seg_start, const opusfe_token* __restrict__ tok, uint32_t n_tokens,
+                                   const uint32_t* __restrict__ file_start, uint32_t n_files, uint32_t* __restrict__ err_seg, uint32_t* __restrict__ flags) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_segs) return;
+    uint32_t* si = seg_info + (uint64_t)s * SI_WORDS;
+    if (si[SI_ERR_KIND] == OPUSFE_NONE) return;
+    const uint32_t t0 = seg_start[s];
+    if (t0 >= n_tokens) return;
+    const uint32_t f = pos_file(file_start, n_files, tok[t0].low);
+    atomicMin(&err_seg[f], s);
+    atomicOr(&flags[f], (si[SI_ERR_KIND] & 0x200u) ? (uint32_t)FF_INTERNAL : (uint32_t)FF_SYNTAX);
+    si[SI_NODE_COUNT] = 0; si[SI_DEF_COUNT] = 0;
+}
 // counts -> (node_count, def_count) pairs for the scan
 struct Cnt2 { uint32_t nodes, defs; };
 struct OpAddCnt2 { __host__ __device__ Cnt2 operator()(Cnt2 a, Cnt2 b) const { return Cnt2{a.nodes + b.nodes, a.defs + b.defs}; } };
@@ -884,10 +899,19 @@ inline void run_parser(opusfe_ctx* ctx, opusfe_unit* u) {
             for (int i = 0; i < 64; i++) if (h[64 + i]) fprintf(stderr, "  state %2d  %5.1f%%  %12llu steps  %8.0f cycles/step\n", i, 100.0 * h[i] / tot, h[64 + i], 16.0 * (double)h[i] / (double)h[64 + i]);
         }
 #endif
+        if (u->group)
+            LAUNCH(ctx, "group_seg_errors", k_group_seg_errors, grid_for(n_segs, 256), 256, u->d_seg_info, n_segs, (const uint32_t*)u->d_seg_start, (const opusfe_token*)u->d_tokens, n_tok,
+                   (const uint32_t*)u->group->d_start, u->group->n_files, u->group->d_err_seg, u->group->d_flags);
         count_and_scan();
     }
-    const uint32_t dev_status = ctx->h_status[0];
-    const uint32_t first_err = ctx->h_status[WP_FIRST_ERR];
+    uint32_t dev_status = ctx->h_status[0];
+    uint32_t first_err = ctx->h_status[WP_FIRST_ERR];
+    if (u->group) {
+        // syntax errors are per file (k_group_seg_errors); a dropped resync token concerns a file that is flagged for the single-file
+        // path anyway (lex.h FF_RESYNC); anything else the packed unit cannot attribute to a file fails the whole group
+        first_err = 0xFFFFFFFFu;
+        if (dev_status == DS_UNSUPPORTED_RESYNC) dev_status = DS_OK;
+    }
     if (first_err != 0xFFFFFFFFu || dev_status != DS_OK) u->n_nodes = u->n_defs = 0;   // no AST: the counts must not promise arrays that do not exist
     else { u->n_nodes = ctx->h_status[WP_TOTALS]; u->n_defs = ctx->h_status[WP_TOTALS + 1]; }
     if (first_err != 0xFFFFFFFFu) {

@@ -55,6 +55,9 @@ struct SemView {
     GTable<FuncRec> funcs;
     GTable<GlobalRec> globals;
     uint32_t n_gtypes;
+    const uint32_t* file_start; uint32_t n_files;      // group mode: where every file of the packed unit starts (else null, 0)
+    // the mix of the symbol keys a definition's code looks up (NameKey)
+    __device__ __forceinline__ uint32_t mix_of_def(uint32_t def_node) const { return n_files ? pos_file(file_start, n_files, nodes[def_node].low) * FILE_MIX : 0u; }
 };
 
 // ---- names ------------------------------------------------------------------------------------
@@ -79,12 +82,20 @@ __host__ __device__ __forceinline__ uint8_t sym_of_op(uint8_t op) {
     }
 }
 // A name is either an identifier token or the symbol of an operator-ish token kind.
-struct NameKey { uint32_t tok; uint8_t sym; };   // tok != NONE: identifier/operator token in the source; else symbol kind
+// Group mode (files packed into one unit): the payload of every name token carries file * FILE_MIX (lex.h k_lex_emit) — an identifier's
+// hash is shifted by it, a symbol token's payload IS it — and a symbol key carries the `mix` of the function that looks it up, so that
+// one name table scopes every name to its file.  Outside group mode every mix is 0.
+struct NameKey { uint32_t tok; uint8_t sym; uint32_t mix; };   // tok != NONE: identifier/operator token in the source; else symbol kind (+ file mix)
 // (TokP / SrcP: a raw pointer or a GTable)
 template <class TokP> __host__ __device__ __forceinline__ uint8_t name_sym(TokP tok, NameKey k) { return k.tok != OPUSFE_NONE ? (uint8_t)tok[k.tok].kind : k.sym; }
+__host__ __device__ __forceinline__ uint32_t sym_hash(uint8_t s);
+template <class TokP> __host__ __device__ __forceinline__ uint32_t name_mix(TokP tok, NameKey k) { return k.tok != OPUSFE_NONE ? (uint32_t)tok[k.tok].payload : k.mix; }   // symbol keys only
 template <class TokP> __host__ __device__ __forceinline__ uint32_t name_hash(TokP tok, NameKey k) {
     uint8_t s = name_sym(tok, k);
     if (s == T_Identifier) return tok[k.tok].payload;
+    return sym_hash(s) + name_mix(tok, k);
+}
+__host__ __device__ __forceinline__ uint32_t sym_hash(uint8_t s) {
     switch (s) {   // FNV-1a of the symbol text, folded at compile time
         case T_Plus: return fnv1a("+", 1); case T_Minus: return fnv1a("-", 1); case T_Asterisk: return fnv1a("*", 1); case T_Slash: return fnv1a("/", 1);
         case T_Percent: return fnv1a("%", 1); case T_EqualsEquals: return fnv1a("=", 1); case T_LessThan: return fnv1a("<", 1);
@@ -96,7 +107,7 @@ template <class TokP> __host__ __device__ __forceinline__ uint32_t name_hash(Tok
 template <class SrcP, class TokP> __host__ __device__ __forceinline__ bool name_eq(SrcP src, TokP tok, NameKey a, NameKey b) {
     uint8_t sa = name_sym(tok, a), sb = name_sym(tok, b);
     if (sa != sb) return false;
-    if (sa != T_Identifier) return true;
+    if (sa != T_Identifier) return name_mix(tok, a) == name_mix(tok, b);
     const opusfe_token x = tok[a.tok], y = tok[b.tok];
     if (x.len != y.len || x.payload != y.payload) return false;
     if (x.low == y.low) return true;
@@ -109,8 +120,8 @@ template <class SrcP, class TokP> __host__ __device__ __forceinline__ bool name_
     for (uint32_t i = 0; i < n; i++) if (src[x.low + i] != (uint8_t)lit[i]) return false;
     return true;
 }
-__host__ __device__ __forceinline__ NameKey key_tok(uint32_t t) { return NameKey{t, 0}; }
-__host__ __device__ __forceinline__ NameKey key_sym(uint8_t s) { return NameKey{OPUSFE_NONE, s}; }
+__host__ __device__ __forceinline__ NameKey key_tok(uint32_t t) { return NameKey{t, 0, 0}; }
+__host__ __device__ __forceinline__ NameKey key_sym(uint8_t s, uint32_t mix) { return NameKey{OPUSFE_NONE, s, mix}; }
 
 // slot of a name, or NONE
 __device__ __forceinline__ uint32_t name_find(const SemView& S, NameKey k) {
@@ -434,6 +445,37 @@ __global__ void k_sem_table_sort(NameSlot* __restrict__ slots, uint32_t n_slots,
     };
     for (uint32_t i = n / 2; i > 0; i--) sift(i - 1, n);
     for (uint32_t end = n; end > 1; end--) { NameEntry t = e[0]; e[0] = e[end - 1]; e[end - 1] = t; sift(0, end - 1); }
+}
+
+// ---- group mode (a corpus of files packed into one unit): every name is scoped to its file by the mix in its key (NameKey) ----
+// Which operator symbols have user-defined overloads is asked per unit (k_sem_user_syms: a gate in front of the builtin shortcut, where
+// "yes" only means "take the general path"): in a group, a symbol that ANY file defines answers yes.
+__global__ void k_group_user_syms(const opusfe_node* __restrict__ nodes, const opusfe_token* __restrict__ tok, const uint32_t* __restrict__ def_nodes, uint32_t n_defs,
+                                  unsigned long long* __restrict__ user_syms) {
+    const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= n_defs) return;
+    const opusfe_node n = nodes[def_nodes[d]];
+    if (n.kind != D_Function && n.kind != D_Extern) return;
+    const uint8_t k = tok[n.payload].kind;
+    if (k != T_Identifier) atomicOr(user_syms, 1ull << (k & 63));
+}
+// first definition of every file (definitions are in file order); files without definitions keep NONE
+__global__ void k_group_first_defs(const opusfe_node* __restrict__ nodes, const uint32_t* __restrict__ def_nodes, uint32_t n_defs, const uint32_t* __restrict__ file_start,
+                                   uint32_t n_files, uint32_t* __restrict__ first_def, uint32_t* __restrict__ def_file) {
+    const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= n_defs) return;
+    const uint32_t f = pos_file(file_start, n_files, nodes[def_nodes[d]].low);
+    def_file[d] = f;
+    if (d == 0 || pos_file(file_start, n_files, nodes[def_nodes[d - 1]].low) != f) first_def[f] = d;
+}
+
+__global__ void k_group_def_mask(const uint32_t* __restrict__ def_file, const uint32_t* __restrict__ flags, uint32_t n_defs, uint32_t mask, uint8_t* __restrict__ out) {
+    const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d < n_defs) out[d] = (flags[def_file[d]] & mask) ? 1 : 0;
+}
+__global__ void k_group_finerr(const uint32_t* __restrict__ fin_cnt, const uint32_t* __restrict__ def_file, uint32_t n_defs, uint32_t* __restrict__ flags) {
+    const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d < n_defs && fin_cnt[d]) atomicOr(&flags[def_file[d]], (uint32_t)FF_FINERR);
 }
 
 __global__ void k_sem_slots_init(NameSlot* __restrict__ slots, uint32_t n_slots) {

@@ -2,8 +2,22 @@
 #pragma once
 #include "runtime.h"
 
+// A corpus of independent files packed into one unit (opusfe_parse_group, BASELINE config 5): file f is the bytes
+// [start[f], start[f] + len[f]) of the unit's source (starts are multiples of 64, '\n' in between).  Device tables, owned by the group.
+struct GroupInfo {
+    uint32_t n_files = 0;
+    uint32_t* d_start = nullptr; uint32_t* d_len = nullptr;
+    uint32_t* d_flags = nullptr;        // lex.h FF_*: why a file needs the single-file path / has a syntax error
+    uint32_t* d_fstatus = nullptr;      // [2 n_files] the lexer's unsupported-input record per file {code, first position}
+    uint32_t* d_tok_begin = nullptr;    // first token of the file in the final token stream
+    uint32_t* d_err_seg = nullptr;      // lowest failing segment of the file, NONE = none
+    uint32_t* d_first_def = nullptr;    // first definition / function / global of the file (filled by the parser / the lowering)
+    uint32_t* d_first_func = nullptr; uint32_t* d_first_global = nullptr;
+};
+
 struct opusfe_unit {
     opusfe_ctx* ctx = nullptr;
+    GroupInfo* group = nullptr;                                // set while the unit is the packed source of a group
     int status = OPUSFE_OK;
     uint32_t dev_status = 0;
     // source

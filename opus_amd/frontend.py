@@ -61,6 +61,16 @@ def lib():
         for name in ("opusfe_lex", "opusfe_lex_device"):
             getattr(L, name).argtypes = [vp, vp, u64, i, C.POINTER(vp)]
         L.opusfe_parse_batch.argtypes = [vp, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(u64), i, C.POINTER(vp), C.POINTER(i)]
+        L.opusfe_parse_group.argtypes = [vp, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(u64), i, C.POINTER(vp)]
+        L.opusfe_parse_group_device.argtypes = [vp, vp, u64, C.c_uint32, C.POINTER(u64), C.POINTER(u64), i, C.POINTER(vp)]
+        L.opusfe_group_file_status.argtypes = [vp, C.c_uint32]
+        L.opusfe_group_file_error.argtypes = [vp, C.c_uint32, C.POINTER(Error)]
+        L.opusfe_group_unit.argtypes = [vp]; L.opusfe_group_unit.restype = vp
+        L.opusfe_group_file_unit.argtypes = [vp, C.c_uint32]; L.opusfe_group_file_unit.restype = vp
+        L.opusfe_group_file_ranges.argtypes = [vp, C.c_uint32, C.POINTER(u64)]
+        L.opusfe_group_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
+        L.opusfe_group_dump.argtypes = [vp, C.c_uint32, i, C.POINTER(vp), C.POINTER(u64)]
+        L.opusfe_free_group.argtypes = [vp]
         L.opusfe_semantic_error_count.argtypes = [vp, C.POINTER(u64)]
         u32 = C.c_uint32
         L.opusfe_shard_ctx.argtypes = [vp, vp, u64, C.POINTER(u32)]
@@ -231,6 +241,104 @@ class Unit:
         return arr
 
 
+class _BorrowedUnit(Unit):
+    """a unit owned by a Group (the packed unit, or the unit of a file that took the single-file path): never freed from here"""
+
+    def close(self):
+        self.handle = None
+
+
+class Group:
+    """Result of Context.compile_group: a corpus of independent files answered by one packed pass (opusfe_parse_group)."""
+
+    def __init__(self, ctx, handle, n_files):
+        self.ctx, self.handle, self.n_files = ctx, handle, n_files
+
+    def close(self):
+        if self.handle:
+            if self.ctx.handle:
+                lib().opusfe_free_group(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return self.n_files
+
+    def status(self, f):
+        return lib().opusfe_group_file_status(self.handle, f)
+
+    def statuses(self):
+        return [self.status(f) for f in range(self.n_files)]
+
+    def error(self, f):
+        e = Error()
+        if lib().opusfe_group_file_error(self.handle, f, C.byref(e)) != OK:
+            return None
+        return e
+
+    def stats(self):
+        """(files answered by the packed pass, files that took the single-file path, files with a syntax error)"""
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        lib().opusfe_group_stats(self.handle, C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, c.value
+
+    def ranges(self, f):
+        r = (C.c_uint64 * 10)()
+        if lib().opusfe_group_file_ranges(self.handle, f, r) != OK:
+            raise OpusfeError(ERR_ARG, "opusfe_group_file_ranges")
+        return [int(x) for x in r]
+
+    def unit(self):
+        return _BorrowedUnit(self.ctx, C.c_void_p(lib().opusfe_group_unit(self.handle)), OK)
+
+    def file_unit(self, f):
+        h = lib().opusfe_group_file_unit(self.handle, f)
+        return _BorrowedUnit(self.ctx, C.c_void_p(h), self.status(f)) if h else None
+
+    def _dump(self, f, what):
+        out, n = C.c_void_p(), C.c_uint64()
+        rc = lib().opusfe_group_dump(self.handle, f, what, C.byref(out), C.byref(n))
+        if rc != OK:
+            raise OpusfeError(rc, self.ctx.message())
+        try:
+            return C.string_at(out, n.value).decode("utf-8", errors="surrogateescape")
+        finally:
+            lib().opusfe_free_text(out)
+
+    def dump_tokens(self, f):
+        return self._dump(f, 0)
+
+    def dump_ast(self, f):
+        return self._dump(f, 1)
+
+    def dump_ir(self, f):
+        return self._dump(f, 2)
+
+    def dump_error(self, f):
+        return self._dump(f, 3)
+
+    def dump_semantic_errors(self, f):
+        return self._dump(f, 4)
+
+
+def pack_group(sources):
+    """host-side packing for opusfe_parse_group_device: (packed bytes, starts, lens) — file f at a 64-byte aligned start,
+    '\n' in between (at least one)"""
+    starts, total = [], 0
+    for s in sources:
+        starts.append(total)
+        total = (total + len(s) + 1 + 63) // 64 * 64
+    buf = bytearray(b"\n" * (total + 64))
+    for st, s in zip(starts, sources):
+        buf[st:st + len(s)] = s
+    return bytes(buf), starts, [len(s) for s in sources], total
+
+
 class Context:
     def __init__(self, device=0):
         h = C.c_void_p()
@@ -294,6 +402,28 @@ class Context:
         if rc != OK:
             raise OpusfeError(rc, self.message())
         return out
+
+    def compile_group(self, sources, lower=True):
+        """Corpus of independent files as ONE packed pass (opusfe_parse_group): a Group with a status per file."""
+        n = len(sources)
+        srcs = (C.c_char_p * n)(*sources)
+        lens = (C.c_uint64 * n)(*[len(s) for s in sources])
+        out = C.c_void_p()
+        rc = lib().opusfe_parse_group(self.handle, n, srcs, lens, int(lower), C.byref(out))
+        if rc != OK:
+            raise OpusfeError(rc, self.message())
+        return Group(self, out, n)
+
+    def compile_group_device(self, d_ptr, packed_len, starts, lens, lower=True):
+        """opusfe_parse_group_device: the packed buffer (pack_group's layout) is already in HBM"""
+        n = len(starts)
+        st = (C.c_uint64 * n)(*starts)
+        ln = (C.c_uint64 * n)(*lens)
+        out = C.c_void_p()
+        rc = lib().opusfe_parse_group_device(self.handle, C.c_void_p(d_ptr), packed_len, n, st, ln, int(lower), C.byref(out))
+        if rc != OK:
+            raise OpusfeError(rc, self.message())
+        return Group(self, out, n)
 
     def lex(self, source: bytes, force_dents=False):
         out = C.c_void_p()

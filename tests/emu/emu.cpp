@@ -93,16 +93,16 @@ void emu_lex(EmuUnit& E, int force_dents) {
     std::vector<int32_t> depth(G);
     std::vector<uint32_t> gapval(G), prev(G), cnt(G), out_off(G), seg_flag(G), seg_excl(G);
     if (T) {
-        emu_launch(k_tok_delta, grid_for(T, 256), 256, raw.data(), T, depth.data(), force_dents, (uint64_t)TK_NO_PREV);
+        emu_launch(k_tok_delta, grid_for(T, 256), 256, raw.data(), T, depth.data(), force_dents, (uint64_t)TK_NO_PREV, FileTok{});
         for (uint32_t k = 1; k < T; k++) depth[k] += depth[k - 1];
     }
-    emu_launch(k_gap, grid_for(G, 256), 256, src, n, raw.data(), T, depth.data(), gapval.data(), (int32_t)0);
+    emu_launch(k_gap, grid_for(G, 256), 256, src, n, raw.data(), T, depth.data(), gapval.data(), (int32_t)0, FileTok{});
     { uint32_t run = 0; for (uint64_t k = 0; k < G; k++) { prev[k] = run; run = OpLast()(run, gapval[k]); } }
-    emu_launch(k_dent_count, grid_for(G, 256), 256, gapval.data(), prev.data(), T, cnt.data());
+    emu_launch(k_dent_count, grid_for(G, 256), 256, gapval.data(), prev.data(), T, cnt.data(), FileTok{}, (const int32_t*)depth.data());
     uint32_t total = 0;
     for (uint64_t k = 0; k < G; k++) { out_off[k] = total; total += cnt[k]; }
     E.u.h_tokens.assign(total, opusfe_token{});
-    emu_launch(k_final, grid_for(G, 256), 256, raw.data(), T, n, gapval.data(), prev.data(), out_off.data(), E.u.h_tokens.data(), seg_flag.data());
+    emu_launch(k_final, grid_for(G, 256), 256, raw.data(), T, n, gapval.data(), prev.data(), out_off.data(), E.u.h_tokens.data(), seg_flag.data(), FileTok{}, (const int32_t*)depth.data(), (uint32_t*)nullptr);
     uint32_t nseg = 0;
     for (uint32_t k = 0; k < T; k++) { seg_excl[k] = nseg; nseg += seg_flag[k]; }
     E.seg_start.assign((size_t)T + 1, 0);
@@ -268,7 +268,7 @@ void emu_lower(EmuUnit& E) {
         uint32_t* dbo = exact<uint32_t>(cap[2] + 1); uint32_t* dc = exact<uint32_t>(cap[4]);
         TypeRec* dty = exact<TypeRec>(n_gtypes + cap[3]); SemErr* de = nullptr;
         memcpy(dty, gtypes, (size_t)n_gtypes * sizeof(TypeRec));
-        emu_launch(par::k_par_init, grid_for(n_defs, 256), 256, nodes, def_nodes, n_defs, (const DefCnt*)def_excl.data(), R->funcs.data(), &n_bodies);
+        emu_launch(par::k_par_init, grid_for(n_defs, 256), 256, nodes, def_nodes, n_defs, (const DefCnt*)def_excl.data(), R->funcs.data(), &n_bodies, (const uint8_t*)nullptr);
         par::ParArgs PA{};
         PA.def_nodes = def_nodes; PA.n_defs = n_defs; PA.n_nodes = n_nodes; PA.def_excl = def_excl.data(); PA.undefined_flag = undefined_flag.data(); PA.user_syms = &user_syms;
         PA.pp_base = pp_base; PA.out = R->funcs.data(); PA.status = lstatus;
