@@ -367,7 +367,7 @@ def main():
         # exchange steps per pass: all-gathers and point-to-point messages of rank 0 (ONE carry all-gather when every shard
         # starts in code context at depth 0 — `single_all_gather_passes` counts the passes where that held)
         # the exchanges alone (no waiting for a slower rank): every pattern of one pass repeated behind a barrier, with the sizes of the last pass
-        hb = max(1, shard_times["header_bytes"] // max(1, world - 1))
+        hb = int(_sh7.all_reduce_max(float(max(1, shard_times["header_bytes"] // max(1, world - 1))), dist))      # one size for every rank
         probe_t = torch.zeros(hb, dtype=torch.uint8, device="cuda")
         halo = torch.zeros(4096, dtype=torch.uint8, device="cuda")
         reps, acc = 5, 0.0

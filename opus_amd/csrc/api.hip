@@ -461,6 +461,7 @@ void opusfe_destroy(opusfe_ctx* ctx) {
     (void)hipFree(ctx->d_status);
     (void)hipFree(ctx->d_pp_table);
     (void)hipHostFree(ctx->h_status);
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     (void)hipStreamDestroy(ctx->stream);
     if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
@@ -1063,6 +1064,8 @@ int group_run(opusfe_ctx* ctx, opusfe_group* g, const uint8_t* d_packed, uint64_
     GroupInfo& I = g->info;
     const uint32_t F = I.n_files;
     hipStream_t st = ctx->stream;
+    g->unit = new_unit(ctx, d_packed, packed_len, own_src);      // first: from here on the group owns the packed buffer
+    g->unit->group = &I;
     I.d_start = dev_alloc_t<uint32_t>(ctx, F); I.d_len = dev_alloc_t<uint32_t>(ctx, F); I.d_flags = dev_alloc_t<uint32_t>(ctx, F);
     I.d_fstatus = dev_alloc_t<uint32_t>(ctx, 2ull * F); I.d_tok_begin = dev_alloc_t<uint32_t>(ctx, F); I.d_err_seg = dev_alloc_t<uint32_t>(ctx, F);
     I.d_first_def = dev_alloc_t<uint32_t>(ctx, F); I.d_first_func = dev_alloc_t<uint32_t>(ctx, F); I.d_first_global = dev_alloc_t<uint32_t>(ctx, F);
@@ -1072,8 +1075,6 @@ int group_run(opusfe_ctx* ctx, opusfe_group* g, const uint8_t* d_packed, uint64_
     for (uint32_t* p : {I.d_tok_begin, I.d_err_seg, I.d_first_def, I.d_first_func, I.d_first_global}) HIP_TRY(hipMemsetAsync(p, 0xFF, (size_t)F * 4, st));
     hipLaunchKernelGGL(k_group_init, dim3(grid_for(F, 256)), dim3(256), 0, st, I.d_fstatus, F);
     HIP_TRY(hipGetLastError());
-    g->unit = new_unit(ctx, d_packed, packed_len, own_src);
-    g->unit->group = &I;
     g->status.assign(F, OPUSFE_ERR_INTERNAL); g->error.assign(F, opusfe_error{}); g->single.assign(F, nullptr);
     const bool packed_ok = group_packed_pass(ctx, g, lower);
     if (!packed_ok) { g->flags.assign(F, FF_INTERNAL); g->lowered = false; }
@@ -1147,18 +1148,40 @@ int opusfe_parse_group(opusfe_ctx* ctx, uint32_t n_files, const uint8_t* const* 
     for (uint32_t f = 0; f < n_files; f++) { g->start[f] = (uint32_t)starts[f]; g->len[f] = (uint32_t)lens[f]; }
     *out = g;
     int rc = guarded(ctx, [&] {
-        // pack on the host (one pinned staging buffer), one copy to the device
-        uint8_t* h = nullptr;
-        HIP_TRY(hipHostMalloc((void**)&h, total + 64, hipHostMallocDefault));
-        memset(h, '\n', total + 64);
-        for (uint32_t f = 0; f < n_files; f++) if (lens[f]) memcpy(h + starts[f], srcs[f], lens[f]);
-        uint8_t* d = nullptr;
+        // pack on the host into the context's pinned staging buffer (a few threads: the copy is memory-bound), one copy to the device
+        if (ctx->h_stage_bytes < total + 64) {
+            if (ctx->h_stage) { (void)hipHostFree(ctx->h_stage); ctx->h_stage = nullptr; ctx->h_stage_bytes = 0; }
+            const size_t want = (size_t)((total + 64) * 5 / 4 + (1 << 20));
+            HIP_TRY(hipHostMalloc((void**)&ctx->h_stage, want, hipHostMallocDefault));
+            ctx->h_stage_bytes = want;
+        }
+        uint8_t* h = ctx->h_stage;
+        auto pack = [&](uint32_t f0, uint32_t f1) {
+            for (uint32_t f = f0; f < f1; f++) {
+                if (lens[f]) memcpy(h + starts[f], srcs[f], lens[f]);
+                const uint64_t end = starts[f] + lens[f], next = f + 1 < n_files ? starts[f + 1] : total + 64;
+                memset(h + end, '\n', next - end);
+            }
+        };
+        const uint32_t n_thr = total > (8u << 20) ? 8u : 1u;
+        if (n_thr == 1) pack(0, n_files);
+        else {
+            std::vector<std::thread> thr;
+            uint32_t f0 = 0;
+            for (uint32_t t = 0; t < n_thr; t++) {      // equal byte shares
+                uint32_t f1 = f0;
+                const uint64_t upto = total / n_thr * (t + 1);
+                while (f1 < n_files && (t + 1 == n_thr || starts[f1] < upto)) f1++;
+                thr.emplace_back(pack, f0, f1);
+                f0 = f1;
+            }
+            for (auto& t : thr) t.join();
+        }
+        uint8_t* d = dev_alloc_t<uint8_t>(ctx, total + 64);
         try {
-            d = dev_alloc_t<uint8_t>(ctx, total + 64);
             HIP_TRY(hipMemcpyAsync(d, h, total + 64, hipMemcpyHostToDevice, ctx->stream));
-            HIP_TRY(hipStreamSynchronize(ctx->stream));
-        } catch (...) { (void)hipHostFree(h); if (d) dev_free(ctx, d); throw; }
-        (void)hipHostFree(h);
+            HIP_TRY(hipStreamSynchronize(ctx->stream));      // the staging buffer is reused by the next call
+        } catch (...) { dev_free(ctx, d); throw; }
         return group_run(ctx, g, d, total, true, srcs, lower);
     });
     if (rc != OPUSFE_OK && rc != OPUSFE_SYNTAX) { (void)hipStreamSynchronize(ctx->stream); group_release(g); *out = nullptr; }
@@ -1213,6 +1236,7 @@ int opusfe_group_dump(opusfe_group* g, uint32_t file, int what, char** out, uint
     if (!g || !out || file >= g->info.n_files) return OPUSFE_ERR_ARG;
     *out = nullptr;
     if (g->single[file]) return opusfe_dump(g->single[file], what, out, out_len);
+    if (g->tok_begin.size() <= (size_t)file + 1) return fail(g->ctx, OPUSFE_ERR_ARG, "the file has no result (its single-file run failed)");
     opusfe_unit* u = g->unit;
     return guarded(g->ctx, [&] {
         std::string s;

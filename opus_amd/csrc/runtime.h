@@ -43,6 +43,8 @@ struct opusfe_ctx {
     // opusfe_parse_batch: worker contexts (own stream and allocator each) owned by this context; units they created
     // are released before the context is destroyed
     std::vector<opusfe_ctx*> workers;
+    // opusfe_parse_group: pinned staging buffer the files are packed into (grow-only, kept: pinning memory costs more than the copy)
+    uint8_t* h_stage = nullptr; size_t h_stage_bytes = 0;
 };
 
 namespace opusfe {
