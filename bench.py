@@ -347,6 +347,7 @@ def main():
     if par and not os.environ.get("OPUSFE_BENCH_RAW_KERNELS"):      # (diagnostics: keep the class launches apart)
         kstats = [k for k in kstats if not k[0].startswith("lower_par_")] + [("lower_par", sum(k[1] for k in par), sum(k[2] for k in par))]
     held = ctx.memory_held()
+    mem = ctx.memory_stats()      # live results / cached blocks / temporaries arena / high-water mark
     total_bytes_all = nbytes
     if dist is not None and workload == "c5":
         from opus_amd import sharding as _sh6
@@ -510,7 +511,7 @@ def main():
                           "files": counts.get("files"), "files_with_syntax_error": counts.get("files_with_syntax_error")},
                "hbm_gbs_whole_path": round(world * total_alg / (dt / args.steps) / 1e9, 2),
                "hbm_frac_whole_path": round(total_alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 5),
-               "hbm_held_bytes": held, "lowering_functions": lowering or None, "sharded_totals": sharded_totals,
+               "hbm_held_bytes": held, "hbm_peak_bytes": mem["peak"], "hbm_bytes_by_kind": {k: mem[k] for k in ("live", "cached", "arena")}, "lowering_functions": lowering or None, "sharded_totals": sharded_totals,
                "roofline": roofline, "cpu_baseline": cpu, "parity_check": parity if cpu is not None else None, "extra": extra,
                "kernels": [{"name": n, "ms_per_step": round(ms / args.steps, 4), "launches_per_step": l / args.steps} for n, ms, l in kstats[:24]],
                "gen_seconds": round(gen_s, 1)}

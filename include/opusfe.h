@@ -220,6 +220,10 @@ int opusfe_set_parser_mode(opusfe_ctx* ctx, int mode);
 /* device memory this context holds (result buffers of live units + the caching allocator's free blocks): the high-water mark
    of the HBM footprint of the calls made so far */
 int opusfe_memory_held(opusfe_ctx* ctx, uint64_t* bytes);
+/* what the held bytes are: stats[0] live results (units not yet freed), [1] cached blocks (freed results kept for the next unit of
+   the same size), [2] the temporaries' arena (one per context: the largest stage's need, not the sum), [3] the high-water mark of
+   [0] + [1] + [2] + transient overflow allocations since opusfe_create */
+int opusfe_memory_stats(opusfe_ctx* ctx, uint64_t stats[4]);
 
 /* ---- results ---- */
 /* number of resync passes opusfe_parse took for this unit (0 for well-formed input).  A byte-range shard of a

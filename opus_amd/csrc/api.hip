@@ -111,7 +111,7 @@ void run_lexer(opusfe_ctx* ctx, opusfe_unit* u, int force_dents) {
     uint32_t* cnt = tmp.get<uint32_t>(G);
     uint32_t* out_off = tmp.get<uint32_t>(G);
     uint32_t* seg_flag = tmp.get<uint32_t>(G);
-    uint32_t* seg_excl = tmp.get<uint32_t>(G);
+    uint32_t* seg_excl = prev;      // (prev is dead behind k_final, which writes seg_flag; the segment scan then writes seg_excl)
     uint32_t* scan_tmp32 = tmp.get<uint32_t>((G + SCAN_TILE - 1) / SCAN_TILE + 1);
     FileTok ft{};
     if (grp && T > 0) {
@@ -150,11 +150,13 @@ void run_lexer(opusfe_ctx* ctx, opusfe_unit* u, int force_dents) {
         prof_begin(ctx, "scan_seg");
         device_scan<true>(seg_flag, seg_excl, T, OpAddU32(), (uint32_t)0, scan_tmp32, ctx->d_status + W_NSEG, st);
         prof_end(ctx);
-        u->d_seg_start = dev_alloc_t<uint32_t>(ctx, (uint64_t)T + 1);
-        LAUNCH(ctx, "tok_seg_starts", k_seg_starts, grid_for(T, 256), 256, seg_flag, seg_excl, out_off, cnt, T, u->d_seg_start);
     }
     fetch_status(ctx);
     u->n_segs = T > 0 ? ctx->h_status[W_NSEG] : 0;
+    if (T > 0) {      // (sized from the count: one entry per segment, not per token)
+        u->d_seg_start = dev_alloc_t<uint32_t>(ctx, (uint64_t)u->n_segs + 1);
+        LAUNCH(ctx, "tok_seg_starts", k_seg_starts, grid_for(T, 256), 256, seg_flag, seg_excl, out_off, cnt, T, u->d_seg_start);
+    }
     u->end_ctx_state = ntiles > 0 ? ctx_apply(ctx->h_status[W_ENDFN], CS_N) : (uint32_t)CS_N;
     u->end_depth = T > 0 ? (int32_t)ctx->h_status[W_ENDDEPTH] : 0;
     u->dev_status = ctx->h_status[W_STATUS];
@@ -190,6 +192,7 @@ int guarded(opusfe_ctx* ctx, F&& f) {
     if (!ctx) return OPUSFE_ERR_ARG;
     try {
         HIP_TRY(hipSetDevice(ctx->device));
+        ctx->epoch++;
         return f();
     } catch (HipError& e) {
         ctx->pending.clear();
@@ -462,6 +465,7 @@ void opusfe_destroy(opusfe_ctx* ctx) {
     (void)hipFree(ctx->d_pp_table);
     (void)hipHostFree(ctx->h_status);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+    if (ctx->arena) (void)hipFree(ctx->arena);
     (void)hipStreamDestroy(ctx->stream);
     if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
@@ -777,6 +781,16 @@ int opusfe_set_parser_mode(opusfe_ctx* ctx, int mode) {
 int opusfe_memory_held(opusfe_ctx* ctx, uint64_t* bytes) {
     if (!ctx || !bytes) return OPUSFE_ERR_ARG;
     *bytes = ctx->bytes_allocated;
+    return OPUSFE_OK;
+}
+
+int opusfe_memory_stats(opusfe_ctx* ctx, uint64_t* stats) {
+    if (!ctx || !stats) return OPUSFE_ERR_ARG;
+    uint64_t live = 0, cached = 0;
+    for (auto& kv : ctx->live_blocks) live += kv.second;
+    for (auto& kv : ctx->free_blocks) cached += kv.first;
+    stats[0] = live; stats[1] = cached; stats[2] = ctx->arena_size;
+    stats[3] = ctx->bytes_peak > ctx->bytes_allocated ? ctx->bytes_peak : ctx->bytes_allocated;
     return OPUSFE_OK;
 }
 

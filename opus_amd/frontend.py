@@ -90,6 +90,7 @@ def lib():
         L.opusfe_parsing_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
         L.opusfe_set_parser_mode.argtypes = [vp, i]
         L.opusfe_memory_held.argtypes = [vp, C.POINTER(u64)]
+        L.opusfe_memory_stats.argtypes = [vp, C.POINTER(u64)]
         L.opusfe_unit_resync_passes.argtypes = [vp, C.POINTER(u32)]
         L.opusfe_get_counts.argtypes = [vp, C.POINTER(Counts)]
         L.opusfe_get_error.argtypes = [vp, C.POINTER(Error)]
@@ -363,6 +364,12 @@ class Context:
         n = C.c_uint64()
         lib().opusfe_memory_held(self.handle, C.byref(n))
         return n.value
+
+    def memory_stats(self):
+        """device bytes by kind: live results, cached blocks, the temporaries' arena, high-water mark"""
+        st = (C.c_uint64 * 4)()
+        lib().opusfe_memory_stats(self.handle, st)
+        return {"live": st[0], "cached": st[1], "arena": st[2], "peak": st[3]}
 
     def _finish(self, rc, out):
         if rc not in (OK, SYNTAX, UNSUPPORTED):
