@@ -67,3 +67,20 @@ def test_one_gigabyte_properties():
         assert ins[1] == c["instrs"] and ins[2] == 24
     finally:
         ctx.close()
+
+
+def test_four_gigabyte_unit_fits_one_gpu():
+    """The 2-GPU point of BASELINE config 4 is 4 GB per rank, the edge of the u32 positions (4 GiB - 64 KiB): one unit of
+    3.96e9 bytes through lex + parse + lower on ONE GPU (tools/big_unit.py, a process of its own so that its HBM goes away with
+    it) — the per-function headers tile the dense arrays, the last 64 MB block parsed alone has the kinds and spans of the unit's
+    last nodes (positions beyond 2^31, node indices beyond 2^29), lowering twice gives the same totals, and the context's
+    high-water mark stays under 30 B of HBM per source byte."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-u", os.path.join(root, "tools", "big_unit.py"), "4e9"], capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0 and out.stdout.rstrip().endswith("OK"), (out.stdout[-1500:], out.stderr[-1500:])
+    per_byte = float(re.search(r"bytes per source byte \(peak\) ([0-9.]+)", out.stdout).group(1))
+    assert per_byte < 30.0, per_byte
