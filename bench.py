@@ -418,7 +418,7 @@ def main():
             if args.stage == "ir":
                 pairs += [("instrs", c2.instrs), ("vars", c2.vars)]
             parity = {"sample_bytes": len(sample), "oracle_status": c2.status, "gpu_status": us.status,
-                      "counts_match": all(cs[k] == v for k, v in pairs) and (us.status == 0) == (c2.status == 0),
+                      "counts_match": all(cs[k] == v for k, v in pairs) and (us.status == 0) == (c2.status in (0, 3)),      # (oracle 3: IR generated, with diagnostics)
                       "compared": [k for k, _ in pairs]}
             if cs["nodes"]:
                 node_ratio = c2.nodes / cs["nodes"]

@@ -400,10 +400,40 @@ struct Gen {
         if (rng.chance(50)) n = (int)rng.range(3, 10);
         push_scope();
         for (int i = 0; i < n; i++) statement(1, false, 0);
+        if (decline_pct && rng.chance((uint32_t)decline_pct)) decliner();      // (never consulted without the flag: the plain generator's output is unchanged)
         if (f.ret >= 0) { tabs(1); out += "return "; expr((Ty)f.ret, (int)rng.below(4), true); out += '\n'; }
         pop_scope();
         pop_scope();
         funcs.push_back(std::move(f));
+    }
+    // flags bit 1: one statement that the node-parallel lowering declines (the function then goes through the sequential machine):
+    // a shadowed name, an undefined function (a diagnostic), a call through a local of function type, a parenthesised callee
+    // (CallOrIndex), a `proc` expression — what hand-written code has and the plain generator never emits
+    int decline_pct = 0;
+    void call_args(const Func& f) {
+        static const char* const LIT[] = {"1", "1i64", "1n8", "true"};
+        out += '(';
+        for (size_t i = 0; i < f.params.size(); i++) { if (i) out += ", "; out += LIT[(int)f.params[i] < 4 ? (int)f.params[i] : 0]; }
+        out += ")\n";
+    }
+    void decliner() {
+        uint32_t k = rng.below(5);
+        const Func* callee = funcs.empty() ? nullptr : &funcs[rng.below((uint32_t)funcs.size())];
+        if (callee) for (Ty t : callee->params) if ((int)t >= 4) { callee = nullptr; break; }
+        if (k >= 2 && !callee) k = 1;
+        tabs(1);
+        switch (k) {
+            case 0: out += "var "; out += scopes[scopes.size() - 2][0].name; out += " = 0\n"; break;
+            case 1: out += "nosuch_q(1)\n"; break;
+            case 2: out += "var cb_q = "; out += callee->name; out += '\n'; tabs(1); out += "cb_q"; call_args(*callee); break;
+            case 3: out += '('; out += callee->name; out += ')'; call_args(*callee); break;
+            default: {
+                out += "var pr_q = proc "; out += callee->name; out += '(';
+                for (size_t i = 0; i < callee->params.size(); i++) { if (i) out += ", "; out += TY_NAME[callee->params[i]]; }
+                out += ")\n";
+                break;
+            }
+        }
     }
     void global_def() {
         uint32_t r = rng.below(100);
@@ -500,8 +530,9 @@ void pad_to(std::string& s, size_t target) {
     }
 }
 
-std::string generate_block(uint64_t seed, uint32_t block, size_t target, bool prelude_here, bool deep, int deep_depth) {
+std::string generate_block(uint64_t seed, uint32_t block, size_t target, bool prelude_here, bool deep, int deep_depth, int decline_pct = 0) {
     Gen g(seed * 0x9E3779B97F4A7C15ull + 0x1234567ull * (block + 1), block == 0 ? std::string("") : "b" + std::to_string(block) + "_", true);
+    g.decline_pct = decline_pct;
     g.out.reserve(target + 4096);
     if (prelude_here) g.prelude();
     if (deep) g.deep_regions(deep_depth);
@@ -518,7 +549,8 @@ std::string generate_block(uint64_t seed, uint32_t block, size_t target, bool pr
 
 extern "C" {
 
-// flags: bit0 = inject the C3 deep regions (depth 1000) into block 0.
+// flags: bit0 = inject the C3 deep regions (depth 1000) into block 0; bit1 = 5 % of the functions carry one statement that the
+// node-parallel lowering declines (Gen::decliner): the "fallback cliff" workload.
 // Generates exactly `target` bytes into out (cap >= target).  Blocks of `block_bytes` are generated
 // independently (seed, block index) so that the result does not depend on the thread count.
 uint64_t opusgen_generate(uint64_t seed, uint64_t target, uint32_t flags, uint64_t block_bytes, char* out, uint64_t cap, int threads) {
@@ -532,7 +564,7 @@ uint64_t opusgen_generate(uint64_t seed, uint64_t target, uint32_t flags, uint64
     auto work = [&](int tid) {
         for (uint64_t b = (uint64_t)tid; b < nblocks; b += (uint64_t)threads) {
             uint64_t lo = b * block_bytes, hi = lo + block_bytes < target ? lo + block_bytes : target;
-            std::string s = generate_block(seed, (uint32_t)b, (size_t)(hi - lo), b == 0, b == 0 && (flags & 1), 1000);
+            std::string s = generate_block(seed, (uint32_t)b, (size_t)(hi - lo), b == 0, b == 0 && (flags & 1), 1000, (flags & 2) ? 5 : 0);
             if (s.size() != hi - lo) { ok[b] = 0; continue; }
             memcpy(out + lo, s.data(), s.size());
         }
@@ -554,7 +586,7 @@ uint64_t opusgen_generate_range(uint64_t seed, uint64_t first_block, uint64_t n_
     auto work = [&](int tid) {
         for (uint64_t i = (uint64_t)tid; i < n_blocks; i += (uint64_t)threads) {
             uint64_t b = first_block + i;
-            std::string s = generate_block(seed, (uint32_t)b, (size_t)block_bytes, b == 0, b == 0 && (flags & 1), 1000);
+            std::string s = generate_block(seed, (uint32_t)b, (size_t)block_bytes, b == 0, b == 0 && (flags & 1), 1000, (flags & 2) ? 5 : 0);
             if (s.size() != block_bytes) { ok[i] = 0; continue; }
             memcpy(out + i * block_bytes, s.data(), s.size());
         }
