@@ -91,7 +91,8 @@ void run_lexer(opusfe_ctx* ctx, opusfe_unit* u, int force_dents) {
         Cnt3* scan_tmp = tmp.get<Cnt3>((ntiles + SCAN_TILE - 1) / SCAN_TILE + 1);
         LAUNCH(ctx, "lex_ctx_chunk", k_ctx_chunk, ntiles, LEX_THREADS, src, n, chunk_fn, tile_fn, rs);
         LAUNCH(ctx, "lex_ctx_tiles", k_ctx_tiles, 1, SCAN_THREADS, tile_fn, tile_state, (uint32_t)ntiles, (uint32_t)CS_N, ctx->d_status + W_ENDFN);
-        LAUNCH(ctx, "lex_count", k_lex_count, ntiles, LEX_THREADS, src, n, chunk_fn, tile_state, chunk_state, chunk_cnt, chunk_str, tile_cnt, status, rs);
+        uint64_t* chunk_mask = tmp.get<uint64_t>(nchunks);
+        LAUNCH(ctx, "lex_count", k_lex_count, ntiles, LEX_THREADS, src, n, chunk_fn, tile_state, chunk_state, chunk_cnt, chunk_str, tile_cnt, status, rs, chunk_mask);
         prof_begin(ctx, "scan_cnt3");
         device_scan<true>(tile_cnt, tile_cnt, ntiles, OpAddCnt3(), Cnt3{0, 0, 0, 0}, scan_tmp, (Cnt3*)(ctx->d_status + W_LEXTOT), st);
         prof_end(ctx);
@@ -101,7 +102,12 @@ void run_lexer(opusfe_ctx* ctx, opusfe_unit* u, int force_dents) {
         u->d_val64 = dev_alloc_t<uint64_t>(ctx, nval);
         u->d_strpool = dev_alloc_t<uint8_t>(ctx, nstr);
         u->n_val64 = nval; u->n_strpool = nstr;
-        LAUNCH(ctx, "lex_emit", k_lex_emit, ntiles, LEX_THREADS, src, n, chunk_state, chunk_cnt, chunk_str, tile_cnt, raw, u->d_val64, u->d_strpool, status, rs);
+#ifdef OPUSFE_DIAG
+        static const bool old_emit = getenv("OPUSFE_LEX_EMIT_OLD") != nullptr;      // A/B against the chunk-per-lane emit
+        if (old_emit) LAUNCH(ctx, "lex_emit", k_lex_emit, ntiles, LEX_THREADS, src, n, chunk_state, chunk_cnt, chunk_str, tile_cnt, raw, u->d_val64, u->d_strpool, status, rs);
+        else
+#endif
+        LAUNCH(ctx, "lex_emit", k_lex_emit_tok, ntiles, LEX_THREADS, src, n, (const uint32_t*)chunk_cnt, (const uint64_t*)chunk_mask, (const Cnt3*)tile_cnt, raw, u->d_val64, u->d_strpool, status, rs);
     }
     // token-level passes over T raw tokens and T + 1 gaps
     const uint64_t G = (uint64_t)T + 1;
@@ -322,7 +328,8 @@ static int shard_lex_impl(opusfe_ctx* ctx, const uint8_t* d_src, uint64_t len, u
         uint32_t* status = ctx->d_status + W_STATUS;
         LAUNCH(ctx, "lex_ctx_chunk", k_ctx_chunk, ntiles, LEX_THREADS, d_src, n, chunk_fn, tile_fn, Resync{nullptr, 0});
         LAUNCH(ctx, "lex_ctx_tiles", k_ctx_tiles, 1, SCAN_THREADS, tile_fn, tile_state, (uint32_t)ntiles, start_state, ctx->d_status + 60);
-        LAUNCH(ctx, "lex_count", k_lex_count, ntiles, LEX_THREADS, d_src, n, chunk_fn, tile_state, chunk_state, chunk_cnt, chunk_str, tile_cnt, status, Resync{nullptr, 0});
+        uint64_t* chunk_mask = tmp.get<uint64_t>(nchunks);
+        LAUNCH(ctx, "lex_count", k_lex_count, ntiles, LEX_THREADS, d_src, n, chunk_fn, tile_state, chunk_state, chunk_cnt, chunk_str, tile_cnt, status, Resync{nullptr, 0}, chunk_mask);
         device_scan<true>(tile_cnt, tile_cnt, ntiles, OpAddCnt3(), Cnt3{0, 0, 0, 0}, scan_tmp, (Cnt3*)(ctx->d_status + W_LEXTOT), st);
         fetch_status(ctx);
         if (fn_out) *fn_out = ctx->h_status[60];
@@ -331,7 +338,7 @@ static int shard_lex_impl(opusfe_ctx* ctx, const uint8_t* d_src, uint64_t len, u
         s->raw = dev_alloc_t<opusfe_token>(ctx, T);
         s->val64 = dev_alloc_t<uint64_t>(ctx, nval);
         s->strpool = dev_alloc_t<uint8_t>(ctx, nstr);
-        LAUNCH(ctx, "lex_emit", k_lex_emit, ntiles, LEX_THREADS, d_src, n, chunk_state, chunk_cnt, chunk_str, tile_cnt, s->raw, s->val64, s->strpool, status, Resync{nullptr, 0});
+        LAUNCH(ctx, "lex_emit", k_lex_emit_tok, ntiles, LEX_THREADS, d_src, n, (const uint32_t*)chunk_cnt, (const uint64_t*)chunk_mask, (const Cnt3*)tile_cnt, s->raw, s->val64, s->strpool, status, Resync{nullptr, 0});
         const uint64_t G = (uint64_t)T + 1;
         s->depth = dev_alloc_t<int32_t>(ctx, G); s->gapval = dev_alloc_t<uint32_t>(ctx, G); s->prev = dev_alloc_t<uint32_t>(ctx, G);
         s->scan_tmp = dev_alloc_t<uint32_t>(ctx, (G + SCAN_TILE - 1) / SCAN_TILE + 2);

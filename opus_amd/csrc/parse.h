@@ -859,7 +859,9 @@ inline void run_parser(opusfe_ctx* ctx, opusfe_unit* u) {
         LAUNCH(ctx, "order_scatter", k_order_scatter, grid_for(n_segs, 256), 256, u->d_seg_start, n_segs, n_tok, order_hist, order);
         prec = tmp.get<pp::Rec16>((uint64_t)n_tok + 1);
         pp::RolesArgs A{};
-        A.tok = u->d_tokens; A.n_tokens = n_tok; A.seg_start = u->d_seg_start; A.n_segs = n_segs; A.order = order;
+        uint8_t* kinds = tmp.get<uint8_t>((uint64_t)n_tok + 16);
+        LAUNCH(ctx, "tok_kinds", pp::k_tok_kinds, grid_for(n_tok, 256), 256, (const opusfe_token*)u->d_tokens, n_tok, kinds);
+        A.tok = u->d_tokens; A.n_tokens = n_tok; A.kinds = kinds; A.seg_start = u->d_seg_start; A.n_segs = n_segs; A.order = order;
         A.table = ctx->d_pp_table; A.n_states = ctx->pp_states; A.start = ctx->pp_start;
         A.prec = prec; A.stack = tmp.get<pp::StackEnt>((uint64_t)n_tok / 2 + n_segs + 2);
         A.seg_info = u->d_seg_info; A.work = ctx->d_status + WP_PAR; A.decl_list = decl_list;

@@ -376,6 +376,7 @@ struct Rec16 { uint64_t w, x; };    // PRec as two 8-byte words
 
 struct RolesArgs {
     const opusfe_token* tok; uint32_t n_tokens;
+    const uint8_t* kinds;             // kinds[i] = tok[i].kind, one byte per token (k_tok_kinds): the automaton reads nothing else of a token
     const uint32_t* seg_start; uint32_t n_segs;
     const uint32_t* order;            // largest segments first (scan.h), may be null
     const uint32_t* table; uint32_t n_states, start;
@@ -393,10 +394,15 @@ __host__ __device__ __forceinline__ uint64_t prec_pack(uint32_t role, uint32_t k
     return (uint64_t)(role & 0xFF) | ((uint64_t)(kind & 0xFF) << 8) | ((uint64_t)(cnt & 0xFFFF) << 16) | ((uint64_t)(link & 0xFFFF) << 32) | ((uint64_t)(nid & 0xFFFF) << 48);
 }
 // 16-bit field f (0..7) of the record of token t
-__device__ __forceinline__ void prec_patch(Rec16* prec, uint32_t t, uint32_t f, uint32_t v) { gst((uint16_t*)(prec + t) + f, (uint16_t)v); }
 enum { PF_LINK = 2, PF_A = 4, PF_B = 5, PF_C = 6, PF_D = 7 };
 
 struct RolesLds { MACHINE_STATE uint32_t tbl[PP_MAX_STATES * NCLS + 16 + 32]; };
+
+// the kind of every token as a byte array: the automaton walks its segment's kinds only (1 byte of every 16-byte token record)
+__global__ void k_tok_kinds(const opusfe_token* __restrict__ tok, uint32_t n_tokens, uint8_t* __restrict__ kinds) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_tokens) kinds[i] = tok[i].kind;
+}
 
 __global__ __launch_bounds__(256) void k_pp_roles(RolesArgs a) {
 #ifdef OPUSFE_EMU
@@ -414,8 +420,29 @@ __global__ __launch_bounds__(256) void k_pp_roles(RolesArgs a) {
     const uint32_t s = a.order ? a.order[slot] : slot;
     const uint32_t tb = a.seg_start[s], te = s + 1 < a.n_segs ? a.seg_start[s + 1] : a.n_tokens;
     StackEnt* const stack = a.stack + ((uint64_t)tb / 2 + s);
-    Rec16* const prec = a.prec + tb;
     const uint32_t scap = (te - tb) / 2 + 1;
+    // The lane's records leave in WHOLE 128-byte lines: the eight records of an aligned group of tokens are kept in LDS (where the
+    // two-byte patches of the operator chain mostly land too) and stored back to back when the automaton moves on to the next group.
+    // One 16-byte store per token per lane was 64 partly written lines per wave instruction, each of them evicted and merged
+    // again several times: 12 GB written per GB of source for 3.5 GB of records.
+    __shared__ Rec16 ring[8][256];
+    const uint32_t lane = threadIdx.x;
+    uint32_t cur_grp = tb >> 3, put_end = tb;      // absolute token indices: group in the ring, end of the records written to it
+    auto flush_ring = [&]() {
+        const uint32_t lo = cur_grp * 8 > tb ? cur_grp * 8 : tb;
+        for (uint32_t ai = lo; ai < put_end; ai++) gst(&a.prec[ai], ring[ai & 7][lane]);
+    };
+    auto prec_put = [&](uint32_t rel, const Rec16& rc) {
+        const uint32_t ai = tb + rel;
+        if ((ai >> 3) != cur_grp) { flush_ring(); cur_grp = ai >> 3; }
+        ring[ai & 7][lane] = rc;
+        put_end = ai + 1;
+    };
+    auto prec_patch = [&](uint32_t t, uint32_t f, uint32_t v) {      // field f (16-bit words) of the record of token t (relative), written earlier
+        const uint32_t ai = tb + t;
+        if ((ai >> 3) == cur_grp && ai < put_end) ((uint16_t*)&ring[ai & 7][lane])[f] = (uint16_t)v;
+        else gst((uint16_t*)(a.prec + ai) + f, (uint16_t)v);
+    };
     uint32_t state = tv.start, depth = 0, count = 0, ncount = 0;
     uint32_t prev_kd = T_EndOfFile, prev_role = R_NONE;
     // the open expression and the atom being read at the current level
@@ -427,17 +454,17 @@ __global__ __launch_bounds__(256) void k_pp_roles(RolesArgs a) {
     auto fetch = [&](uint32_t from) {
         uint64_t w = 0;
 #pragma unroll
-        for (uint32_t q = 0; q < AHEAD; q++) { const uint32_t j = from + q; const uint32_t k = j < a.n_tokens ? (uint32_t)gld(&a.tok[j].kind) : (uint32_t)T_EndOfFile; w |= (uint64_t)k << (8 * q); }
+        for (uint32_t q = 0; q < AHEAD; q++) { const uint32_t j = from + q; const uint32_t k = j < a.n_tokens ? (uint32_t)gld(&a.kinds[j]) : (uint32_t)T_EndOfFile; w |= (uint64_t)k << (8 * q); }
         return w;
     };
     // the expression open at this level ends before token `at` (relative)
     auto close_sequence = [&](uint32_t at) {
         if (seq_head == PP_NONE16) return;
         const uint32_t atom_root = first_prefix != PP_NONE16 ? first_prefix : top;
-        if (last_op != PP_NONE16) { prec_patch(prec, last_op, PF_B, at | PX_END); prec_patch(prec, last_op, PF_D, atom_root); }
+        if (last_op != PP_NONE16) { prec_patch(last_op, PF_B, at | PX_END); prec_patch(last_op, PF_D, atom_root); }
         const uint32_t root = best_op != PP_NONE16 ? best_op : atom_root;
-        if (best_prec & 0x80) prec_patch(prec, seq_head, PF_C, root);       // the expression starts with `not`
-        else { prec_patch(prec, seq_head, PF_A, root); prec_patch(prec, seq_head, PF_B, at); }
+        if (best_prec & 0x80) prec_patch(seq_head, PF_C, root);       // the expression starts with `not`
+        else { prec_patch(seq_head, PF_A, root); prec_patch(seq_head, PF_B, at); }
         seq_head = PP_NONE16;
     };
     if (ok && tb < te) { cur = fetch(tb); nxt = fetch(tb + AHEAD); }
@@ -451,7 +478,7 @@ __global__ __launch_bounds__(256) void k_pp_roles(RolesArgs a) {
         else if (kd == T_LeftBrace && next_kd == T_RightBrace) cls = C_LBE;
         else if (kd == T_Var) {            // parse.rs:1134: `=` behind the name decides between a definition and a typed declaration
             const uint32_t j = i + (next_kd == T_Operator ? 3u : 2u);
-            if (j < a.n_tokens && gld(&a.tok[j].kind) == T_Equals) cls = C_VAR_EQ;
+            if (j < a.n_tokens && gld(&a.kinds[j]) == T_Equals) cls = C_VAR_EQ;
         }
         const Entry e = tv.t[state * NCLS + cls];
         if (e.act & A_ERR) { ok = false; break; }
@@ -469,7 +496,7 @@ __global__ __launch_bounds__(256) void k_pp_roles(RolesArgs a) {
             const uint32_t p = (uint32_t)prec_of_kind((uint8_t)kd);
             r_a = last_op != PP_NONE16 ? last_op : (seq_head | PX_END);
             r_c = atom_root;
-            if (last_op != PP_NONE16) { prec_patch(prec, last_op, PF_B, rel); prec_patch(prec, last_op, PF_D, atom_root); }
+            if (last_op != PP_NONE16) { prec_patch(last_op, PF_B, rel); prec_patch(last_op, PF_D, atom_root); }
             if (p <= (best_prec & 0x7F)) { best_op = rel; best_prec = (best_prec & 0x80) | p; }
             last_op = rel; first_prefix = PP_NONE16; top = PP_NONE16;
         } else if (ic == IC_PREFIX) { if (first_prefix == PP_NONE16) first_prefix = rel; }
@@ -487,19 +514,19 @@ __global__ __launch_bounds__(256) void k_pp_roles(RolesArgs a) {
             if (depth == 0) { ok = false; break; }
             const StackEnt se = gld(&stack[--depth]);
             r_link = se.opener; r_cnt = count;
-            prec_patch(prec, se.opener, PF_LINK, rel);
+            prec_patch(se.opener, PF_LINK, rel);
             count = se.count; state = se.ret;
             seq_head = se.seq_head; last_op = se.last_op; best_op = se.best_op; best_prec = se.best_prec; first_prefix = se.first_prefix; top = se.top;
         } else state = e.next;
         Rec16 rc; rc.w = prec_pack(e.role, kd, r_cnt, r_link, ncount);
         rc.x = (uint64_t)(r_a & 0xFFFF) | ((uint64_t)(r_b & 0xFFFF) << 16) | ((uint64_t)(r_c & 0xFFFF) << 32) | ((uint64_t)(r_d & 0xFFFF) << 48);
-        gst(&prec[rel], rc);
+        prec_put(rel, rc);
         ncount += nn;
         if (ncount > 65535u || count > 65535u) { ok = false; break; }
         prev_kd = kd; prev_role = e.role;
     }
     if (ok && (depth != 0 || (tv.t[state * NCLS + C_END].act & A_ERR))) ok = false;
-    if (ok) close_sequence(te - tb);        // `var x T = e` / `const` at the end of the segment
+    if (ok) { close_sequence(te - tb); flush_ring(); }        // `var x T = e` / `const` at the end of the segment
     uint32_t* si = a.seg_info + (uint64_t)s * PSI_WORDS;
     if (ok) {
         si[PSI_NODE_COUNT] = ncount; si[PSI_DEF_COUNT] = count; si[PSI_ERR_KIND] = OPUSFE_NONE; si[PSI_PATH] = 0;

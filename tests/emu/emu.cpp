@@ -133,6 +133,9 @@ void emu_parse(EmuUnit& E) {
     if (getenv("EMU_PARSER_SEQ")) emu_launch(pp::k_pp_all_sequential, grid_for(n_segs, 256), 256, (const uint32_t*)E.seg_start.data(), n_segs, n_tok, E.seg_info.data(), work, decl_list.data());
     else {
         pp::RolesArgs A{};
+        std::vector<uint8_t> kinds(n_tok);
+        emu_launch(pp::k_tok_kinds, grid_for(n_tok, 256), 256, (const opusfe_token*)u.h_tokens.data(), n_tok, kinds.data());
+        A.kinds = kinds.data();
         A.tok = u.h_tokens.data(); A.n_tokens = n_tok; A.seg_start = E.seg_start.data(); A.n_segs = n_segs; A.order = nullptr;
         A.table = PT.blob.data(); A.n_states = PT.n_states; A.start = PT.start; A.prec = prec; A.stack = pstack;
         A.seg_info = E.seg_info.data(); A.work = work; A.decl_list = decl_list.data();
