@@ -795,6 +795,20 @@ __device__ __forceinline__ uint32_t type_next(const Walker& W, uint32_t ts, uint
     }
 }
 
+// role class of a token for k_pp_build's in-block ordering (7: the role creates no node)
+__device__ __forceinline__ uint32_t build_class(uint32_t role) {
+    switch (role) {
+        case R_E_LEAF: return 0;
+        case R_BINOP: case R_E_NOT: return 1;
+        case R_POST_AT: case R_POST_DOT: case R_CALL_LP: case R_POST_COLON: case R_E_LP: case R_E_PREFIX: return 2;
+        case R_S_RETURN: case R_S_VAR_DEF: case R_S_VAR_T: case R_S_IFWHILE: case R_S_FOR: case R_S_BREAKCONT: case R_INDENT: return 3;
+        case R_TY_NAME: case R_TY_NULL: case R_TY_AT: case R_TY_LB: case R_TY_LP: case R_TY_RECORD: case R_TY_FIELD: case R_SIG_ARG: return 4;
+        case R_D_EXTERN: case R_D_FN: case R_D_VAR: case R_D_CONST: case R_D_TYPE: case R_D_IMPORT: return 5;
+        case R_E_VARDEF: case R_E_SIZEOF: case R_E_RECORD: case R_E_FIELD: case R_E_PROC: return 6;
+        default: return 7;
+    }
+}
+
 // One thread per token: the node records of the nodes its token creates.
 __global__ __launch_bounds__(PP_BLOCK) void k_pp_build(const opusfe_token* __restrict__ tok, uint32_t n_tokens, const uint32_t* __restrict__ seg_start, uint32_t n_segs,
                                                         const Rec16* __restrict__ pr, const uint32_t* __restrict__ seg_info, const NodeBase* __restrict__ base,
@@ -809,10 +823,49 @@ __global__ __launch_bounds__(PP_BLOCK) void k_pp_build(const opusfe_token* __res
     }
     __syncthreads();
 #endif
-    const uint32_t i = b0 + threadIdx.x;
-    if (i >= n_tokens) return;
+    uint32_t i = b0 + threadIdx.x;
     uint32_t s = 0;
+#ifndef OPUSFE_EMU
+    {   // Tokens of one role class to neighbouring lanes: the switch below is one body per role and a wave pays for every body any of
+        // its lanes takes; in token order a wave holds a dozen roles.  A counting sort of the block's 256 tokens by role class (LDS
+        // atomics) puts leaves next to leaves and operators next to operators; tokens that create no node drop out together.
+        __shared__ uint32_t hist[8];
+        __shared__ uint16_t order[PP_BLOCK];
+        uint32_t cls = 7;
+        if (i < n_tokens) {
+            Rec r; r.w = BuildLds::w[i - wlo]; r.x = 0;
+            cls = build_class(r.role());
+            if (cls == 7 && r.head()) cls = 3;
+        }
+        if (threadIdx.x < 8) hist[threadIdx.x] = 0;
+        __syncthreads();
+        const uint32_t rank = atomicAdd(&hist[cls], 1u);
+        __syncthreads();
+        if (threadIdx.x == 0) { uint32_t run = 0; for (int c = 0; c < 8; c++) { const uint32_t v = hist[c]; hist[c] = run; run += v; } }
+        __syncthreads();
+        order[hist[cls] + rank] = (uint16_t)threadIdx.x;
+        __syncthreads();
+        i = b0 + order[threadIdx.x];
+        if (threadIdx.x >= hist[7]) i = 0xFFFFFFFFu;      // no node to write (leaves behind the barriers below)
+    }
+    {   // the segment of every token of the block: ONE search of the segment table (for the block's first token), then the block's
+        // window of segment starts in LDS (a segment has at least one token, so the block touches at most PP_BLOCK segments)
+        __shared__ uint32_t seg_first;
+        __shared__ uint32_t segw[PP_BLOCK];
+        if (threadIdx.x == 0) { uint32_t a = 0, b = n_segs; while (b - a > 1) { const uint32_t m = (a + b) >> 1; if (seg_start[m] <= b0) a = m; else b = m; } seg_first = a; }
+        __syncthreads();
+        const uint32_t s0 = seg_first;
+        segw[threadIdx.x] = s0 + threadIdx.x < n_segs ? seg_start[s0 + threadIdx.x] : 0xFFFFFFFFu;
+        __syncthreads();
+        uint32_t a = 0, b = PP_BLOCK;
+        while (b - a > 1) { const uint32_t m = (a + b) >> 1; if (segw[m] <= i) a = m; else b = m; }
+        s = s0 + a;
+    }
+    if (i >= n_tokens) return;      // (also the tokens that create no node)
+#else
+    if (i >= n_tokens) return;
     { uint32_t a = 0, b = n_segs; while (b - a > 1) { const uint32_t m = (a + b) >> 1; if (seg_start[m] <= i) a = m; else b = m; } s = a; }
+#endif
     if (seg_info[(uint64_t)s * PSI_WORDS + PSI_PATH] != 0) return;          // SegParser's segment
     Walker W; W.tok = tok; W.pr = pr; W.wlo = wlo;
     W.tb = seg_start[s]; W.te = s + 1 < n_segs ? seg_start[s + 1] : n_tokens; W.nb = base[s].nodes;
