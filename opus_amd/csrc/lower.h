@@ -1532,6 +1532,7 @@ struct IrResult {
     uint32_t* d_cargs = nullptr; TypeRec* d_types = nullptr; SemErr* d_errs = nullptr; FuncRec* d_funcrecs = nullptr; GlobalRec* d_globals = nullptr;
     uint32_t* d_tid_of_node = nullptr;
     uint64_t n_funcs = 0, n_globals = 0, n_vars = 0, n_instrs = 0, n_bbs = 0, n_types = 0, n_gtypes = 0, n_cargs = 0, n_errs = 0, n_sem_errors = 0;
+    uint32_t n_rounds = 0;                   // rounds of the count pass of the flat lowering (longest dependency chain of a function)
     uint64_t n_fallback = 0, n_bodies = 0;   // functions that the sequential machine lowered, of n_bodies functions with bodies
     // host mirrors
     bool have_host = false;
@@ -1730,22 +1731,33 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
         HIP_TRY(hipMemsetAsync(ctx->d_status + WL_STATUS, 0, 2 * sizeof(uint32_t), st));
         HIP_TRY(hipMemsetAsync(ctx->d_status + WL_BODIES, 0, sizeof(uint32_t), st));
         HIP_TRY(hipMemcpyAsync(R->d_types, gtypes, (size_t)n_gtypes * sizeof(TypeRec), hipMemcpyDeviceToDevice, st));
-        LAUNCH(ctx, "par_init", par::k_par_init, grid_for(n_defs, 256), 256, u->d_nodes, u->d_def_nodes, n_defs, def_excl, R->d_funcs, ctx->d_status + WL_BODIES, (const uint8_t*)def_skip);
+        TempList tmp2(ctx);       // the machine's sparse regions and the per-node state of the flat passes live for one attempt
+        // per-node state of the flat passes (lower_par.h FlatArgs): 58 B per node + three lists of 4 B per node
+        par::FlatArgs X{};
+        const uint64_t n_list = (uint64_t)n_nodes + 64 * par::KC_ACTIVE;
+        X.ctl = tmp2.get<uint32_t>(par::CTL_WORDS);
+        X.fninfo = tmp2.get<par::FnInfo>(n_funcs); X.fb = tmp2.get<uint32_t>(n_funcs);
+        X.st = tmp2.get<uint32_t>(n_nodes); X.ref = tmp2.get<uint32_t>(n_nodes); X.rvi = tmp2.get<uint32_t>(n_nodes); X.rt = tmp2.get<uint64_t>(n_nodes); X.cnt = tmp2.get<uint64_t>(2ull * n_nodes);
+        X.tail = tmp2.get<uint8_t>(2ull * n_nodes); X.pe = tmp2.get<uint16_t>(n_nodes); X.sz = tmp2.get<uint16_t>(n_nodes); X.cg = tmp2.get<uint16_t>(n_nodes); X.pa = tmp2.get<uint16_t>(n_nodes);
+        X.wnext = tmp2.get<uint16_t>(n_nodes); X.whead = tmp2.get<uint16_t>(n_nodes); X.fn_of = tmp2.get<uint32_t>(n_nodes);
+        X.order = tmp2.get<uint32_t>(n_list); X.wl0 = tmp2.get<uint32_t>(n_list); X.wl1 = tmp2.get<uint32_t>(n_list);
+        HIP_TRY(hipMemsetAsync(X.ctl, 0, par::CTL_WORDS * sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(X.fn_of, 0xFF, (size_t)n_nodes * sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(X.rt, 0xFF, (size_t)n_nodes * sizeof(uint64_t), st));      // DESC_NONE
+        HIP_TRY(hipMemsetAsync(X.cnt, 0, (size_t)n_nodes * 2 * sizeof(uint64_t), st));
+        HIP_TRY(hipMemsetAsync(X.tail, 0, (size_t)n_nodes * 2, st));
+        HIP_TRY(hipMemsetAsync(X.rvi, 0, (size_t)n_nodes * sizeof(uint32_t), st));
+        LAUNCH(ctx, "par_init", par::k_par_init, grid_for(n_defs, 256), 256, u->d_nodes, u->d_def_nodes, n_defs, def_excl, R->d_funcs, ctx->d_status + WL_BODIES, (const uint8_t*)def_skip, X.fninfo, X.fb);
         par::ParArgs PA{};
         PA.def_nodes = u->d_def_nodes; PA.n_defs = n_defs; PA.n_nodes = n_nodes; PA.def_excl = def_excl; PA.undefined_flag = undefined_flag; PA.user_syms = user_syms;
         PA.pp_base = pp_base; PA.out = R->d_funcs; PA.status = ctx->d_status + WL_STATUS; PA.skip = def_skip;
-#ifdef OPUSFE_DIAG
-        { static const char* sp = getenv("OPUSFE_PAR_STOP"); PA.stop_phase = sp ? (uint32_t)atoi(sp) : 0u; }
-        { static const char* sr = getenv("OPUSFE_PAR_ROUNDS"); PA.stop_rounds = sr ? (uint32_t)atoi(sr) : 0u; }
-        { static const char* cl = getenv("OPUSFE_PAR_CLIMB"); PA.climb = cl ? (uint32_t)atoi(cl) : 0u; }
-#endif
         PA.counters = counters; PA.overflow = (uint32_t*)(counters + par::CTR_COUNT); PA.err_counter = (uint32_t*)(counters + par::CTR_COUNT + 1);
         PA.cap_vars = cap[0]; PA.cap_instrs = cap[1]; PA.cap_bbs = cap[2]; PA.cap_types = cap[3]; PA.cap_cargs = cap[4]; PA.cap_errs = cap[5];
         PA.vars = R->d_vars; PA.instrs = R->d_instrs; PA.bb_offsets = R->d_bb_offsets; PA.cargs = R->d_cargs; PA.types_out = R->d_types;
+        PA.dbg = X.ctl + par::CTL_DBG;
         S.types = gtypes;
         // The sequential machine on the functions flagged in `flag` (sparse regions laid out by `idx`), then their places in the
         // dense arrays and the compaction into them; all on stream `ms`.
-        TempList tmp2(ctx);       // the machine's sparse regions live for one attempt
         // Declared behind the temporaries, so destroyed before them: if anything below throws while the second stream still runs the
         // machine on tmp2's blocks (and writes R's arrays), both streams are drained before a block returns to the allocator.
         struct ForkGuard {
@@ -1793,22 +1805,17 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
         HIP_TRY(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
         fork_guard.armed = true;
         if (big_funcs) { if (!machine_pass(ctx->stream2, big_flag, big_idx, big_nodes, big_funcs, false)) { HIP_TRY(hipStreamSynchronize(ctx->stream2)); return; } }
-        {
-            // One launch per half-octave size class (scan.h order_class_of_size): the LDS a workgroup reserves is sized for the largest
-            // function of its class, so at most a third of it is unused.  Functions of 2048 nodes and more, and the ones the fast path
-            // declines, go through the sequential machine.  OPUSFE_PAR_SHAPE=a,b,c overrides the thread counts of the three shapes.
-#ifdef OPUSFE_DIAG
-            static const char* shape_env = getenv("OPUSFE_PAR_SHAPE");
-#else
-            constexpr const char* shape_env = nullptr;
-#endif
-            uint32_t ts = 64, tm = 256, tl = 512;      // (only with OPUSFE_PAR_SHAPE)
-            if (shape_env) sscanf(shape_env, "%u,%u,%u", &ts, &tm, &tl);
-            static const char* const NAMES[12] = {"lower_par_64", "lower_par_96", "lower_par_128", "lower_par_192", "lower_par_256", "lower_par_384", "lower_par_512",
-                                                  "lower_par_768", "lower_par_1024", "lower_par_1536", "lower_par_2048", "lower_par"};
+        if (!seq_only) {
+            // k_flat_pre: one launch per half-octave size class (scan.h order_class_of_size): the LDS a workgroup reserves is sized for the
+            // largest function of its class, so at most a third of it is unused.  Functions of 2048 nodes and more, and the ones the
+            // flat path declines, go through the sequential machine.
+            LAUNCH(ctx, "flat_kind_hist", par::k_flat_kind_hist, std::min<unsigned>(grid_for(n_nodes, 256), 4096u), 256, (const opusfe_node*)u->d_nodes, n_nodes, X.ctl);
+            LAUNCH(ctx, "flat_offsets", par::k_flat_offsets, 1, 64, X.ctl);
+            static const char* const NAMES[12] = {"lower_pre_64", "lower_pre_96", "lower_pre_128", "lower_pre_192", "lower_pre_256", "lower_pre_384", "lower_pre_512",
+                                                  "lower_pre_768", "lower_pre_1024", "lower_pre_1536", "lower_pre_2048", "lower_pre"};
             const uint32_t c_top = order_class_of_size(2047), c_small = order_class_of_size(63);     // classes above c_top: sequential machine
             int name_i = 10;
-            for (uint32_t c = c_top; c >= c_small && !seq_only; c--, name_i--) {
+            for (uint32_t c = c_top; c >= c_small; c--, name_i--) {
                 // the smallest launch takes every class up to c_small
                 const uint32_t lo = class_end[c + 1], hi = c == c_small ? n_defs : class_end[c];
                 if (hi <= lo) continue;
@@ -1816,39 +1823,75 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
                 a.list = order + lo; a.n_list = hi - lo;
                 a.nmax = (uint32_t)order_class_lo(c + 1) - 1u; if (a.nmax < 63) a.nmax = 63;
                 a.maxdef = a.nmax / 8 < 32 ? 32 : a.nmax / 8;
-                // threads: as many waves per workgroup as it takes to reach the waves per CU that the registers allow
-                // (4 SIMDs x OPUSFE_PAR_WAVES) with the workgroups that fit the 160 KB of LDS
-                uint32_t threads;
-                if (shape_env) threads = a.nmax <= 256 ? ts : a.nmax <= 1024 ? tm : tl;
-                else {
-                    // any number of waves per workgroup: the one that keeps the most functions resident among those that fill the
-                    // CU's wave slots to within one wave (16 = 4 SIMDs x OPUSFE_PAR_WAVES; LDS is allocated in 1280-byte granules)
-                    uint32_t best_waves = 0;
-                    uint32_t resident[17] = {0};
-                    for (uint32_t w = 1; w <= 16; w++) {
-                        const size_t need = (par::lds_bytes(a.nmax, a.maxdef, 64 * w) + 256 + 1279) / 1280 * 1280;
-                        const uint32_t blocks = (uint32_t)std::min<size_t>((160u << 10) / need, (4 * OPUSFE_PAR_WAVES) / w);
-                        resident[w] = blocks * w;
-                        best_waves = std::max(best_waves, resident[w]);
-                    }
-                    uint32_t w = 1;
-#ifdef OPUSFE_DIAG
-                    static const uint32_t slack = getenv("OPUSFE_PAR_SLACK") ? (uint32_t)atoi(getenv("OPUSFE_PAR_SLACK")) : 1u;
-#else
-                    constexpr uint32_t slack = 1u;
-#endif
-                    while (w < 16 && resident[w] + slack < best_waves) w++;
-                    threads = 64 * w;
+                // any number of waves per workgroup: the one that keeps the most functions resident among those that fill the
+                // CU's wave slots to within one wave (4 SIMDs x OPUSFE_PAR_WAVES; LDS is allocated in 1280-byte granules)
+                uint32_t best_waves = 0;
+                uint32_t resident[17] = {0};
+                for (uint32_t w = 1; w <= 16; w++) {
+                    const size_t need = (par::lds_bytes(a.nmax, a.maxdef, 64 * w) + 256 + 1279) / 1280 * 1280;
+                    const uint32_t blocks = (uint32_t)std::min<size_t>((160u << 10) / need, (4 * OPUSFE_PAR_WAVES) / w);
+                    resident[w] = blocks * w;
+                    best_waves = std::max(best_waves, resident[w]);
                 }
+                uint32_t w = 1;
+                while (w < 16 && resident[w] + 1u < best_waves) w++;
+                const uint32_t threads = 64 * w;
                 const size_t lds = par::lds_bytes(a.nmax, a.maxdef, threads);
                 prof_begin(ctx, NAMES[name_i < 0 ? 11 : name_i]);
-{
-                    HIP_TRY(hipFuncSetAttribute((const void*)par::k_lower_par, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                    hipLaunchKernelGGL(par::k_lower_par, dim3(a.n_list), dim3(threads), lds, st, S, a);
-                }
+                HIP_TRY(hipFuncSetAttribute((const void*)par::k_flat_pre, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(par::k_flat_pre, dim3(a.n_list), dim3(threads), lds, st, S, a, X);
                 HIP_TRY(hipGetLastError());
                 prof_end(ctx);
             }
+            // The rounds of the count pass: one launch per kind class and round over that round's ready list.  How many rounds there
+            // are is the longest dependency chain of any function; the host looks at the list lengths every few rounds.
+            const unsigned rgrid = std::min<unsigned>(grid_for(n_nodes, 256), 2048u);
+            auto launch_classes = [&](auto kernel_of_class, auto... extra) {
+                kernel_of_class(std::integral_constant<int, 0>(), extra...); kernel_of_class(std::integral_constant<int, 1>(), extra...);
+                kernel_of_class(std::integral_constant<int, 2>(), extra...); kernel_of_class(std::integral_constant<int, 3>(), extra...);
+                kernel_of_class(std::integral_constant<int, 4>(), extra...); kernel_of_class(std::integral_constant<int, 5>(), extra...);
+                kernel_of_class(std::integral_constant<int, 6>(), extra...); kernel_of_class(std::integral_constant<int, 7>(), extra...);
+            };
+            auto count_round = [&](auto cls, uint32_t r) {
+                hipLaunchKernelGGL(par::k_flat_count<decltype(cls)::value>, dim3(rgrid), dim3(256), 0, st, S, PA, X, r);
+            };
+            uint32_t hcnt[par::KC_ACTIVE];
+            uint32_t rounds_run = 0;
+            bool tail = false;      // few ready nodes left: one small launch per round that holds every class
+            for (uint32_t r = 0; r < par::FLAT_MAX_ROUNDS;) {
+                const uint32_t chunk = tail ? 32u : 4u;
+                prof_begin(ctx, tail ? "lower_count_tail" : "lower_count");
+                for (uint32_t k = 0; k < chunk && r < par::FLAT_MAX_ROUNDS; k++, r++) {
+                    if (tail) hipLaunchKernelGGL(par::k_flat_count<par::KC_ANY>, dim3(64), dim3(256), 0, st, S, PA, X, r);
+                    else launch_classes(count_round, r);
+                }
+                HIP_TRY(hipGetLastError());
+                prof_end(ctx);
+                rounds_run = r;
+                HIP_TRY(hipMemcpyAsync(hcnt, X.ctl + par::CTL_ROUNDS + (size_t)r * par::KC_ACTIVE, sizeof hcnt, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                prof_collect(ctx);
+                uint64_t ready = 0;
+                for (uint32_t c = 0; c < par::KC_ACTIVE; c++) ready += hcnt[c];
+                if (!ready) break;
+                tail = ready <= (1u << 16);
+            }
+            R->n_rounds = rounds_run;
+            if (getenv("OPUSFE_ROUNDS_DUMP")) {
+                std::vector<uint32_t> hc((size_t)(rounds_run + 1) * par::KC_ACTIVE);
+                HIP_TRY(hipMemcpy(hc.data(), X.ctl + par::CTL_ROUNDS, hc.size() * 4, hipMemcpyDeviceToHost));
+                for (uint32_t r = 0; r <= rounds_run; r++) { uint64_t t = 0; for (int c = 0; c < 8; c++) t += hc[r * 8 + c]; if (r < 48 || r % 32 == 0) fprintf(stderr, "round %u: %llu ready (%u %u %u %u %u %u %u %u)\n", r, (unsigned long long)t, hc[r*8], hc[r*8+1], hc[r*8+2], hc[r*8+3], hc[r*8+4], hc[r*8+5], hc[r*8+6], hc[r*8+7]); }
+            }
+            LAUNCH(ctx, "lower_scan", par::k_flat_scan, grid_for((uint64_t)n_defs * 64, 256), 256, S, PA, X);
+            LAUNCH(ctx, "lower_rv", par::k_flat_rv, std::min<unsigned>(grid_for(n_nodes, 256), 4096u), 256, PA, X);
+            auto emit_class = [&](auto cls) {
+                hipLaunchKernelGGL(par::k_flat_emit<decltype(cls)::value>, dim3(rgrid), dim3(256), 0, st, S, PA, X);
+            };
+            prof_begin(ctx, "lower_emit");
+            launch_classes(emit_class);
+            HIP_TRY(hipGetLastError());
+            prof_end(ctx);
+            LAUNCH(ctx, "flat_check", par::k_flat_check, 1, 64, (const uint32_t*)X.ctl, ctx->d_status + WL_STATUS);
         }
         HIP_TRY(hipEventRecord(ctx->ev_join, ctx->stream2));
         HIP_TRY(hipStreamWaitEvent(st, ctx->ev_join, 0));
@@ -1870,7 +1913,11 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
         HIP_TRY(hipStreamSynchronize(st));
         prof_collect(ctx);
         const uint32_t lst = ctx->h_status[WL_STATUS];
-        if (lst >= DS_INTERNAL_CAPACITY) { u->status = OPUSFE_ERR_INTERNAL; ctx->msg = "lowering: internal capacity / consistency check failed"; return; }
+        if (lst >= DS_INTERNAL_CAPACITY) {
+            uint32_t line = 0;
+            (void)hipMemcpy(&line, X.ctl + par::CTL_DBG, 4, hipMemcpyDeviceToHost);
+            u->status = OPUSFE_ERR_INTERNAL; ctx->msg = "lowering: internal capacity / consistency check failed (lower_par.h:" + std::to_string(line) + ")"; return;
+        }
         if (lst != DS_OK) { u->status = OPUSFE_UNSUPPORTED; u->dev_status = lst; ctx->msg = "construct on which the reference panics (unreachable!/unwrap) or overflows its stack"; return; }
         const uint64_t tot[5] = {hc[par::CTR_VARS], hc[par::CTR_INSTR_BB] & ((1ull << par::CTR_BB_SHIFT) - 1), hc[par::CTR_INSTR_BB] >> par::CTR_BB_SHIFT, hc[par::CTR_TYPES], hc[par::CTR_CARGS]};
         const bool overflow = (uint32_t)hc[par::CTR_COUNT] != 0;

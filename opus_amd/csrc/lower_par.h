@@ -1,33 +1,38 @@
-// Node-parallel IR generation (generate_ir.rs:100-1199 as count -> scan -> emit instead of a sequential walk).
+// Node-parallel IR generation (generate_ir.rs:100-1199 as count -> scan -> emit instead of a sequential walk), FLAT over the
+// whole unit: one lane per AST node of ANY function, nodes of one kind class in neighbouring lanes, per-node state in HBM.
 //
-// One workgroup lowers one function with ONE LANE PER AST NODE (strided); all per-node state lives in LDS.
+// Round 2 ran all of this inside one workgroup per function with the state in LDS; a function has a handful of ready nodes
+// of one kind per dependency level, so 11 of 64 lanes worked and the kernel was bound by instructions issued (1 % of the HBM
+// roofline).  Here only the part that is local to a function by nature stays in a workgroup:
 //
-//   structure   parent / subtree size / depth / pre-order rank of every node of the function (nodes arrive in the parser's
-//               creation order, not pre-order: none of this is index arithmetic)
-//   names       every local definition (arguments, `var`, `for` variables) goes to a small table; every name use finds
-//               its definition by (definition point <= use < end of the defining block): lookups are structural,
-//               no scope stack is walked (generate_ir.rs:176-185, 857-893)
-//   contexts    how a node is evaluated: generate_ir_from_expression with which expected type (:510) or
-//               try_generate_pointer_from_expression with which pointer kind (:985), decided by the parent
-//   types       bottom-up fixpoint: a node is lowered as soon as its operands (and the locals it reads) have types.
-//               Lowering a node = running its slice of the reference's emission schema against an
-//               emitter that only COUNTS: variables, types, instructions and basic blocks per EVENT.  Events are the
-//               points of the Euler tour of the tree: ENTER(node) and EXIT(node) (= what the parent emits right after
-//               this child).
-//   scan        exclusive scan of the counts in Euler order: variable ids, block ids and instruction slots.  Two facts make
-//               this the final layout: (1) the current block is always the newest block (every `bb_index = x` of the
-//               reference assigns the block it has just created), so emission order IS block-major order; (2) every
-//               deferred terminator (`bbs[branch].push(..)`, :310-312, 357-359) goes to a block at the moment that block stops
-//               being current, so it can be emitted right there (last paragraph).
-//   emit        the same visitor again, now writing variables / instructions / types at the scanned positions, straight
-//               into the dense result arrays.
+//   k_flat_pre    (one workgroup per function, LDS) structure: parent / subtree size / depth / pre-order rank of every node
+//                 (nodes arrive in the parser's creation order, not pre-order: none of this is index arithmetic); evaluation
+//                 contexts (generate_ir_from_expression with which expected type :510, try_generate_pointer_from_expression with
+//                 which pointer kind :985); local definitions and name resolution by (definition point <= use < end of the
+//                 defining block) — no scope stack is walked (generate_ir.rs:176-185, 857-893); the kind class of every node and
+//                 what it WAITS for: its operands, the `var` / `for` definition it reads, the left side of its assignment.
+//                 Everything a later pass reads is written to the unit-wide per-node arrays (FlatArgs).
+//   k_flat_count  (one lane per READY node, one launch per kind class and round) lowering a node = running its slice of the
+//                 reference's emission schema against an emitter that only COUNTS variables, types,
+//                 instructions and basic blocks per EVENT (the points of the Euler tour of the tree: ENTER(node), EXIT(node)).
+//                 A finished node releases who waits for it (atomic counters in the state words); what becomes ready is
+//                 appended to the next round's list of its class.  Rounds = the longest dependency chain of any function.
+//   k_flat_scan   (one wave per function) exclusive scan of the counts in Euler order: variable ids, block ids, instruction
+//                 slots.  Two facts make this the final layout: (1) the current block is always the newest block, so emission
+//                 order IS block-major order; (2) every deferred terminator (`bbs[branch].push(..)`, :310-312, 357-359) goes to a
+//                 block at the moment that block stops being current.  The function takes its place in the dense result
+//                 arrays with one atomic per array.
+//   k_flat_rv     (one lane per node) every node learns the id of the variable that holds its result.
+//   k_flat_emit   (one lane per node, one launch per kind class) the same visitor again, writing variables / instructions /
+//                 types at the scanned positions, straight into the dense result arrays.
 //
 // The fast path declines (the function is lowered by the sequential machine of lower.h instead, bit-identical by
 // construction) whenever it meets something it does not model: any semantic error, shadowing, structural type
-// comparisons of records / function types with different ids, E_Proc / CallOrIndex / `is`, functions larger than the
-// LDS tables.  How many functions decline is reported (FuncIr.status == DS_FALLBACK, IrResult::n_fallback).
+// comparisons of records / function types with different ids, E_Proc / CallOrIndex, functions larger than the
+// LDS tables of k_flat_pre.  How many functions decline is reported (FuncIr.status == DS_FALLBACK, IrResult::n_fallback).
 #pragma once
 // (included from lower.h, behind the sequential machine: uses FuncIr, DefCnt, the tables of sem.h)
+
 
 namespace opusfe {
 namespace par {
@@ -81,13 +86,32 @@ struct ParArgs {
     // counters[0] = instructions | blocks << 36 (one atomic, so that block order and instruction order agree: the end of a
     // function's last block is the start of the next function's first), [1] variables, [2] local types, [3] call arguments.
     // When an array is too small nothing is written, `overflow` is raised and the host runs again with the exact totals.
-    uint32_t stop_phase;      // diagnostics (OPUSFE_PAR_STOP): leave after phase n, 0 = run everything
-    uint32_t stop_rounds;     // diagnostics (OPUSFE_PAR_ROUNDS): at most n rounds of the type fixpoint, 0 = no limit
-    uint32_t climb;           // type fixpoint: the lane that lowers the last operand goes on with the parent (OPUSFE_PAR_CLIMB=0 turns it off)
     unsigned long long* counters; uint32_t* overflow; uint32_t* err_counter;   // (semantic errors: sequential machine only)
     uint64_t cap_vars, cap_instrs, cap_bbs, cap_types, cap_cargs, cap_errs;
     opusfe_variable* vars; opusfe_instr* instrs; uint32_t* bb_offsets; uint32_t* cargs; TypeRec* types_out;
+    uint32_t* dbg;            // source line of the consistency check that failed (diagnostics of DS_INTERNAL_CAPACITY)
 };
+
+// Kind class of a node: neighbouring lanes lower the same kind of node, and every class has a kernel of its own that contains
+// only its cases of the visitor (registers, code size).  KC_NONE: nothing to lower (type nodes, carriers, dead code).
+enum { KC_VARIABLE = 0, KC_INTEGER = 1, KC_OPERATOR = 2, KC_SIMPLE = 3, KC_STATEMENT = 4, KC_CONTROL = 5, KC_CALL = 6, KC_OTHER = 7, KC_ACTIVE = 8, KC_NONE = 15, KC_ANY = 99 };
+
+// The unit-wide per-node state of the flat passes (temporaries of one lowering; index = node index in the unit).
+struct FnInfo { uint32_t dn, nn, nargs, ret, sym_mix, pad0, pad1, pad2; };     // what a lane needs of its function (nn == 0: not on the flat path)
+enum : uint32_t { CTL_OFF = 0 /* KC_ACTIVE + 1 class offsets into the lists */, CTL_ORDER = 16 /* KC_ACTIVE counts: all nodes of a class */, CTL_DBG = 30, CTL_LISTOVF = 31 /* a list region was too small (never) */, CTL_HIST = 32 /* upper bounds by kind */,
+                  CTL_ROUNDS = 64 /* (MAX_ROUNDS + 2) x KC_ACTIVE list lengths: round r reads [r], appends to [r + 1] */, FLAT_MAX_ROUNDS = 2048,
+                  CTL_WORDS = CTL_ROUNDS + (FLAT_MAX_ROUNDS + 2) * KC_ACTIVE };
+enum : uint32_t { FB_NOFIT = 0xFFFFFFFEu };   // fb[]: the function counted, but its place in a result array is beyond the array (the host runs again)
+struct FlatArgs {
+    uint32_t* st; uint32_t* ref; uint32_t* rvi; uint64_t* rt; uint64_t* cnt; uint8_t* tail;
+    uint16_t* pe; uint16_t* sz; uint16_t* cg; uint16_t* pa; uint16_t* wnext; uint16_t* whead;
+    uint32_t* fn_of;          // function index of every node of a function on the flat path, else NONE
+    FnInfo* fninfo; uint32_t* fb;      // per function: fb != 0 = declined (source line of the reason)
+    uint32_t* order;          // all nodes that are lowered, by kind class (regions CTL_OFF): the emit pass and the first round go through it
+    uint32_t* wl0; uint32_t* wl1;      // the ready lists of the rounds, same regions, used alternately
+    uint32_t* ctl;
+};
+
 enum { CTR_INSTR_BB = 0, CTR_VARS = 1, CTR_TYPES = 2, CTR_CARGS = 3, CTR_COUNT = 4, CTR_BB_SHIFT = 36 };
 struct Bases { uint32_t var_base, instr_base, bb_base, type_base, carg_base; bool fits; };
 // a function's place in the dense arrays (one lane)
@@ -103,7 +127,6 @@ __device__ __forceinline__ Bases bump_allocate(const ParArgs& A, uint32_t n_vars
     if (!b.fits) atomicMax(A.overflow, 1u);
     return b;
 }
-
 struct DefEnt { uint32_t hash, low, len, node, dpoint, send, var; uint32_t pad; Desc vt; };   // a local definition, visible to nodes of pre-order rank [dpoint, send); vt = type of its variable
 struct ArgEnt { uint32_t hash, low, len, pad; Desc vt; };
 enum { MAX_ARGS = 16, MAX_CALL_ARGS = 8 };
@@ -123,11 +146,6 @@ enum : uint8_t { TAIL_NONE = 0, TAIL_INSTR = 1, TAIL_TERM = 2, TAIL_NEWBB = 3 };
 struct Cnt4 { uint32_t v, t, i, b; };
 __device__ __forceinline__ uint64_t pack4(const Cnt4& c) { return (uint64_t)c.v | ((uint64_t)c.t << 16) | ((uint64_t)c.i << 32) | ((uint64_t)c.b << 48); }
 __device__ __forceinline__ Cnt4 unpack4(uint64_t w) { return Cnt4{(uint32_t)(w & 0xFFFF), (uint32_t)((w >> 16) & 0xFFFF), (uint32_t)((w >> 32) & 0xFFFF), (uint32_t)(w >> 48)}; }
-
-// The function being lowered: tables, LDS arrays, result bases.  Lives in registers (everything is inlined into the kernel).
-// The per-node arrays live in LDS.  Their pointers carry the address space in the type: 32-bit offsets instead of 64-bit generic
-// pointers (twenty of them were most of the kernel's scalar-register pressure: 1279 spilled SGPRs), and every access is a
-// ds_read / ds_write by construction, never a flat instruction that decides at run time where the address points.
 #ifdef OPUSFE_EMU
 #define LDS_AS
 #else
@@ -145,51 +163,66 @@ __device__ __forceinline__ uint32_t lds_sub(lds_u32* p, uint32_t v) { return __h
 __device__ __forceinline__ uint32_t lds_or(lds_u32* p, uint32_t v) { return __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ uint32_t lds_and(lds_u32* p, uint32_t v) { return __hip_atomic_fetch_and(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 #endif
+
+// ---- the function a lane works in (flat passes) ----------------------------------------------------------------------
+// Per-node arrays are unit-wide arrays in HBM seen through the function's first node (`base`): f.st[i] is the state word of the
+// function's i-th node, exactly as the visitor addressed its LDS arrays in round 2.  Links (first child, next sibling), kinds
+// and payloads are read from the parser's node records directly.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(OPUSFE_EMU)
+#define G_AS OPUSFE_GLOBAL
+#else
+#define G_AS
+#endif
+template <class T> struct GArr {
+    G_AS T* p; uint32_t base;
+    __device__ __forceinline__ G_AS T& operator[](uint32_t i) const { return p[base + i]; }
+};
+#define NONE16 0xFFFFu
+struct NodeKn {      // kind | sub << 8 | nchild << 16 (the first word of the node record)
+    const G_AS opusfe_node* p; uint32_t base;
+    __device__ __forceinline__ uint32_t operator[](uint32_t i) const { const G_AS opusfe_node* q = p + base + i; return (uint32_t)q->kind | ((uint32_t)q->sub << 8) | ((uint32_t)q->nchild << 16); }
+};
+struct NodeFc { const G_AS opusfe_node* p; uint32_t base; __device__ __forceinline__ uint32_t operator[](uint32_t i) const { const uint32_t v = p[base + i].first_child; return v == OPUSFE_NONE ? NONE16 : v - base; } };
+struct NodeNx { const G_AS opusfe_node* p; uint32_t base; __device__ __forceinline__ uint32_t operator[](uint32_t i) const { const uint32_t v = p[base + i].next; return v == OPUSFE_NONE ? NONE16 : v - base; } };
+struct NodePay { const G_AS opusfe_node* p; uint32_t base; __device__ __forceinline__ uint32_t operator[](uint32_t i) const { return p[base + i].payload; } };
 struct Fn {
     SemView S; ParArgs A;
-    uint32_t dn, nn, fidx, nargs; FuncRec F; uint64_t user_syms; uint32_t sym_mix /* file mix of symbol keys (sem.h NameKey) */;
-    // LDS
-    lds_u64* rt; lds_u64* cnt; lds_u32* kn; lds_u32* st; lds_u32* ref; lds_u32* rvi; lds_u32* pay;
-    lds_u16* fc; lds_u16* nx; lds_u16* pa; lds_u16* rk; lds_u16* sz; lds_u16* pe; lds_u16* cg; lds_u16* by_kind; lds_u8* tail;
-    DefEnt* defs; ArgEnt* args; lds_u32* misc; lds_u64* scratch;
+    uint32_t dn, nn, fidx, nargs, ret; uint64_t user_syms; uint32_t sym_mix /* file mix of symbol keys (sem.h NameKey) */;
+    bool fb, emitting; G_AS uint32_t* fbp;     // fb: this lane declined the function (fbp[fidx] tells the other lanes)
+    GArr<uint64_t> rt, cnt; GArr<uint32_t> st, ref, rvi; GArr<uint16_t> pe, sz, cg, pa; GArr<uint8_t> tail;
+    NodeKn kn; NodeFc fc; NodeNx nx; NodePay pay;
     // emit bases
     uint32_t var_base, instr_base, bb_base, type_base, carg_base, n_vars_tot, n_instrs_tot, n_bbs_tot, n_types_tot, n_cargs_tot;
-    uint32_t tid, nthreads;
 };
-enum { MI_FB = 0, MI_NDEFS = 1, MI_SUM_V = 2, MI_SUM_T = 3, MI_SUM_I = 4, MI_SUM_B = 5, MI_BAD = 6, MI_WHY = 7, MI_VBASE = 8, MI_IBASE = 9, MI_BBASE = 10, MI_TBASE = 11, MI_CBASE = 12, MI_FITS = 13, MI_NACTIVE = 14, MI_KHIST = 16 /* 16 words */, MI_WORDS = 32 };
-
-__host__ __device__ inline size_t lds_bytes(uint32_t nmax, uint32_t maxdef, uint32_t nthreads) {
-    size_t b = 0;
-    b += 8ull * nmax;            // rt
-    b += 8ull * 2 * nmax;        // cnt
-    b += 4ull * 5 * nmax;        // kn st ref rvi pay
-    b += 2ull * 8 * nmax;        // fc nx pa rk sz pe cg by_kind
-    b += 2ull * nmax;            // tail (2 per node)
-    b = (b + 7) & ~(size_t)7;
-    b += sizeof(DefEnt) * maxdef + sizeof(ArgEnt) * MAX_ARGS + 4 * MI_WORDS;
-    b = (b + 7) & ~(size_t)7;
-    b += 8ull * (nthreads + 1);   // scan scratch
-    return (b + 15) & ~(size_t)15;
-}
-
-#define NONE16 0xFFFFu
-// declines the function; the first reason (source line of the check) is kept for the fallback statistics
-__device__ __forceinline__ void fallback_at(Fn& f, uint32_t line) { if (!f.misc[MI_FB]) f.misc[MI_WHY] = line; f.misc[MI_FB] = 1; }
+#ifdef OPUSFE_EMU
+inline uint32_t at_or(uint32_t* p, uint32_t v) { const uint32_t o = *p; *p = o | v; return o; }
+inline uint32_t at_sub(uint32_t* p, uint32_t v) { const uint32_t o = *p; *p = o - v; return o; }
+inline uint32_t at_add(uint32_t* p, uint32_t v) { const uint32_t o = *p; *p = o + v; return o; }
+#else
+__device__ __forceinline__ uint32_t at_or(G_AS uint32_t* p, uint32_t v) { return __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t at_sub(G_AS uint32_t* p, uint32_t v) { return __hip_atomic_fetch_add(p, 0u - v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t at_add(G_AS uint32_t* p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#endif
+// the count and emit visits must agree, and nothing may be written outside a function's place: an internal error of the unit
+__device__ __forceinline__ void bad_at(const Fn& f, uint32_t line) { atomicMax(f.A.status, (uint32_t)DS_INTERNAL_CAPACITY); if (f.A.dbg) atomicMax(f.A.dbg, line); }
+#define inconsistent(f) bad_at(f, __LINE__)
+// declines the function; a reason (source line of the check) is kept for the fallback statistics
+__device__ __forceinline__ void fallback_at(Fn& f, uint32_t line) { f.fb = true; if (f.emitting) inconsistent(f); else f.fbp[f.fidx] = line; }
 #define fallback(f) fallback_at(f, __LINE__)
-__device__ __forceinline__ bool failed(const Fn& f) { return f.misc[MI_FB] != 0; }
-__device__ __forceinline__ opusfe_node ND(const Fn& f, uint32_t i) { return f.S.nodes[f.dn + i]; }
-__device__ __forceinline__ uint8_t KIND(const Fn& f, uint32_t i) { return (uint8_t)f.kn[i]; }
-__device__ __forceinline__ uint8_t SUB(const Fn& f, uint32_t i) { return (uint8_t)(f.kn[i] >> 8); }
-__device__ __forceinline__ uint32_t NCH(const Fn& f, uint32_t i) { return f.kn[i] >> 16; }
-__device__ __forceinline__ uint32_t POS_ENTER(const Fn& f, uint32_t i) { return f.pe[i]; }
-__device__ __forceinline__ uint32_t POS_EXIT(const Fn& f, uint32_t i) { return (uint32_t)f.pe[i] + 2u * (uint32_t)f.sz[i] - 1u; }
+__device__ __forceinline__ bool failed(const Fn& f) { return f.fb; }
+
+template <class F> __device__ __forceinline__ uint8_t KIND(const F& f, uint32_t i) { return (uint8_t)f.kn[i]; }
+template <class F> __device__ __forceinline__ uint8_t SUB(const F& f, uint32_t i) { return (uint8_t)(f.kn[i] >> 8); }
+template <class F> __device__ __forceinline__ uint32_t NCH(const F& f, uint32_t i) { return f.kn[i] >> 16; }
+template <class F> __device__ __forceinline__ uint32_t POS_ENTER(const F& f, uint32_t i) { return f.pe[i]; }
+template <class F> __device__ __forceinline__ uint32_t POS_EXIT(const F& f, uint32_t i) { return (uint32_t)f.pe[i] + 2u * (uint32_t)f.sz[i] - 1u; }
 // pre-order rank of a node, and of the first node behind its subtree (nodes are stored in creation order, not pre-order)
-__device__ __forceinline__ uint32_t RANK(const Fn& f, uint32_t i) { return f.rk[i]; }
-__device__ __forceinline__ uint32_t RANK_END(const Fn& f, uint32_t i) { return (uint32_t)f.rk[i] + f.sz[i]; }
-__device__ __forceinline__ uint32_t child_at(const Fn& f, uint32_t i, uint32_t k) { uint32_t c = f.fc[i]; while (k-- && c != NONE16) c = f.nx[c]; return c; }
-__device__ __forceinline__ uint32_t last_child(const Fn& f, uint32_t i) { uint32_t c = f.fc[i], l = NONE16; while (c != NONE16) { l = c; c = f.nx[c]; } return l; }
+template <class F> __device__ __forceinline__ uint32_t RANK(const F& f, uint32_t i) { return f.rk[i]; }
+template <class F> __device__ __forceinline__ uint32_t RANK_END(const F& f, uint32_t i) { return (uint32_t)f.rk[i] + f.sz[i]; }
+template <class F> __device__ __forceinline__ uint32_t child_at(const F& f, uint32_t i, uint32_t k) { uint32_t c = f.fc[i]; while (k-- && c != NONE16) c = f.nx[c]; return c; }
+template <class F> __device__ __forceinline__ uint32_t last_child(const F& f, uint32_t i) { uint32_t c = f.fc[i], l = NONE16; while (c != NONE16) { l = c; c = f.nx[c]; } return l; }
 // global type id of a parse-tree type node of this function
-__device__ __forceinline__ uint32_t TID(const Fn& f, uint32_t local_node) { return f.ref[local_node]; }      // (type nodes keep their resolved id in ref[], loaded with the node)
+template <class F> __device__ __forceinline__ uint32_t TID(const F& f, uint32_t local_node) { return f.ref[local_node]; }      // (type nodes keep their resolved id in ref[], loaded with the node)
 
 // ---- views of a type ------------------------------------------------------------------------------------------------
 struct TView { uint8_t kind, ptr; bool plain; Desc sub; TypeRec rec; };
@@ -209,7 +242,7 @@ __device__ __forceinline__ TView view(const Fn& f, Desc d) {
     return v;
 }
 // pointer to `sub` (type_pointer, compile.rs:563-589); pointers to primitives are pre-made ids
-__device__ __forceinline__ Desc d_ptr(Fn& f, uint32_t pt, Desc sub) {
+template <class F> __device__ __forceinline__ Desc d_ptr(F& f, uint32_t pt, Desc sub) {
     if (sub == DESC_NONE) return DESC_NONE;
     if (d_plain(sub) && d_base(sub) < TP_COUNT) return d_id(f.A.pp_base + pt * TP_COUNT + d_base(sub));
     const uint32_t nw = d_nw(sub);
@@ -310,7 +343,7 @@ template <bool EMIT> struct Em {
     uint32_t v, t, i, b; uint8_t tail; uint32_t pos;
     __device__ __forceinline__ uint32_t emit_type(Fn& f, const TypeRec& r) {
         const uint32_t id = f.S.n_gtypes + f.type_base + t;
-        if (EMIT) { if (t < f.n_types_tot) gst(f.A.types_out + id, r); else f.misc[MI_BAD] = 1; }
+        if (EMIT) { if (t < f.n_types_tot) gst(f.A.types_out + id, r); else inconsistent(f); }
         t++;
         return id;
     }
@@ -325,19 +358,19 @@ template <bool EMIT> struct Em {
     __device__ __forceinline__ uint32_t newvar(Fn& f, Desc ty, bool temp) {
         if (ty == DESC_NONE) { fallback(f); ty = d_id(TP_Error); }
         const uint32_t tid = type_id(f, ty);
-        if (EMIT) { if (v < f.n_vars_tot) gst(f.A.vars + f.var_base + v, opusfe_variable{tid, temp ? 1u : 0u}); else f.misc[MI_BAD] = 1; }
+        if (EMIT) { if (v < f.n_vars_tot) gst(f.A.vars + f.var_base + v, opusfe_variable{tid, temp ? 1u : 0u}); else inconsistent(f); }
         return v++;
     }
     __device__ __forceinline__ void ins(Fn& f, uint16_t op, uint32_t dst = 0, uint32_t a = 0, uint32_t b_ = 0, uint32_t c = 0, uint32_t extra = 0, uint16_t sub = 0) {
         if (EMIT) {
             opusfe_instr in; in.opcode = op; in.sub = sub; in.dst = dst; in.a = a; in.b = b_; in.c = c; in.extra = extra;
-            if (i < f.n_instrs_tot) gst(f.A.instrs + f.instr_base + i, in); else f.misc[MI_BAD] = 1;
+            if (i < f.n_instrs_tot) gst(f.A.instrs + f.instr_base + i, in); else inconsistent(f);
         }
         i++;
         tail = (op == I_Return || op == I_Jump || op == I_Branch || op == I_Unreachable) ? TAIL_TERM : TAIL_INSTR;
     }
     __device__ __forceinline__ uint32_t newbb(Fn& f) {
-        if (EMIT) { if (b < f.n_bbs_tot) gst(f.A.bb_offsets + f.bb_base + b, f.instr_base + i); else f.misc[MI_BAD] = 1; }
+        if (EMIT) { if (b < f.n_bbs_tot) gst(f.A.bb_offsets + f.bb_base + b, f.instr_base + i); else inconsistent(f); }
         tail = TAIL_NEWBB;
         return b++;
     }
@@ -359,28 +392,15 @@ template <bool EMIT> __device__ __forceinline__ void close_slot(Fn& f, const Em<
 __device__ __forceinline__ uint32_t bb_at(const Fn& f, uint32_t pos) { return unpack4(f.cnt[pos]).b; }
 
 // ---- names --------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool bytes_eq(const Fn& f, uint32_t lo1, uint32_t lo2, uint32_t len) {
+__device__ __forceinline__ bool bytes_eq(const SemView& S, uint32_t lo1, uint32_t lo2, uint32_t len) {
     if (lo1 == lo2) return true;
-    for (uint32_t k = 0; k < len; k++) if (f.S.src[lo1 + k] != f.S.src[lo2 + k]) return false;
+    for (uint32_t k = 0; k < len; k++) if (S.src[lo1 + k] != S.src[lo2 + k]) return false;
     return true;
 }
-// definition of identifier token `t` visible at node `use`: RF_LOCAL | index, RF_ARG | index, or RF_NONE
-__device__ __forceinline__ uint32_t find_local(const Fn& f, const opusfe_token& t, uint32_t use_node) {
-    const uint32_t nd = f.misc[MI_NDEFS], use = RANK(f, use_node);
-    for (uint32_t k = 0; k < nd; k++) {
-        const DefEnt& d = f.defs[k];
-        if (d.hash == t.payload && d.len == t.len && d.dpoint <= use && use < d.send && bytes_eq(f, d.low, t.low, t.len)) return RF_LOCAL | k;
-    }
-    for (uint32_t k = 0; k < f.nargs; k++) {
-        const ArgEnt& a = f.args[k];
-        if (a.hash == t.payload && a.len == t.len && bytes_eq(f, a.low, t.low, t.len)) return RF_ARG | k;
-    }
-    return RF_NONE;
-}
-__device__ __forceinline__ bool slot_has_functions(const Fn& f, uint32_t slot) {
+__device__ __forceinline__ bool slot_has_functions(const SemView& S, uint32_t slot) {
     if (slot == OPUSFE_NONE) return false;
-    const NameSlot sl = f.S.slots[slot];
-    for (uint32_t j = 0; j < sl.count; j++) if ((f.S.entries[sl.offset + j].kind_index >> 30) == NK_FUNCTION) return true;
+    const NameSlot sl = S.slots[slot];
+    for (uint32_t j = 0; j < sl.count; j++) if ((S.entries[sl.offset + j].kind_index >> 30) == NK_FUNCTION) return true;
     return false;
 }
 
@@ -408,7 +428,7 @@ __device__ __forceinline__ uint32_t lookup_function(Fn& f, NameKey name, const D
     if (n > MAX_CALL_ARGS) { fallback(f); return FN_NONE; }
     const uint32_t slot = name_find(f.S, name);
     const uint32_t nb = sym != T_Identifier ? (uint32_t)builtin_count(sym) : 0u;
-    const bool has_user = slot_has_functions(f, slot);
+    const bool has_user = slot_has_functions(f.S, slot);
     if (nb == 0 && !has_user) { fallback(f); return FN_NONE; }                      // UndefinedFunction
     const NameSlot sl = slot != OPUSFE_NONE ? f.S.slots[slot] : NameSlot{OPUSFE_NONE, 0, 0, 0};
     const uint32_t total = nb + sl.count;
@@ -552,7 +572,7 @@ __device__ __forceinline__ uint32_t record_field(const Fn& f, const TypeRec& rec
     for (uint32_t k = 0; k < n && c != OPUSFE_NONE; k++) {
         const opusfe_node m = f.S.nodes[c];
         const opusfe_token t = f.S.tok[m.payload];
-        if (t.kind == name.kind && (t.kind != T_Identifier || (t.payload == name.payload && t.len == name.len && bytes_eq(f, t.low, name.low, t.len)))) return f.S.tid_of_node[m.first_child];
+        if (t.kind == name.kind && (t.kind != T_Identifier || (t.payload == name.payload && t.len == name.len && bytes_eq(f.S, t.low, name.low, t.len)))) return f.S.tid_of_node[m.first_child];
         c = m.next;
     }
     return OPUSFE_NONE;
@@ -596,7 +616,7 @@ __device__ __forceinline__ Desc expected_of(Fn& f, uint32_t i, bool* ready) {
     switch (exp) {
         case EXP_GENINT: return d_id(TP_GenericInteger);
         case EXP_BOOL: return d_id(TP_Bool);
-        case EXP_RET: return d_id(f.F.ret);
+        case EXP_RET: return d_id(f.ret);
         case EXP_SIZE: return d_id(TP_Size);
         case EXP_ASSIGN: case EXP_FIELD: case EXP_ARG: {
             uint32_t a = f.pa[i];
@@ -620,7 +640,7 @@ __device__ __forceinline__ Desc expected_of(Fn& f, uint32_t i, bool* ready) {
 }
 
 // the loop a `break` / `continue` at node i belongs to (generate_ir.rs:327-331, 432-436: the loop target is set for the then-block only)
-__device__ __forceinline__ uint32_t enclosing_loop(const Fn& f, uint32_t i) {
+template <class F> __device__ __forceinline__ uint32_t enclosing_loop(const F& f, uint32_t i) {
     uint32_t c = i, a = f.pa[i];
     while (a != NONE16) {
         const uint8_t k = KIND(f, a);
@@ -631,7 +651,7 @@ __device__ __forceinline__ uint32_t enclosing_loop(const Fn& f, uint32_t i) {
     return NONE16;
 }
 // then-block and else-block (or NONE16) of an if / while / for node
-__device__ __forceinline__ void blocks_of(const Fn& f, uint32_t s, uint32_t* cond, uint32_t* then_b, uint32_t* else_b) {
+template <class F> __device__ __forceinline__ void blocks_of(const F& f, uint32_t s, uint32_t* cond, uint32_t* then_b, uint32_t* else_b) {
     uint32_t c = f.fc[s];
     if (KIND(f, s) == S_For && SUB(f, s)) c = f.nx[c];
     *cond = c; *then_b = f.nx[c]; *else_b = f.nx[*then_b];
@@ -663,16 +683,9 @@ __device__ __forceinline__ Desc for_variable_type(Fn& f, uint32_t i) {
     return d_id(fn_arg_type(f, cf, 1));
 }
 
-// Are all operands of node i typed?  (A node is lowered in the sweep after its last operand.)
-__device__ __forceinline__ bool operands_done(const Fn& f, uint32_t i) {
-    const uint8_t k = KIND(f, i);
-    if (k == E_Operator && SUB(f, i) == OP_Not) return (f.st[f.nx[f.fc[i]]] & ST_DONE) != 0;
-    for (uint32_t c = f.fc[i]; c != NONE16; c = f.nx[c]) if (!(f.st[c] & (ST_DONE | ST_DEAD))) return false;
-    return true;
-}
-
 // Lowers node i: all events it owns.  Returns false when an input is not ready yet (count pass only).
-template <bool EMIT> __device__ __forceinline__ bool visit(Fn& f, uint32_t i) {
+template <int C> __device__ __forceinline__ constexpr bool has_class(int c) { return C == KC_ANY || C == c; }
+template <bool EMIT, int C> __device__ __forceinline__ bool visit(Fn& f, uint32_t i) {
     const uint32_t st = f.st[i];
     const uint8_t kind = KIND(f, i);
     const uint32_t mode = st & ST_MODE_MASK;
@@ -680,15 +693,15 @@ template <bool EMIT> __device__ __forceinline__ bool visit(Fn& f, uint32_t i) {
     // ---- statements, blocks, the function itself ----
     if (mode == 0) {
         switch (kind) {
-            case D_Function: {
+            case D_Function: { if (!has_class<C>(KC_CONTROL)) return true;
                 // prologue (generate_ir.rs:133-149) at ENTER; epilogue (:151-171) after the body
                 const uint32_t body = last_child(f, i);
                 Em<EMIT> e = open_slot<EMIT>(f, POS_ENTER(f, i));
                 e.newbb(f);
-                for (uint32_t k = 0; k < f.nargs; k++) e.newvar(f, pointee(f, f.args[k].vt), true);
-                for (uint32_t k = 0; k < f.nargs; k++) { const uint32_t v = e.newvar(f, f.args[k].vt, false); e.ins(f, I_Allocate, v); e.ins(f, I_Store, 0, v, k); }
+                { uint32_t a = f.fc[i]; for (uint32_t k = 0; k < f.nargs && a != NONE16; k++, a = f.nx[a]) e.newvar(f, pointee(f, f.rt[a]), true); }
+                { uint32_t a = f.fc[i]; for (uint32_t k = 0; k < f.nargs && a != NONE16; k++, a = f.nx[a]) { const uint32_t v = e.newvar(f, f.rt[a], false); e.ins(f, I_Allocate, v); e.ins(f, I_Store, 0, v, k); } }
                 close_slot(f, e);
-                const bool returns_null = view(f, d_id(f.F.ret)).kind == TY_Null;
+                const bool returns_null = view(f, d_id(f.ret)).kind == TY_Null;
                 const bool rdiv = (f.st[body] & ST_DIV) != 0;
                 if (!(rdiv || returns_null)) { fallback(f); return true; }             // FunctionMightNotReturn
                 // last thing emitted before this point: an instruction (which?) or a new block
@@ -703,14 +716,14 @@ template <bool EMIT> __device__ __forceinline__ bool visit(Fn& f, uint32_t i) {
                 close_slot(f, x);
                 return true;
             }
-            case X_Block: {
+            case X_Block: { if (!has_class<C>(KC_CONTROL)) return true;
                 uint32_t div = 0;
                 for (uint32_t c = f.fc[i]; c != NONE16; c = f.nx[c]) div |= f.st[c] & ST_DIV;
                 if (!EMIT) f.st[i] |= div;
                 return true;
             }
             case S_Expression: return true;
-            case S_VariableDefinition: {   // :252-264
+            case S_VariableDefinition: { if (!has_class<C>(KC_STATEMENT)) return true;   // :252-264
                 const uint32_t c = f.fc[i];
                 Em<EMIT> e = open_slot<EMIT>(f, POS_EXIT(f, c));
                 const Desc t = f.rt[c];
@@ -721,10 +734,10 @@ template <bool EMIT> __device__ __forceinline__ bool visit(Fn& f, uint32_t i) {
                 e.ins(f, I_Allocate, nv);
                 e.ins(f, I_Store, 0, nv, RV<EMIT>(f, c));
                 close_slot(f, e);
-                if (!EMIT) { DefEnt& d = f.defs[f.ref[i]]; d.vt = vt; d.var = info; }
+                if (!EMIT) { f.rt[i] = vt; f.rvi[i] = info; }      // (the statement node is the slot of its definition)
                 return true;
             }
-            case S_Assignment: {           // :265-274
+            case S_Assignment: { if (!has_class<C>(KC_STATEMENT)) return true;           // :265-274
                 const uint32_t l = f.fc[i], r = f.nx[l];
                 Em<EMIT> e = open_slot<EMIT>(f, POS_EXIT(f, r));
                 const Desc T = pointee(f, f.rt[l]);
@@ -734,16 +747,16 @@ template <bool EMIT> __device__ __forceinline__ bool visit(Fn& f, uint32_t i) {
                 close_slot(f, e);
                 return true;
             }
-            case S_Return: {               // :275-283
+            case S_Return: { if (!has_class<C>(KC_STATEMENT)) return true;               // :275-283
                 const uint32_t c = f.fc[i];
                 Em<EMIT> e = open_slot<EMIT>(f, POS_EXIT(f, c));
-                Val<EMIT> fin = autocast<EMIT>(f, e, child_val<EMIT>(f, c), c, d_id(f.F.ret));
+                Val<EMIT> fin = autocast<EMIT>(f, e, child_val<EMIT>(f, c), c, d_id(f.ret));
                 e.ins(f, I_Return, 0, fin.var);
                 close_slot(f, e);
                 if (!EMIT) f.st[i] |= ST_DIV;
                 return true;
             }
-            case S_If: case S_While: case S_For: {
+            case S_If: case S_While: case S_For: { if (!has_class<C>(KC_CONTROL)) return true;
                 uint32_t cond, tb, eb; blocks_of(f, i, &cond, &tb, &eb);
                 if (tb == NONE16) { fallback(f); return true; }
                 uint32_t loop_bb = 0;
@@ -789,7 +802,7 @@ template <bool EMIT> __device__ __forceinline__ bool visit(Fn& f, uint32_t i) {
                     }
                     const uint32_t iteration_variable = e.newvar(f, pointer_type, false);
                     e.ins(f, I_Allocate, iteration_variable);
-                    if (!EMIT) { DefEnt& d = f.defs[f.ref[i]]; d.vt = pointer_type; d.var = info; }
+                    if (!EMIT) { f.rt[i] = pointer_type; f.rvi[i] = info; }
                     const uint32_t cont_fn = e.newvar(f, d_func(cf), true);
                     e.ins(f, I_Function, cont_fn, 0, 0, cf);
                     Val<EMIT> a0; a0.var = iterator_variable; a0.t = iter_t; a0.info = 0;
@@ -832,7 +845,7 @@ template <bool EMIT> __device__ __forceinline__ bool visit(Fn& f, uint32_t i) {
                 }
                 return true;
             }
-            case S_Break: case S_Continue: {   // :470-489
+            case S_Break: case S_Continue: { if (!has_class<C>(KC_CONTROL)) return true;   // :470-489
                 const uint32_t loop = f.ref[i];
                 if (loop == NONE16) { fallback(f); return true; }
                 Em<EMIT> e = open_slot<EMIT>(f, POS_ENTER(f, i));
@@ -849,7 +862,7 @@ template <bool EMIT> __device__ __forceinline__ bool visit(Fn& f, uint32_t i) {
     // ---- expressions ----
     if (mode == ST_MODE_E) {
         switch (kind) {
-            case E_Integer: {
+            case E_Integer: { if (!has_class<C>(KC_INTEGER)) return true;
                 // ref[i] = the token's aux word (suffix) | the final type + 1 of the variable << 24 once an autocast retyped it
                 const uint32_t aux = f.ref[i] & 0xFFFF;
                 Desc typ;
@@ -889,7 +902,7 @@ template <bool EMIT> __device__ __forceinline__ bool visit(Fn& f, uint32_t i) {
                 set_result<EMIT>(f, i, o);
                 return true;
             }
-            case E_Float: case E_Null: case E_Bool: case E_String: {
+            case E_Float: case E_Null: case E_Bool: case E_String: { if (!has_class<C>(KC_SIMPLE)) return true;
                 Em<EMIT> e = open_slot<EMIT>(f, POS_ENTER(f, i));
                 Val<EMIT> o; o.info = own_rv(e.pos, e.v);
                 if (kind == E_Float) {
@@ -905,7 +918,7 @@ template <bool EMIT> __device__ __forceinline__ bool visit(Fn& f, uint32_t i) {
                 set_result<EMIT>(f, i, o);
                 return true;
             }
-            case E_Operator: {
+            case E_Operator: { if (!has_class<C>(KC_OPERATOR)) return true;
                 const uint32_t l = f.fc[i], r = f.nx[l];
                 const uint8_t op = SUB(f, i);
                 if (op == OP_Is) {       // :616-634: pointer identity; anything else is InvalidOperandTypes (sequential machine)
@@ -979,7 +992,7 @@ template <bool EMIT> __device__ __forceinline__ bool visit(Fn& f, uint32_t i) {
                 set_result<EMIT>(f, i, o);
                 return true;
             }
-            case E_Cast: {                   // :720-732
+            case E_Cast: { if (!has_class<C>(KC_OTHER)) return true;                   // :720-732
                 const uint32_t c = f.fc[i], ty = f.nx[c];
                 Em<EMIT> e = open_slot<EMIT>(f, POS_EXIT(f, ty));
                 const Desc typ = d_id(TID(f, ty));
@@ -992,12 +1005,12 @@ template <bool EMIT> __device__ __forceinline__ bool visit(Fn& f, uint32_t i) {
                 set_result<EMIT>(f, i, o);
                 return true;
             }
-            case E_Reference: case E_MutableReference: case E_ArrayReference: case E_MutableArrayReference: {   // :733-748: the child's pointer itself
+            case E_Reference: case E_MutableReference: case E_ArrayReference: case E_MutableArrayReference: { if (!has_class<C>(KC_OTHER)) return true;   // :733-748: the child's pointer itself
                 Val<EMIT> o = child_val<EMIT>(f, f.fc[i]);
                 set_result<EMIT>(f, i, o);
                 return true;
             }
-            case E_Negate: {                 // :749-789
+            case E_Negate: { if (!has_class<C>(KC_SIMPLE)) return true;                 // :749-789
                 const uint32_t c = f.fc[i];
                 const Desc stp = f.rt[c];
                 const uint8_t k = view(f, stp).kind;
@@ -1015,7 +1028,7 @@ template <bool EMIT> __device__ __forceinline__ bool visit(Fn& f, uint32_t i) {
                 } else fallback(f);
                 return true;
             }
-            case E_Sizeof: case E_Alignof: {  // :790-801
+            case E_Sizeof: case E_Alignof: { if (!has_class<C>(KC_OTHER)) return true;  // :790-801
                 Em<EMIT> e = open_slot<EMIT>(f, POS_ENTER(f, i));
                 Val<EMIT> o; o.t = d_id(TP_Size); o.info = own_rv(e.pos, e.v);
                 o.var = e.newvar(f, o.t, true);
@@ -1030,17 +1043,17 @@ template <bool EMIT> __device__ __forceinline__ bool visit(Fn& f, uint32_t i) {
     }
     // ---- pointers / lvalues (try_generate_pointer_from_expression :985-1088) ----
     switch (kind) {
-        case E_Variable: {
+        case E_Variable: { if (!has_class<C>(KC_VARIABLE)) return true;
             const uint32_t r = f.ref[i], tag = r & RF_TAG, idx = r & RF_VAL;
             Em<EMIT> e = open_slot<EMIT>(f, POS_ENTER(f, i));
             Val<EMIT> v{}; bool lv = true;
             if (tag == RF_LOCAL) {
-                const DefEnt& d = f.defs[idx];
-                if (!EMIT && d.vt == DESC_NONE) return false;   // its type is not known yet
-                v.t = d.vt; v.info = RV_LOCAL | idx; v.var = EMIT ? d.var : 0u;
+                const Desc dvt = f.rt[idx];                      // idx = the slot node of the definition
+                if (!EMIT && dvt == DESC_NONE) return false;    // its type is not known yet (the scheduler never lets this happen)
+                v.t = dvt; v.info = RV_LOCAL | idx; v.var = EMIT ? (f.rvi[idx] & RV_VAL) : 0u;
                 v = try_cast_pointer<EMIT>(f, e, v, pt);
             } else if (tag == RF_ARG) {
-                v.t = f.args[idx].vt; v.info = RV_ARG | idx; v.var = f.nargs + idx;
+                v.t = f.rt[idx >> 4]; v.info = RV_ARG | (idx & 15u); v.var = f.nargs + (idx & 15u);      // idx = argument number | its X_NamedType node << 4
                 v = try_cast_pointer<EMIT>(f, e, v, pt);
             } else if (tag == RF_GLOBAL) {
                 v.t = d_ptr(f, PT_Mutable, EMIT ? d_id(f.S.globals[idx].type_id) : f.rt[i]);
@@ -1067,11 +1080,12 @@ template <bool EMIT> __device__ __forceinline__ bool visit(Fn& f, uint32_t i) {
             set_result<EMIT>(f, i, v);
             return true;
         }
-        case E_VariableDefinition: {         // :1008-1021
+        case E_VariableDefinition: { if (!has_class<C>(KC_OTHER)) return true;         // :1008-1021
             Em<EMIT> e = open_slot<EMIT>(f, POS_EXIT(f, f.fc[i]));
-            Val<EMIT> v; v.t = f.defs[f.ref[i]].vt; v.info = own_rv(e.pos, e.v);
+            const uint32_t slot = f.fc[i];            // (the type node is the slot of this definition)
+            Val<EMIT> v; v.t = f.rt[slot]; v.info = own_rv(e.pos, e.v);
             v.var = e.newvar(f, v.t, false);
-            if (!EMIT) f.defs[f.ref[i]].var = v.info;
+            if (!EMIT) f.rvi[slot] = v.info;
             e.ins(f, I_Allocate, v.var);
             v = try_cast_pointer<EMIT>(f, e, v, pt);
             if (failed(f)) return true;
@@ -1080,7 +1094,7 @@ template <bool EMIT> __device__ __forceinline__ bool visit(Fn& f, uint32_t i) {
             set_result<EMIT>(f, i, v);
             return true;
         }
-        case E_Dereference: {                // :1022-1026
+        case E_Dereference: { if (!has_class<C>(KC_OTHER)) return true;                // :1022-1026
             const uint32_t c = f.fc[i];
             Em<EMIT> e = open_slot<EMIT>(f, POS_EXIT(f, c));
             Val<EMIT> v = try_cast_pointer<EMIT>(f, e, child_val<EMIT>(f, c), pt);
@@ -1090,7 +1104,7 @@ template <bool EMIT> __device__ __forceinline__ bool visit(Fn& f, uint32_t i) {
             set_result<EMIT>(f, i, v);
             return true;
         }
-        case E_Field: {                      // :1027-1030
+        case E_Field: { if (!has_class<C>(KC_OTHER)) return true;                      // :1027-1030
             const uint32_t c = f.fc[i];
             Em<EMIT> e = open_slot<EMIT>(f, POS_EXIT(f, c));
             Val<EMIT> v = field_access<EMIT>(f, e, child_val<EMIT>(f, c), f.pay[i], pt);
@@ -1100,7 +1114,7 @@ template <bool EMIT> __device__ __forceinline__ bool visit(Fn& f, uint32_t i) {
             set_result<EMIT>(f, i, v);
             return true;
         }
-        case E_NamedCall: {
+        case E_NamedCall: { if (!has_class<C>(KC_CALL)) return true;
             const uint32_t r = f.ref[i], tag = r & RF_TAG, idx = r & RF_VAL;
             const uint32_t n = NCH(f, i);
             const uint32_t lastc = last_child(f, i);
@@ -1152,10 +1166,10 @@ template <bool EMIT> __device__ __forceinline__ bool visit(Fn& f, uint32_t i) {
             Em<EMIT> e = open_slot<EMIT>(f, POS_ENTER(f, i));
             Val<EMIT> v{};
             if (tag == RF_LOCAL) {
-                const DefEnt& d = f.defs[idx];
-                if (!EMIT && d.vt == DESC_NONE) return false;
-                v.t = d.vt; v.var = EMIT ? d.var : 0u;
-            } else if (tag == RF_ARG) { v.t = f.args[idx].vt; v.var = f.nargs + idx; }
+                const Desc dvt = f.rt[idx];
+                if (!EMIT && dvt == DESC_NONE) return false;
+                v.t = dvt; v.var = EMIT ? (f.rvi[idx] & RV_VAL) : 0u;
+            } else if (tag == RF_ARG) { v.t = f.rt[idx >> 4]; v.var = f.nargs + (idx & 15u); }
             else if (tag == RF_GLOBAL) { v.t = d_ptr(f, PT_Mutable, EMIT ? d_id(f.S.globals[idx].type_id) : f.rt[i]); v.var = e.newvar(f, v.t, true); e.ins(f, I_GlobalVariable, v.var, 0, 0, idx); }
             else { fallback(f); return true; }
             v = try_cast_pointer<EMIT>(f, e, v, pt);
@@ -1186,7 +1200,7 @@ template <bool EMIT> __device__ __forceinline__ bool visit(Fn& f, uint32_t i) {
             set_result<EMIT>(f, i, o);
             return true;
         }
-        case E_Record: {                     // :1064-1078
+        case E_Record: { if (!has_class<C>(KC_OTHER)) return true;                     // :1064-1078
             const uint32_t tyn = f.fc[i];
             Em<EMIT> e = open_slot<EMIT>(f, POS_EXIT(f, tyn));
             const Desc rec_t = d_id(TID(f, tyn));
@@ -1216,59 +1230,364 @@ template <bool EMIT> __device__ __forceinline__ bool visit(Fn& f, uint32_t i) {
     }
 }
 
-// Kind class of a node: neighbouring lanes lower the same kind of node (the visitor is one big switch and a wave pays for
-// every case any of its lanes takes).  Class 15: nothing to lower (type nodes, carriers, dead code).
-enum { KC_COUNT = 16, KC_NONE = 15 };
-__device__ __forceinline__ uint32_t kind_class(const Fn& f, uint32_t i) {
-    const uint32_t s = f.st[i];
-    const uint8_t k = KIND(f, i);
+// ---- kind classes ---------------------------------------------------------------------------------------------------------
+// class of a node from its state word and kind (the visitor is one big switch; every class kernel holds only its cases)
+__host__ __device__ __forceinline__ uint32_t kind_class_of(uint32_t s, uint8_t k) {
     if (s & ST_DEAD) return KC_NONE;
     if ((s & ST_MODE_MASK) == 0) {
-        if (k == S_Expression || k == S_Assignment || k == S_VariableDefinition || k == S_Return) return 4;
-        if (k == S_If || k == S_While || k == S_For || k == S_Break || k == S_Continue || k == X_Block || k == D_Function || k == X_FieldInit) return 5;   // (a field initialiser waits for its value)
+        if (k == S_Expression || k == S_Assignment || k == S_VariableDefinition || k == S_Return) return KC_STATEMENT;
+        if (k == S_If || k == S_While || k == S_For || k == S_Break || k == S_Continue || k == X_Block || k == D_Function || k == X_FieldInit) return KC_CONTROL;   // (a field initialiser waits for its value)
         return KC_NONE;
     }
-    if (k == E_Variable) return 0;
-    if (k == E_Integer) return 1;
-    if (k == E_Operator) return 2;
-    if (k == E_Parentheses || k == E_Negate || k == E_Float || k == E_Bool || k == E_Null || k == E_String) return 3;
-    if (k == E_NamedCall) return 6;
-    return 7;
+    if (k == E_Variable) return KC_VARIABLE;
+    if (k == E_Integer) return KC_INTEGER;
+    if (k == E_Operator) return KC_OPERATOR;
+    if (k == E_Parentheses || k == E_Negate || k == E_Float || k == E_Bool || k == E_Null || k == E_String) return KC_SIMPLE;
+    if (k == E_NamedCall) return KC_CALL;
+    return KC_OTHER;
+}
+// upper bound of the same from the kind alone (sizes of the list regions); S_For can be listed twice in one round (stage 1, visit)
+__host__ __device__ __forceinline__ uint32_t kind_class_bound(uint8_t k) {
+    if (k == S_Expression || k == S_Assignment || k == S_VariableDefinition || k == S_Return) return KC_STATEMENT;
+    if (k == S_If || k == S_While || k == S_For || k == S_Break || k == S_Continue || k == X_Block || k == D_Function || k == X_FieldInit) return KC_CONTROL;
+    if (k < E_Integer || k > E_Parentheses) return KC_NONE;
+    return kind_class_of(ST_MODE_E, k);
+}
+__global__ void k_flat_kind_hist(const opusfe_node* __restrict__ nodes, uint32_t n_nodes, uint32_t* __restrict__ ctl) {
+#ifdef OPUSFE_EMU
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_nodes) return;
+    const uint8_t k = nodes[g].kind; const uint32_t c = kind_class_bound(k);
+    if (c < KC_ACTIVE) ctl[CTL_HIST + c] += k == S_For ? 2u : 1u;
+#else
+    __shared__ uint32_t h[KC_ACTIVE];
+    if (threadIdx.x < KC_ACTIVE) h[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_nodes; g += (uint64_t)gridDim.x * blockDim.x) {
+        const uint8_t k = nodes[g].kind; const uint32_t c = kind_class_bound(k);
+        if (c < KC_ACTIVE) atomicAdd(&h[c], k == S_For ? 2u : 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < KC_ACTIVE && h[threadIdx.x]) atomicAdd(ctl + CTL_HIST + threadIdx.x, h[threadIdx.x]);
+#endif
+}
+__global__ void k_flat_offsets(uint32_t* __restrict__ ctl) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    uint32_t run = 0;
+    for (uint32_t c = 0; c < KC_ACTIVE; c++) { ctl[CTL_OFF + c] = run; run += (ctl[CTL_HIST + c] + 63u) & ~63u; }
+    ctl[CTL_OFF + KC_ACTIVE] = run;
 }
 
-// ---- block-wide exclusive scan of an LDS array (packed event counters; call-argument counts); returns the total -------
-template <class E, class P> __device__ __forceinline__ uint64_t block_scan(Fn& f, P a, uint32_t n) {
-    const uint32_t T = f.nthreads, per = (n + T - 1) / T;
-    const uint32_t lo = f.tid * per < n ? f.tid * per : n, hi = lo + per < n ? lo + per : n;
-    uint64_t sum = 0;
-    for (uint32_t k = lo; k < hi; k++) sum += a[k];
-    PAR_SYNC();
-    f.scratch[f.tid] = sum;
-    PAR_SYNC();
+// ---- the lane's function ----------------------------------------------------------------------------------------------------
+// false: the function is off the flat path (declined by an earlier visit)
+__device__ __forceinline__ bool make_fn(Fn& f, const SemView& S, const ParArgs& A, const FlatArgs& X, uint32_t g, uint32_t* local, bool emitting) {
+    const uint32_t fidx = gld(X.fn_of + g);
+    if (fidx == OPUSFE_NONE) return false;                   // (a node of a function that was declined while it was being listed)
+    const FnInfo I = gld(X.fninfo + fidx);
+    f.S = S; f.A = A; f.dn = I.dn; f.nn = I.nn; f.fidx = fidx; f.nargs = I.nargs; f.ret = I.ret; f.sym_mix = I.sym_mix; f.user_syms = *A.user_syms;
+    f.fb = false; f.emitting = emitting; f.fbp = (G_AS uint32_t*)X.fb;
+    const uint32_t dn = I.dn;
+    f.rt = GArr<uint64_t>{(G_AS uint64_t*)X.rt, dn}; f.cnt = GArr<uint64_t>{(G_AS uint64_t*)X.cnt, 2u * dn};
+    f.st = GArr<uint32_t>{(G_AS uint32_t*)X.st, dn}; f.ref = GArr<uint32_t>{(G_AS uint32_t*)X.ref, dn}; f.rvi = GArr<uint32_t>{(G_AS uint32_t*)X.rvi, dn};
+    f.pe = GArr<uint16_t>{(G_AS uint16_t*)X.pe, dn}; f.sz = GArr<uint16_t>{(G_AS uint16_t*)X.sz, dn}; f.cg = GArr<uint16_t>{(G_AS uint16_t*)X.cg, dn}; f.pa = GArr<uint16_t>{(G_AS uint16_t*)X.pa, dn};
+    f.tail = GArr<uint8_t>{(G_AS uint8_t*)X.tail, 2u * dn};
+    const G_AS opusfe_node* nd = (const G_AS opusfe_node*)S.nodes.ptr();
+    f.kn = NodeKn{nd, dn}; f.fc = NodeFc{nd, dn}; f.nx = NodeNx{nd, dn}; f.pay = NodePay{nd, dn};
+    f.var_base = f.instr_base = f.bb_base = f.type_base = f.carg_base = 0;
+    f.n_vars_tot = f.n_instrs_tot = f.n_bbs_tot = f.n_types_tot = f.n_cargs_tot = 0;
+    *local = g - dn;
+    return gld(X.fb + fidx) == 0;
+}
+
+// ---- ready lists ------------------------------------------------------------------------------------------------------------
+// Appends node g to the list of class c that the next round reads (c >= KC_ACTIVE: nothing to append).  Called by ALL lanes of a
+// wave in converged control flow — the lanes that append to the same list share one atomic.  (Ballots inside divergent branches
+// are not an option: the compiler may hoist a convergent operation out of a branch or loop, and the mask then counts lanes that
+// never reached it.)
+__device__ __forceinline__ void wave_push(const FlatArgs& X, uint32_t* out, uint32_t* out_cnt, uint32_t c, uint32_t g) {
 #ifdef OPUSFE_EMU
-    if (f.tid == 0) { uint64_t run = 0; for (uint32_t k = 0; k < T; k++) { const uint64_t v = f.scratch[k]; f.scratch[k] = run; run += v; } f.scratch[T] = run; }
+    if (c >= KC_ACTIVE) return;
+    const uint32_t at = out_cnt[c]++;
+    if (at >= X.ctl[CTL_OFF + c + 1] - X.ctl[CTL_OFF + c]) { fprintf(stderr, "emu: ready list of class %u overflows\n", c); abort(); }
+    out[X.ctl[CTL_OFF + c] + at] = g;
 #else
-    if (f.tid < 64) {      // the first wave scans the per-thread sums: T / 64 each, a shuffle scan across the lanes
-        const uint32_t per2 = T / 64, b2 = f.tid * per2;
-        uint64_t s2 = 0;
-        for (uint32_t k = 0; k < per2; k++) s2 += f.scratch[b2 + k];
-        const uint64_t incl = wave_inclusive_scan(s2, OpAddU64());
-        uint64_t run2 = incl - s2;
-        for (uint32_t k = 0; k < per2; k++) { const uint64_t v = f.scratch[b2 + k]; f.scratch[b2 + k] = run2; run2 += v; }
-        if (f.tid == 63) f.scratch[T] = incl;
+    const uint32_t lane = __lane_id();
+    for (uint32_t k = 0; k < KC_ACTIVE; k++) {
+        const bool mine = c == k;
+        const uint64_t m = __ballot(mine);
+        if (m == 0) continue;                                // (uniform)
+        const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), n = (uint32_t)__popcll(m);
+        const int leader = __ffsll((long long)m) - 1;
+        uint32_t base = 0;
+        if (mine && rank == 0) base = atomicAdd(out_cnt + k, n);
+        base = (uint32_t)__shfl((int)base, leader);
+        if (mine) {
+            const uint32_t off = gld(X.ctl + CTL_OFF + k), cap = gld(X.ctl + CTL_OFF + k + 1) - off;
+            if (base + rank < cap) gst(out + off + base + rank, g); else atomicMax(X.ctl + CTL_LISTOVF, 1u);     // (cannot happen: the regions hold every node of the class)
+        }
     }
 #endif
-    PAR_SYNC();
-    uint64_t run = f.scratch[f.tid];
-    for (uint32_t k = lo; k < hi; k++) { const uint64_t v = a[k]; a[k] = (E)run; run += v; }
-    const uint64_t total = f.scratch[T];
-    PAR_SYNC();
-    return total;
+}
+// what a finished node hands to the next round: up to two nodes that became ready (class, node), and a chain of waiters to release
+struct Ready { uint32_t c0, g0, c1, g1, waiters, dn; };
+// one operand (or awaited definition) of `node` is done: its class when that was the last one, else KC_NONE
+__device__ __forceinline__ uint32_t release(Fn& f, uint32_t node) {
+    const uint32_t old = at_sub(&f.st[node], (uint32_t)ST_PEND_ONE);
+    if ((old & ST_PEND_MASK) != ST_PEND_ONE) return KC_NONE;
+    return kind_class_of(old, KIND(f, node));
+}
+// is node c an unsuffixed integer literal that takes its type from the left side of its assignment (generate_ir.rs:265-274, 514-549)?
+template <class F> __device__ __forceinline__ bool literal_waits_for_lhs(const F& f, uint32_t c) {
+    const uint32_t s = f.st[c];
+    return KIND(f, c) == E_Integer && !(s & ST_DEAD) && (s & ST_MODE_MASK) == ST_MODE_E && ((s & ST_EXP_MASK) >> ST_EXP_SHIFT) == EXP_ASSIGN && !(f.ref[c] & 0x8000u);
 }
 
-// One function per workgroup.
-__device__ __forceinline__ void lower_function(Fn& f) {
-    const uint32_t nn = f.nn, tid = f.tid, T = f.nthreads;
+// a node of this kind waits for ONE operand: when that operand's lane finishes, everything the node reads was written by that lane
+__device__ __forceinline__ bool single_operand(uint8_t k) {
+    return k == E_Parentheses || k == E_Negate || k == S_Expression || k == S_VariableDefinition || k == S_Return || k == E_Reference || k == E_MutableReference
+        || k == E_ArrayReference || k == E_MutableArrayReference || k == E_Dereference || k == E_Field || k == E_Cast || k == X_FieldInit;
+}
+// One ready node: lower it (count pass) and say what it releases.  The lane goes on with the parent when that has become ready, waits
+// for this one operand only and is of a class this kernel holds (chains of parentheses, field accesses, ...: no round per link).
+template <int C> __device__ __forceinline__ void count_one(const SemView& S, const ParArgs& A, const FlatArgs& X, uint32_t g, Ready& R) {
+    Fn f; uint32_t i;
+    if (!make_fn(f, S, A, X, g, &i, false)) return;
+    R.dn = f.dn;
+    for (uint32_t guard = 0; guard <= f.nn; guard++) {
+        const uint32_t s = f.st[i];
+        if (s & (ST_DONE | ST_DEAD)) { inconsistent(f); return; }         // (a node is listed once)
+        const uint8_t kind = KIND(f, i);
+        if (C == KC_CONTROL || C == KC_ANY) {
+            if (kind == S_For && !(s & ST_STAGE1)) {
+                // stage 1, listed by the iteree: the loop variable gets its type (Q13), the body may go on; the node itself is lowered when
+                // everything below it is (the iteree's share of the operand count is given up here)
+                const Desc vt = for_variable_type(f, i);
+                if (failed(f)) return;
+                f.rt[i] = vt;
+                at_or(&f.st[i], (uint32_t)ST_STAGE1);
+                R.waiters = gld(X.whead + f.dn + i);
+                R.c0 = release(f, i); R.g0 = f.dn + i;
+                return;
+            }
+        }
+        if (guard == 0 && (s & ST_PEND_MASK)) { inconsistent(f); return; }
+        if (!visit<false, C>(f, i)) { fallback(f); return; }     // (an input that is not ready: the scheduler never lets this happen)
+        if (failed(f)) return;
+        at_or(&f.st[i], (uint32_t)ST_DONE);
+        if (C == KC_STATEMENT || C == KC_ANY) { if (kind == S_VariableDefinition) R.waiters = gld(X.whead + f.dn + i); }
+        const uint32_t p = f.pa[i];
+        if (p == NONE16) return;
+        const uint8_t pk = KIND(f, p);
+        if (pk == S_Assignment && f.fc[p] == i) {                // the left side: an integer literal on the right takes its type from it
+            uint32_t c = f.nx[i];
+            while (c != NONE16 && (KIND(f, c) == E_Parentheses || KIND(f, c) == E_Negate)) c = f.fc[c];
+            if (c != NONE16 && literal_waits_for_lhs(f, c)) { R.c1 = release(f, c); R.g1 = f.dn + c; }
+        }
+        if (pk == S_For) {
+            uint32_t cond, tb, eb; blocks_of(f, p, &cond, &tb, &eb);
+            if (cond == i) { R.c0 = KC_CONTROL; R.g0 = f.dn + p; return; }      // stage 1 of the loop
+        }
+        const uint32_t pc = release(f, p);
+        if (pc >= KC_ACTIVE) return;                             // the parent waits for others
+        if ((C == KC_ANY || pc == (uint32_t)C) && single_operand(pk) && R.waiters == NONE16) { i = p; continue; }
+        R.c0 = pc; R.g0 = f.dn + p;
+        return;
+    }
+}
+// Round `round` reads the ready lists in wl0 (even rounds) or wl1 (odd rounds) and appends what becomes ready to the other one; round 0's
+// lists were written by k_flat_pre (the nodes that wait for nothing).  C == KC_ANY: every class in one launch (the long tail of rounds
+// with a few ready nodes each: one small launch per round instead of eight).
+template <int C> __global__ __launch_bounds__(256) void k_flat_count(SemView S, ParArgs A, FlatArgs X, uint32_t round) {
+    uint32_t* out = (round & 1u) ? X.wl0 : X.wl1;
+    uint32_t* out_cnt = X.ctl + CTL_ROUNDS + (round + 1) * KC_ACTIVE;
+#ifdef OPUSFE_EMU
+    const uint32_t lane = 0, W = 1;
+#else
+    const uint32_t lane = threadIdx.x & 63u, W = 64;
+#endif
+    for (uint32_t c = (C == KC_ANY ? 0u : (uint32_t)C); c < (C == KC_ANY ? (uint32_t)KC_ACTIVE : (uint32_t)C + 1u); c++) {
+        const uint32_t* in = ((round & 1u) ? X.wl1 : X.wl0) + X.ctl[CTL_OFF + c];
+        const uint32_t n = X.ctl[CTL_ROUNDS + round * KC_ACTIVE + c];
+        // (wave-uniform trip count: every lane of a wave reaches the appends below)
+        for (uint64_t base = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / W * W; base < n; base += (uint64_t)gridDim.x * blockDim.x) {
+            const uint64_t k = base + lane;
+            Ready R{KC_NONE, 0, KC_NONE, 0, NONE16, 0};
+            if (k < n) count_one<C>(S, A, X, in[k], R);
+            wave_push(X, out, out_cnt, R.c0, R.g0);
+            if (C != KC_INTEGER && C != KC_OPERATOR && C != KC_STATEMENT && C != KC_CONTROL) wave_push(X, out, out_cnt, R.c1, R.g1);      // (the left side of an assignment is never a literal, an operator or a statement)
+            if (C == KC_CONTROL || C == KC_STATEMENT || C == KC_ANY) {
+                // a definition has its type: the nodes that read the variable need not wait for it any longer
+                uint32_t w = R.waiters;
+#ifdef OPUSFE_EMU
+                while (w != NONE16) {
+#else
+                while (__ballot(w != NONE16) != 0) {
+#endif
+                    uint32_t cw = KC_NONE, gw = 0;
+                    if (w != NONE16) {
+                        const uint32_t old = at_sub((G_AS uint32_t*)X.st + R.dn + w, (uint32_t)ST_PEND_ONE);
+                        if ((old & ST_PEND_MASK) == ST_PEND_ONE) { gw = R.dn + w; cw = kind_class_of(old, gld(S.nodes.ptr() + gw).kind); }
+                        w = gld(X.wnext + R.dn + w);
+                    }
+                    wave_push(X, out, out_cnt, cw, gw);
+                }
+            }
+        }
+    }
+}
+
+// ---- scan: one wave per function ------------------------------------------------------------------------------------------
+struct Cnt2x { uint64_t vt, ib; };      // v | t << 32, i | b << 32: the four counters of an event with 32 bits each
+struct OpAddCnt2x { __host__ __device__ Cnt2x operator()(Cnt2x a, Cnt2x b) const { return Cnt2x{a.vt + b.vt, a.ib + b.ib}; } };
+__global__ __launch_bounds__(256) void k_flat_scan(SemView S, ParArgs A, FlatArgs X) {
+#ifdef OPUSFE_EMU
+    const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; const uint32_t lane = 0; constexpr uint32_t W = 1;
+#else
+    const uint32_t d = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; const uint32_t lane = threadIdx.x & 63u; constexpr uint32_t W = 64;
+#endif
+    if (d >= A.n_defs) return;
+    const uint32_t dn = A.def_nodes[d];
+    if (S.nodes[dn].kind != D_Function) return;
+    const uint32_t fidx = A.def_excl[d].funcs;
+    const FnInfo I = gld(X.fninfo + fidx);
+    if (I.nn == 0 || I.dn != dn) return;                     // not on the flat path: stays DS_FALLBACK (k_par_init)
+    uint32_t why = gld(X.fb + fidx);
+    if (why == 0 && !(gld(X.st + dn) & ST_DONE)) why = __LINE__;      // the rounds ended before the function did
+    const uint32_t nn = I.nn, ne = 2u * nn;
+    uint64_t* cnt = X.cnt + 2ull * dn;
+    Cnt2x carry{0, 0};
+    if (why == 0) {
+        for (uint32_t base = 0; base < ne; base += W) {
+            const uint32_t p = base + lane;
+            const Cnt4 c = p < ne ? unpack4(cnt[p]) : Cnt4{0, 0, 0, 0};
+            const Cnt2x mine{(uint64_t)c.v | ((uint64_t)c.t << 32), (uint64_t)c.i | ((uint64_t)c.b << 32)};
+#ifdef OPUSFE_EMU
+            const Cnt2x incl = OpAddCnt2x()(carry, mine);
+            const Cnt2x excl = carry; carry = incl;
+#else
+            Cnt2x incl = wave_inclusive_scan(mine, OpAddCnt2x());
+            const Cnt2x excl{carry.vt + incl.vt - mine.vt, carry.ib + incl.ib - mine.ib};
+            const Cnt2x last{(uint64_t)__shfl((long long)incl.vt, 63), (uint64_t)__shfl((long long)incl.ib, 63)};
+            carry = OpAddCnt2x()(carry, last);
+#endif
+            if (p < ne) cnt[p] = pack4(Cnt4{(uint32_t)excl.vt & 0xFFFFu, (uint32_t)(excl.vt >> 32) & 0xFFFFu, (uint32_t)excl.ib & 0xFFFFu, (uint32_t)(excl.ib >> 32) & 0xFFFFu});
+        }
+    }
+    // call-argument slots in node order
+    uint32_t cg_carry = 0;
+    if (why == 0) {
+        uint16_t* cg = X.cg + dn;
+        for (uint32_t base = 0; base < nn; base += W) {
+            const uint32_t p = base + lane;
+            const uint32_t mine = p < nn ? (uint32_t)cg[p] : 0u;
+#ifdef OPUSFE_EMU
+            const uint32_t excl = cg_carry; cg_carry += mine;
+#else
+            const uint32_t incl = wave_inclusive_scan(mine, OpAddU32());
+            const uint32_t excl = cg_carry + incl - mine;
+            cg_carry += (uint32_t)__shfl((int)incl, 63);
+#endif
+            if (p < nn) cg[p] = (uint16_t)excl;
+        }
+    }
+    if (lane != 0) return;
+    const uint32_t tv = (uint32_t)carry.vt, tt = (uint32_t)(carry.vt >> 32), ti = (uint32_t)carry.ib, tb = (uint32_t)(carry.ib >> 32);
+    // the packed 16-bit fields of an event must hold every prefix
+    if (why == 0 && (tv > 0xFFF0u || tt > 0xFFF0u || ti > 0xFFF0u || tb > 0xFFF0u || cg_carry > 0xFFF0u)) why = __LINE__;
+    FuncIr r{};
+    r.def_node = dn; r.func = fidx;
+    if (why) { r.status = DS_FALLBACK; r.pad = why; X.fb[fidx] = why; A.out[fidx] = r; return; }
+    const Bases b = bump_allocate(A, tv, ti, tb, tt, cg_carry);
+    r.n_vars = tv; r.n_instrs = ti; r.n_bbs = tb; r.n_types = tt; r.n_cargs = cg_carry; r.n_errs = 0; r.status = DS_OK;
+    r.var_base = b.var_base; r.instr_base = b.instr_base; r.bb_base = b.bb_base; r.type_base = b.type_base; r.carg_base = b.carg_base;
+    A.out[fidx] = r;
+    if (!b.fits) X.fb[fidx] = FB_NOFIT;                      // the host runs again with arrays of the exact size
+}
+
+// ---- result variables: every node learns the id of the variable that holds its result -----------------------------------
+// rvi[] after the count pass says who created it: the node's own event (event, offset), a local or an argument, or "the
+// result of node c" (references, parentheses, casts that did nothing).  One lane per node follows that to an id.
+__global__ __launch_bounds__(256) void k_flat_rv(ParArgs A, FlatArgs X) {
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < A.n_nodes; g += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t fidx = gld(X.fn_of + g);
+        if (fidx == OPUSFE_NONE || gld(X.fb + fidx) != 0) continue;
+        const FnInfo I = gld(X.fninfo + fidx);
+        const uint32_t dn = I.dn;
+        uint32_t r = gld(X.rvi + g);
+        uint32_t res = OPUSFE_NONE;
+        for (uint32_t guard = 0; guard <= I.nn + 2u; guard++) {
+            const uint32_t tag = r & RV_TAG;
+            if (tag == RV_RESOLVED) { res = r; break; }
+            if (tag == RV_OWN) { res = RV_RESOLVED | (unpack4(gld(X.cnt + 2ull * dn + ((r >> 12) & 0x1FFFFu))).v + (r & 0xFFFu)); break; }
+            if (tag == RV_ARG) { res = RV_RESOLVED | (I.nargs + (r & RV_VAL)); break; }
+            if (tag == RV_LOCAL) { r = gld(X.rvi + dn + (r & 0xFFFFu)); if ((r & RV_TAG) != RV_OWN && (r & RV_TAG) != RV_RESOLVED) break; continue; }      // the slot of the definition holds its variable
+            if (tag == RV_PASS) { r = gld(X.rvi + dn + (r & 0xFFFFu)); continue; }
+            break;
+        }
+        if (res == OPUSFE_NONE) { atomicMax(A.status, (uint32_t)DS_INTERNAL_CAPACITY); if (A.dbg) atomicMax(A.dbg, (uint32_t)__LINE__); continue; }
+        gst(X.rvi + g, res);
+    }
+}
+
+// ---- emit -----------------------------------------------------------------------------------------------------------------
+template <int C> __global__ __launch_bounds__(256) void k_flat_emit(SemView S, ParArgs A, FlatArgs X) {
+    constexpr uint32_t c = C == KC_ANY ? 0u : (uint32_t)C;
+    const uint32_t* in = X.order + X.ctl[CTL_OFF + c];
+    const uint32_t n = X.ctl[CTL_ORDER + c];
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
+        Fn f; uint32_t i;
+        if (!make_fn(f, S, A, X, in[k], &i, true)) continue;
+        const FuncIr r = gld(A.out + f.fidx);
+        f.var_base = r.var_base; f.instr_base = r.instr_base; f.bb_base = r.bb_base; f.type_base = r.type_base; f.carg_base = r.carg_base;
+        f.n_vars_tot = r.n_vars; f.n_instrs_tot = r.n_instrs; f.n_bbs_tot = r.n_bbs; f.n_types_tot = r.n_types; f.n_cargs_tot = r.n_cargs;
+        visit<true, C>(f, i);
+    }
+}
+
+// ======================================================================================================================
+// k_flat_pre: what is local to a function by nature (one workgroup per function, one lane per node, state in LDS)
+// ======================================================================================================================
+struct Pre {
+    SemView S; ParArgs A;
+    uint32_t dn, nn, fidx, nargs; uint64_t user_syms;
+    lds_u32* kn; lds_u32* st; lds_u32* ref; lds_u32* rvi; lds_u32* pay;
+    lds_u16* fc; lds_u16* nx; lds_u16* pa; lds_u16* rk; lds_u16* sz; lds_u16* pe; lds_u16* cg; lds_u16* wnext;
+    DefEnt* defs; ArgEnt* args; lds_u32* misc; lds_u32* whead;
+    uint32_t tid, nthreads;
+};
+enum { MI_FB = 0, MI_NDEFS = 1, MI_WHY = 7, MI_KHIST = 16 /* 2 x KC_ACTIVE words */, MI_KBASE = 32 /* 2 x KC_ACTIVE words: the function's place in the class lists */, MI_WORDS = 48 };
+
+__host__ __device__ inline size_t lds_bytes(uint32_t nmax, uint32_t maxdef, uint32_t nthreads) {
+    (void)nthreads;
+    size_t b = 0;
+    b += 4ull * 5 * nmax;        // kn st ref rvi pay
+    b += 2ull * 8 * nmax;        // fc nx pa rk sz pe cg wnext
+    b = (b + 7) & ~(size_t)7;
+    b += sizeof(DefEnt) * maxdef + sizeof(ArgEnt) * MAX_ARGS + 4 * MI_WORDS + 4ull * maxdef;
+    return (b + 15) & ~(size_t)15;
+}
+__device__ __forceinline__ void fallback_at(Pre& f, uint32_t line) { if (!f.misc[MI_FB]) f.misc[MI_WHY] = line; f.misc[MI_FB] = 1; }
+__device__ __forceinline__ bool failed(const Pre& f) { return f.misc[MI_FB] != 0; }
+__device__ __forceinline__ opusfe_node ND(const Pre& f, uint32_t i) { return f.S.nodes[f.dn + i]; }
+// definition of identifier token `t` visible at node `use`: RF_LOCAL | index, RF_ARG | index, or RF_NONE
+__device__ __forceinline__ uint32_t find_local(const Pre& f, const opusfe_token& t, uint32_t use_node) {
+    const uint32_t nd = f.misc[MI_NDEFS], use = RANK(f, use_node);
+    for (uint32_t k = 0; k < nd; k++) {
+        const DefEnt& d = f.defs[k];
+        if (d.hash == t.payload && d.len == t.len && d.dpoint <= use && use < d.send && bytes_eq(f.S, d.low, t.low, t.len)) return RF_LOCAL | k;
+    }
+    for (uint32_t k = 0; k < f.nargs; k++) {
+        const ArgEnt& a = f.args[k];
+        if (a.hash == t.payload && a.len == t.len && bytes_eq(f.S, a.low, t.low, t.len)) return RF_ARG | k;
+    }
+    return RF_NONE;
+}
+// the node whose rt / rvi words hold the type and the variable of the local definition made by node i: the statement itself
+// (`var x = e`, `for x in e`: statements have no result of their own), the type node of a `var x T` expression
+__device__ __forceinline__ uint32_t def_slot(const Pre& f, uint32_t i) { return KIND(f, i) == E_VariableDefinition ? (uint32_t)f.fc[i] : i; }
+
+__device__ __forceinline__ void pre_function(Pre& f, const FlatArgs& X) {
+    const uint32_t nn = f.nn, tid = f.tid, T = f.nthreads, dn = f.dn;
     if (tid == 0) { for (uint32_t k = 0; k < MI_WORDS; k++) f.misc[k] = 0; }
     PAR_SYNC();
     // ---- structure ----
@@ -1279,14 +1598,13 @@ __device__ __forceinline__ void lower_function(Fn& f) {
         if ((fc != NONE16 && fc >= nn) || (nx != NONE16 && nx >= nn)) fallback(f);      // links must stay inside the function
         f.fc[i] = (uint16_t)fc; f.nx[i] = (uint16_t)nx;
         f.pay[i] = n.payload;
-        f.pa[i] = NONE16; f.st[i] = 0; f.ref[i] = (n.kind >= Y_Name && n.kind <= Y_Array) ? f.S.tid_of_node[f.dn + i] : 0u; f.rvi[i] = 0; f.rt[i] = DESC_NONE; f.cg[i] = 0; f.rk[i] = 0; f.sz[i] = 0; f.pe[i] = 0;
-        f.cnt[2 * i] = 0; f.cnt[2 * i + 1] = 0; f.tail[2 * i] = TAIL_NONE; f.tail[2 * i + 1] = TAIL_NONE;
+        f.pa[i] = NONE16; f.st[i] = 0; f.ref[i] = (n.kind >= Y_Name && n.kind <= Y_Array) ? f.S.tid_of_node[f.dn + i] : 0u; f.rvi[i] = 0; f.cg[i] = 0; f.rk[i] = 0; f.sz[i] = 0; f.pe[i] = 0; f.wnext[i] = NONE16;
+        // (the unit-wide words that start empty — rt = none, cnt, tail, rvi = 0 — were cleared by the host; the names phase fills some in)
         if (f.A.undefined_flag[f.dn + i]) fallback(f);                                // UndefinedType somewhere in the function
     }
     if (par_sync_or(failed(f))) return;      // (uniform exit: every wave sees the same answer)
     for (uint32_t i = tid; i < nn; i += T) { uint32_t guard = 0; for (uint32_t c = f.fc[i]; c != NONE16 && guard <= nn; c = f.nx[c], guard++) f.pa[c] = (uint16_t)i; if (guard > nn) fallback(f); }
-    if (par_sync_or(failed(f))) return;      // (uniform exit: every wave sees the same answer)
-    if (f.A.stop_phase == 1) { fallback(f); return; }
+    if (par_sync_or(failed(f))) return;
     // Subtree sizes, depths and "dead" marks by one walk up the ancestor chain per node (the nodes arrive in creation order, not
     // pre-order, so none of this is index arithmetic).  Level-synchronous fixpoints did the same in height-of-the-tree rounds of
     // barrier + sweep each (3.7 + 5.8 ms per 256 MB); a walk is depth steps for the one node, with no barrier at all.
@@ -1303,8 +1621,7 @@ __device__ __forceinline__ void lower_function(Fn& f) {
         f.pe[i] = (uint16_t)depth;
         if (dead) f.st[i] = ST_DEAD;
     }
-    if (par_sync_or(failed(f))) return;      // (uniform exit: every wave sees the same answer)
-    if (f.A.stop_phase == 2) { fallback(f); return; }
+    if (par_sync_or(failed(f))) return;
     // every parent hands its children their offset from its own rank (1 + the sizes of the children before them)
     for (uint32_t p = tid; p < nn; p += T) {
         f.sz[p] = (uint16_t)(1u + f.rvi[p]);
@@ -1384,7 +1701,6 @@ __device__ __forceinline__ void lower_function(Fn& f) {
         if (!par_sync_or(progress)) break;
     }
     if (failed(f)) return;
-    if (f.A.stop_phase == 3) { fallback(f); return; }
     // ---- arguments and local definitions ----
     if (tid == 0) {
         uint32_t a = f.fc[0], k = 0;
@@ -1392,8 +1708,9 @@ __device__ __forceinline__ void lower_function(Fn& f) {
             if (k >= MAX_ARGS) { fallback(f); break; }
             const opusfe_token t = f.S.tok[f.pay[a]];
             if (t.kind != T_Identifier) { fallback(f); break; }                         // a symbol as a variable name (sym_locals)
-            ArgEnt e; e.hash = t.payload; e.low = t.low; e.len = t.len; e.pad = 0; e.vt = d_ptr(f, PT_Mutable, d_id(TID(f, f.fc[a])));
+            ArgEnt e; e.hash = t.payload; e.low = t.low; e.len = t.len; e.pad = a; e.vt = d_ptr(f, PT_Mutable, d_id(TID(f, f.fc[a])));
             f.args[k++] = e;
+            gst(X.rt + dn + a, (uint64_t)e.vt);                                        // (the argument's node holds its type for the visits)
             a = f.nx[a];
         }
         if (k != f.nargs) fallback(f);
@@ -1417,9 +1734,10 @@ __device__ __forceinline__ void lower_function(Fn& f) {
                 if (blk == NONE16) { fallback(f); continue; }
                 d.dpoint = k == S_VariableDefinition ? RANK_END(f, i) : RANK(f, i) + 1;
                 d.send = RANK_END(f, blk);
-                if (k == E_VariableDefinition) d.vt = d_ptr(f, PT_Mutable, d_id(TID(f, f.fc[i])));
+                if (k == E_VariableDefinition) { if (f.fc[i] == NONE16) { fallback(f); continue; } d.vt = d_ptr(f, PT_Mutable, d_id(TID(f, f.fc[i]))); }
             }
             f.defs[slot] = d;
+            f.whead[slot] = NONE16;
             f.ref[i] = slot;
         }
         if (k == S_Break || k == S_Continue) {
@@ -1428,7 +1746,7 @@ __device__ __forceinline__ void lower_function(Fn& f) {
             if (loop != NONE16 && k == S_Break) lds_or(&f.st[loop], (uint32_t)ST_HASBREAK);
         }
     }
-    if (par_sync_or(failed(f))) return;      // (uniform exit: every wave sees the same answer)
+    if (par_sync_or(failed(f))) return;
     {   // shadowing (generate_ir.rs:255,410,1009) and redefinition of an argument (Q17): the sequential machine handles those
         const uint32_t nd = f.misc[MI_NDEFS];
         for (uint32_t a = tid; a < nd; a += T) {
@@ -1436,20 +1754,21 @@ __device__ __forceinline__ void lower_function(Fn& f) {
             for (uint32_t b = 0; b < nd; b++) {
                 if (b == a) continue;
                 const DefEnt& db = f.defs[b];
-                if (db.hash != da.hash || db.len != da.len || !bytes_eq(f, da.low, db.low, da.len)) continue;
+                if (db.hash != da.hash || db.len != da.len || !bytes_eq(f.S, da.low, db.low, da.len)) continue;
                 // is a in scope when b's shadow check runs?  (a `var` statement checks after its initialiser, a `for` after its
                 // iteree, a `var x T` expression when it is reached)
                 const uint8_t bk = KIND(f, db.node);
                 const uint32_t at = (bk == S_VariableDefinition || bk == S_For) ? db.dpoint - 1 : RANK(f, db.node);
                 if (at >= da.dpoint && at < da.send) fallback(f);
             }
-            for (uint32_t k = 0; k < f.nargs; k++) { const ArgEnt& g = f.args[k]; if (g.hash == da.hash && g.len == da.len && bytes_eq(f, g.low, da.low, da.len)) fallback(f); }
+            for (uint32_t k = 0; k < f.nargs; k++) { const ArgEnt& g = f.args[k]; if (g.hash == da.hash && g.len == da.len && bytes_eq(f.S, g.low, da.low, da.len)) fallback(f); }
         }
-        for (uint32_t a = tid; a < f.nargs; a += T) for (uint32_t b = 0; b < a; b++) { const ArgEnt& x = f.args[a]; const ArgEnt& y = f.args[b]; if (x.hash == y.hash && x.len == y.len && bytes_eq(f, x.low, y.low, x.len)) fallback(f); }
+        for (uint32_t a = tid; a < f.nargs; a += T) for (uint32_t b = 0; b < a; b++) { const ArgEnt& x = f.args[a]; const ArgEnt& y = f.args[b]; if (x.hash == y.hash && x.len == y.len && bytes_eq(f.S, x.low, y.low, x.len)) fallback(f); }
     }
     PAR_SYNC();
-    if (f.A.stop_phase == 4) { fallback(f); return; }
     // ---- names ----
+    // A use of a local whose type is not known yet (`var x = e`, `for x in e`) WAITS for the definition: one more pending operand,
+    // and a place in the definition's waiter chain (whead / wnext), which the visit of the definition walks.
     for (uint32_t i = tid; i < nn; i += T) {
         const uint8_t k = KIND(f, i);
         if (f.st[i] & ST_DEAD) continue;
@@ -1459,9 +1778,25 @@ __device__ __forceinline__ void lower_function(Fn& f) {
         const opusfe_token t = f.S.tok[name_tok];
         if (t.kind != T_Identifier) { fallback(f); continue; }
         const uint32_t local = find_local(f, t, i);
-        if (k == E_Variable && local != RF_NONE) { f.ref[i] = local; continue; }          // (most names: no table lookup at all)
+        auto use_local = [&](uint32_t l) {
+            // the visits address a local by the node that holds its type and variable (def_slot), an argument by its number and node
+            if ((l & RF_TAG) == RF_ARG) { f.ref[i] = RF_ARG | (l & RF_VAL) | (f.args[l & RF_VAL].pad << 4); return; }
+            const uint32_t di = l & RF_VAL;
+            const DefEnt& d = f.defs[di];
+            f.ref[i] = RF_LOCAL | def_slot(f, d.node);
+            if (d.vt == DESC_NONE && (f.st[i] & ST_MODE_MASK) != 0) {
+#ifdef OPUSFE_EMU
+                const uint32_t oldh = f.whead[di]; f.whead[di] = i;
+#else
+                const uint32_t oldh = __hip_atomic_exchange(&f.whead[di], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+                f.wnext[i] = (uint16_t)oldh;
+                lds_add(&f.st[i], (uint32_t)ST_PEND_ONE);
+            }
+        };
+        if (k == E_Variable && local != RF_NONE) { use_local(local); continue; }          // (most names: no table lookup at all)
         const uint32_t slot = name_find(f.S, key_tok(name_tok));
-        if (k == E_NamedCall && slot_has_functions(f, slot)) {
+        if (k == E_NamedCall && slot_has_functions(f.S, slot)) {
             if (local != RF_NONE) { fallback(f); continue; }      // a local shadows the functions of that name (:1152-1158)
             f.ref[i] = RF_CALL | (slot & RF_VAL);
             f.cg[i] = (uint16_t)NCH(f, i);
@@ -1475,13 +1810,13 @@ __device__ __forceinline__ void lower_function(Fn& f) {
                 const FuncRec fr = f.S.funcs[only];
                 if (fr.nargs != NCH(f, i)) { fallback(f); continue; }                      // NoOverloadForFunction
                 uint32_t c = f.fc[i], a = fr.first_arg;
-                for (uint32_t q = 0; q < fr.nargs && c != NONE16; q++) { f.cnt[POS_EXIT(f, c)] = f.S.tid_of_node[f.S.nodes[a].first_child]; a = f.S.nodes[a].next; c = f.nx[c]; }
-                f.rt[i] = d_id(fr.ret);
+                for (uint32_t q = 0; q < fr.nargs && c != NONE16; q++) { gst(X.cnt + 2ull * dn + POS_EXIT(f, c), (uint64_t)f.S.tid_of_node[f.S.nodes[a].first_child]); a = f.S.nodes[a].next; c = f.nx[c]; }
+                gst(X.rt + dn + i, (uint64_t)d_id(fr.ret));
                 f.ref[i] = RF_CALL1 | only;
             }
             continue;
         }
-        if (local != RF_NONE) { f.ref[i] = local; continue; }
+        if (local != RF_NONE) { use_local(local); continue; }
         uint32_t r = RF_NONE;
         if (slot != OPUSFE_NONE) {
             const NameSlot sl = f.S.slots[slot];
@@ -1495,7 +1830,7 @@ __device__ __forceinline__ void lower_function(Fn& f) {
             if (r == RF_NONE && nfn == 1) r = RF_FUNC | only;
         }
         if (r == RF_NONE || (k == E_NamedCall && ((r & RF_TAG) == RF_CONST || (r & RF_TAG) == RF_FUNC))) { fallback(f); continue; }
-        if ((r & RF_TAG) == RF_GLOBAL || (r & RF_TAG) == RF_CONST) f.rt[i] = d_id(f.S.globals[r & RF_VAL].type_id);    // fetched here, read by the visit
+        if ((r & RF_TAG) == RF_GLOBAL || (r & RF_TAG) == RF_CONST) gst(X.rt + dn + i, (uint64_t)d_id(f.S.globals[r & RF_VAL].type_id));    // fetched here, read by the visit
         f.ref[i] = r;
     }
     // operator calls and `for` reserve their call arguments too (user overloads only use them; sized for the worst case)
@@ -1504,137 +1839,75 @@ __device__ __forceinline__ void lower_function(Fn& f) {
         if (k == E_Operator && !(f.st[i] & ST_DEAD)) { const uint8_t sym = sym_of_op(SUB(f, i)); if ((f.user_syms >> sym) & 1) f.cg[i] = 2; }
         if (k == S_For) f.cg[i] = 3;
     }
-    if (par_sync_or(failed(f))) return;      // (uniform exit: every wave sees the same answer)
-    if (f.A.stop_phase == 5) { fallback(f); return; }
-    // ---- nodes by kind (kind_class): the sweeps below go through the nodes in this order; nodes with nothing to lower are left out ----
-    for (uint32_t k = tid; k < KC_COUNT; k += T) f.misc[MI_KHIST + k] = 0;
+    if (par_sync_or(failed(f))) return;
+    // ---- what every node waits for ----
+    for (uint32_t i = tid; i < nn; i += T) {
+        const uint32_t s = f.st[i];
+        if (kind_class_of(s, KIND(f, i)) >= KC_ACTIVE && !(s & ST_DEAD)) f.st[i] = s | ST_DONE;      // nothing to lower: its parent need not wait
+    }
     PAR_SYNC();
-    for (uint32_t i = tid; i < nn; i += T) lds_add(&f.misc[MI_KHIST + kind_class(f, i)], 1u);
+    // every node counts the operands it has to wait for (in its own state word): each node that will be lowered adds one to its
+    // parent; an integer literal that takes its type from the left side of its assignment waits for that
+    for (uint32_t i = tid; i < nn; i += T) {
+        if (!(f.st[i] & (ST_DONE | ST_DEAD)) && f.pa[i] != NONE16) lds_add(&f.st[f.pa[i]], (uint32_t)ST_PEND_ONE);
+        if (literal_waits_for_lhs(f, i)) lds_add(&f.st[i], (uint32_t)ST_PEND_ONE);
+    }
     PAR_SYNC();
-    if (tid == 0) { uint32_t run = 0; for (uint32_t c = 0; c < KC_COUNT; c++) { const uint32_t v = f.misc[MI_KHIST + c]; f.misc[MI_KHIST + c] = run; run += v; if (c == KC_NONE - 1) f.misc[MI_NACTIVE] = run; } }
+    // ---- nodes by kind class: the function's place in the unit-wide class lists (`order`: every node that is lowered; wl0: the ones
+    //      that wait for nothing, the first round) ----
+    for (uint32_t k = tid; k < 2 * KC_ACTIVE; k += T) f.misc[MI_KHIST + k] = 0;
     PAR_SYNC();
     for (uint32_t i = tid; i < nn; i += T) {
-        const uint32_t c = kind_class(f, i);
-        const uint32_t pos = lds_add(&f.misc[MI_KHIST + c], 1u);
-        f.by_kind[pos] = (uint16_t)i;
-        if (c == KC_NONE && !(f.st[i] & ST_DEAD)) f.st[i] |= ST_DONE;                      // nothing to lower: its parent need not wait
+        const uint32_t s = f.st[i], c = kind_class_of(s, KIND(f, i));
+        if (c >= KC_ACTIVE) continue;
+        lds_add(&f.misc[MI_KHIST + c], 1u);
+        if (!(s & ST_PEND_MASK)) lds_add(&f.misc[MI_KHIST + KC_ACTIVE + c], 1u);
     }
     PAR_SYNC();
-    const uint32_t n_active = f.misc[MI_NACTIVE];
-    // every node counts the operands it has to wait for (in its own state word, so that "ready?" is one LDS read per round instead
-    // of a walk over the children): each node that will be lowered adds one to its parent
-    for (uint32_t i = tid; i < nn; i += T) if (!(f.st[i] & (ST_DONE | ST_DEAD)) && f.pa[i] != NONE16) lds_add(&f.st[f.pa[i]], (uint32_t)ST_PEND_ONE);
+    for (uint32_t k = tid; k < 2 * KC_ACTIVE; k += T) {
+        const uint32_t n = f.misc[MI_KHIST + k];
+        f.misc[MI_KBASE + k] = n ? atomicAdd(X.ctl + (k < KC_ACTIVE ? CTL_ORDER + k : CTL_ROUNDS + k - KC_ACTIVE), n) : 0u;
+    }
     PAR_SYNC();
-    // ---- types, counts (bottom-up fixpoint) ----
-    // (A variant that first compacted the ready nodes of a round into dense per-class queues and lowered those with all lanes was
-    // measured slower: 32 ms against 21 ms per 256 MB — two more barriers and the queue bookkeeping cost more than the idle lanes.)
-    for (uint32_t round = 0; round <= nn + 1; round++) {
-        bool progress = false;
-        if (f.A.stop_rounds && round >= f.A.stop_rounds) break;
-        for (uint32_t j = tid; j < n_active; j += T) {
-            // A lane lowers its node and then, as long as it was the last operand its parent waited for, the parent (and so on up):
-            // what is left for the next round are the nodes that wait for the type of a local (and what hangs above them).
-            uint32_t i = f.by_kind[j];
-            for (;;) {
-                const uint32_t s = f.st[i];
-                if (s & (ST_DONE | ST_DEAD | ST_CLAIM)) break;
-                if (KIND(f, i) == S_For && !(s & ST_STAGE1)) {       // the loop variable gets its type as soon as the iteree has one
-                    uint32_t cond, tb, eb; blocks_of(f, i, &cond, &tb, &eb);
-                    if (cond != NONE16 && (f.st[cond] & ST_DONE)) {
-                        const Desc vt = for_variable_type(f, i);
-                        if (!failed(f)) { f.defs[f.ref[i]].vt = vt; par_fence(); lds_or(&f.st[i], (uint32_t)ST_STAGE1); progress = true; }
-                    }
-                }
-                if (s & ST_PEND_MASK) break;
-                if (lds_or(&f.st[i], (uint32_t)ST_CLAIM) & (ST_CLAIM | ST_DONE)) break;       // another lane got here first
-                par_fence();
-#ifdef OPUSFE_EMU
-                if (!operands_done(f, i)) f.misc[MI_BAD] = 1;        // the counter and the walk must agree
-#endif
-                if (!visit<false>(f, i)) { lds_and(&f.st[i], ~(uint32_t)ST_CLAIM); break; }   // an input is not ready: next round
-                par_fence();
-                lds_or(&f.st[i], (uint32_t)ST_DONE);
-                progress = true;
-                const uint32_t p = f.pa[i];
-                if (p == NONE16) break;
-                const uint32_t before = lds_sub(&f.st[p], (uint32_t)ST_PEND_ONE);
-                if ((before & ST_PEND_MASK) != ST_PEND_ONE || !f.A.climb) break;
-                i = p;
-            }
-        }
-        if (!par_sync_or(progress && !failed(f))) {
-#ifdef OPUSFE_EMU
-            g_emu_stat[0] += 1; g_emu_stat[1] += round + 1; g_emu_stat[2] += (uint64_t)(round + 1) * n_active; g_emu_stat[3] += n_active; g_emu_stat[4] += nn;
-#endif
-            break;
+    for (uint32_t k = tid; k < 2 * KC_ACTIVE; k += T) f.misc[MI_KHIST + k] = 0;
+    PAR_SYNC();
+    for (uint32_t i = tid; i < nn; i += T) {
+        const uint32_t s = f.st[i], c = kind_class_of(s, KIND(f, i));
+        if (c >= KC_ACTIVE) continue;
+        const uint32_t off = X.ctl[CTL_OFF + c], cap = X.ctl[CTL_OFF + c + 1] - off;
+        const uint32_t pos = f.misc[MI_KBASE + c] + lds_add(&f.misc[MI_KHIST + c], 1u);
+        if (pos < cap) gst(X.order + off + pos, dn + i); else fallback(f);
+        if (!(s & ST_PEND_MASK)) {
+            const uint32_t pos0 = f.misc[MI_KBASE + KC_ACTIVE + c] + lds_add(&f.misc[MI_KHIST + KC_ACTIVE + c], 1u);
+            if (pos0 < cap) gst(X.wl0 + off + pos0, dn + i); else fallback(f);
         }
     }
-    if (failed(f)) return;
-    if (!(f.st[0] & ST_DONE)) { fallback(f); return; }
-    if (f.A.stop_phase == 6) { fallback(f); return; }
-    // ---- scans: Euler-order exclusive prefix of the event counters; call-argument slots in node order ----
-    {   // the packed 16-bit fields must not carry into each other: check the four sums first
-        uint32_t sv = 0, stt = 0, si = 0, sb = 0;
-        for (uint32_t p = tid; p < 2 * nn; p += T) { const Cnt4 c = unpack4(f.cnt[p]); sv += c.v; stt += c.t; si += c.i; sb += c.b; }
-        if (sv) lds_add(&f.misc[MI_SUM_V], sv);
-        if (stt) lds_add(&f.misc[MI_SUM_T], stt);
-        if (si) lds_add(&f.misc[MI_SUM_I], si);
-        if (sb) lds_add(&f.misc[MI_SUM_B], sb);
-        PAR_SYNC();
-        if (f.misc[MI_SUM_V] > 0xFFF0u || f.misc[MI_SUM_T] > 0xFFF0u || f.misc[MI_SUM_I] > 0xFFF0u || f.misc[MI_SUM_B] > 0xFFF0u) { fallback(f); return; }
+    if (par_sync_or(failed(f))) return;
+    // ---- hand-over: the per-node words the flat passes read ----
+    for (uint32_t i = tid; i < nn; i += T) {
+        const uint32_t g = dn + i;
+        gst(X.st + g, (uint32_t)f.st[i]); gst(X.ref + g, (uint32_t)f.ref[i]);
+        gst(X.pe + g, (uint16_t)f.pe[i]); gst(X.sz + g, (uint16_t)f.sz[i]); gst(X.cg + g, (uint16_t)f.cg[i]); gst(X.pa + g, (uint16_t)f.pa[i]);
+        gst(X.wnext + g, (uint16_t)f.wnext[i]);
+        gst(X.fn_of + g, f.fidx);
     }
-    const Cnt4 tot = unpack4(block_scan<uint64_t>(f, f.cnt, 2 * nn));
-    const uint32_t tot_cargs = (uint32_t)block_scan<uint16_t>(f, f.cg, nn);
-    if (tot_cargs > 0xFFF0u) { fallback(f); return; }
-    if (f.A.stop_phase == 7) { fallback(f); return; }
-    // ---- the function's place in the dense arrays ----
-    if (tid == 0) {
-        const Bases b = bump_allocate(f.A, tot.v, tot.i, tot.b, tot.t, tot_cargs);
-        FuncIr r{};
-        r.def_node = f.dn; r.func = f.fidx; r.n_vars = tot.v; r.n_instrs = tot.i; r.n_bbs = tot.b; r.n_types = tot.t; r.n_cargs = tot_cargs; r.n_errs = 0; r.status = DS_OK;
-        r.var_base = b.var_base; r.instr_base = b.instr_base; r.bb_base = b.bb_base; r.type_base = b.type_base; r.carg_base = b.carg_base;
-        f.A.out[f.fidx] = r;
-        f.misc[MI_VBASE] = b.var_base; f.misc[MI_IBASE] = b.instr_base; f.misc[MI_BBASE] = b.bb_base; f.misc[MI_TBASE] = b.type_base; f.misc[MI_CBASE] = b.carg_base;
-        f.misc[MI_FITS] = b.fits ? 1u : 0u;
-    }
-    PAR_SYNC();
-    if (!f.misc[MI_FITS]) return;                         // the host runs again with arrays of the exact size
-    f.var_base = f.misc[MI_VBASE]; f.instr_base = f.misc[MI_IBASE]; f.bb_base = f.misc[MI_BBASE]; f.type_base = f.misc[MI_TBASE]; f.carg_base = f.misc[MI_CBASE];
-    f.n_vars_tot = tot.v; f.n_instrs_tot = tot.i; f.n_bbs_tot = tot.b; f.n_types_tot = tot.t; f.n_cargs_tot = tot_cargs;
-    // ---- result variables: every node learns the id of the variable that holds its result ----
     {
         const uint32_t nd = f.misc[MI_NDEFS];
-        for (uint32_t k = tid; k < nd; k += T) { const uint32_t r = f.defs[k].var; f.defs[k].var = unpack4(f.cnt[(r >> 12) & 0x1FFFF]).v + (r & 0xFFF); }
+        for (uint32_t k = tid; k < nd; k += T) {
+            const DefEnt& d = f.defs[k];
+            const uint32_t slot = def_slot(f, d.node);
+            gst(X.whead + dn + slot, (uint16_t)f.whead[k]);
+            if (d.vt != DESC_NONE) gst(X.rt + dn + slot, (uint64_t)d.vt);
+        }
     }
-    PAR_SYNC();
-    for (uint32_t i = tid; i < nn; i += T) {
-        const uint32_t r = f.rvi[i], tag = r & RV_TAG;
-        if (tag == RV_OWN) f.rvi[i] = RV_RESOLVED | (unpack4(f.cnt[(r >> 12) & 0x1FFFF]).v + (r & 0xFFF));
-        else if (tag == RV_LOCAL) f.rvi[i] = RV_RESOLVED | f.defs[r & RV_VAL].var;
-        else if (tag == RV_ARG) f.rvi[i] = RV_RESOLVED | (f.nargs + (r & RV_VAL));
-    }
-    PAR_SYNC();
-    for (uint32_t i = tid; i < nn; i += T) {
-        uint32_t r = f.rvi[i];
-        if ((r & RV_TAG) != RV_PASS) continue;
-        for (uint32_t guard = 0; guard < nn && (r & RV_TAG) == RV_PASS; guard++) r = f.rvi[r & 0xFFFF];
-        if ((r & RV_TAG) != RV_RESOLVED) { f.misc[MI_BAD] = 1; continue; }
-        f.rvi[i] = r;
-    }
-    PAR_SYNC();
-    if (f.A.stop_phase == 8) return;
-    // ---- emit ----
-    for (uint32_t j = tid; j < n_active; j += T) visit<true>(f, f.by_kind[j]);
-    PAR_SYNC();
+    if (tid == 0) { FnInfo I{}; I.dn = dn; I.nn = nn; I.nargs = f.nargs; I.ret = f.S.funcs[f.fidx].ret; I.sym_mix = f.S.mix_of_def(dn); gst(X.fninfo + f.fidx, I); }
 }
 
-// One workgroup per function of `list` (definition indices): sizes, then the dense results (or DS_FALLBACK).
+// One workgroup per function of `list` (definition indices).
 #ifndef OPUSFE_PAR_WAVES
 #define OPUSFE_PAR_WAVES 4
 #endif
-// (One instantiation for every workgroup size: with 4 waves per SIMD the register budget of a 1024-thread workgroup is the same 128
-// VGPRs, and five copies of the two inlined visits made the library take 17 minutes to compile.)
-__global__ MACHINE_ATTR(OPUSFE_PAR_WAVES) __launch_bounds__(1024) void k_lower_par(SemView S, ParArgs A) {
+__global__ MACHINE_ATTR(OPUSFE_PAR_WAVES) __launch_bounds__(1024) void k_flat_pre(SemView S, ParArgs A, FlatArgs X) {
     const uint32_t slot = blockIdx.x;
     if (slot >= A.n_list) return;
     const uint32_t d = A.list ? A.list[slot] : slot;
@@ -1645,16 +1918,12 @@ __global__ MACHINE_ATTR(OPUSFE_PAR_WAVES) __launch_bounds__(1024) void k_lower_p
     const uint32_t dn_end = d + 1 < A.n_defs ? A.def_nodes[d + 1] : A.n_nodes;
     const uint32_t nn = dn_end - dn;
     if (nn > A.nmax || nn < 2) return;                       // stays DS_FALLBACK (k_par_init)
-    Fn f;
-    f.S = S; f.A = A; f.dn = dn; f.nn = nn; f.fidx = fidx; f.F = S.funcs[fidx]; f.nargs = f.F.nargs; f.user_syms = *A.user_syms; f.sym_mix = S.mix_of_def(dn);
+    Pre f;
+    f.S = S; f.A = A; f.dn = dn; f.nn = nn; f.fidx = fidx; f.nargs = S.funcs[fidx].nargs; f.user_syms = *A.user_syms;
     f.tid = threadIdx.x; f.nthreads = blockDim.x;
-    f.var_base = f.instr_base = f.bb_base = f.type_base = f.carg_base = 0;
-    f.n_vars_tot = f.n_instrs_tot = f.n_bbs_tot = f.n_types_tot = f.n_cargs_tot = 0;
     // carve the dynamic LDS block (same order as lds_bytes)
     LDS_AS uint8_t* base = (LDS_AS uint8_t*)PAR_LDS_BASE();
     const uint32_t nmax = A.nmax;
-    f.rt = (lds_u64*)base; base += 8u * nmax;
-    f.cnt = (lds_u64*)base; base += 16u * nmax;
     f.kn = (lds_u32*)base; base += 4u * nmax;
     f.st = (lds_u32*)base; base += 4u * nmax;
     f.ref = (lds_u32*)base; base += 4u * nmax;
@@ -1667,25 +1936,31 @@ __global__ MACHINE_ATTR(OPUSFE_PAR_WAVES) __launch_bounds__(1024) void k_lower_p
     f.sz = (lds_u16*)base; base += 2u * nmax;
     f.pe = (lds_u16*)base; base += 2u * nmax;
     f.cg = (lds_u16*)base; base += 2u * nmax;
-    f.by_kind = (lds_u16*)base; base += 2u * nmax;
-    f.tail = (lds_u8*)base; base += 2u * nmax;
+    f.wnext = (lds_u16*)base; base += 2u * nmax;
     base += (8u - (uint32_t)(uintptr_t)base % 8u) % 8u;
     f.defs = (DefEnt*)base; base += sizeof(DefEnt) * A.maxdef;
     f.args = (ArgEnt*)base; base += sizeof(ArgEnt) * MAX_ARGS;
     f.misc = (lds_u32*)base; base += 4 * MI_WORDS;
-    base += (8u - (uint32_t)(uintptr_t)base % 8u) % 8u;
-    f.scratch = (lds_u64*)base;
-    lower_function(f);
+    f.whead = (lds_u32*)base;
+    pre_function(f, X);
     PAR_SYNC();
     if (f.tid == 0) {
-        if (f.misc[MI_BAD] || (f.misc[MI_FB] && f.misc[MI_FITS])) atomicMax(A.status, (uint32_t)DS_INTERNAL_CAPACITY);   // the count and emit visits must agree
-        else if (f.misc[MI_FB]) { FuncIr r{}; r.def_node = dn; r.func = fidx; r.status = DS_FALLBACK; r.pad = f.misc[MI_WHY]; A.out[fidx] = r; }
+        if (f.misc[MI_FB]) {       // declined: its nodes may be in the class lists already; the visits skip them (fb != 0)
+            FuncIr r{}; r.def_node = dn; r.func = fidx; r.status = DS_FALLBACK; r.pad = f.misc[MI_WHY]; A.out[fidx] = r;
+            FnInfo I{}; I.dn = dn; I.nn = 0; gst(X.fninfo + fidx, I);
+            gst(X.fb + fidx, (uint32_t)f.misc[MI_WHY]);
+        }
     }
 }
 
-// every function starts as "declined": the count pass overwrites the ones it lowers
+// a ready list that was too small for its class (the regions hold every node of the class: never) is an internal error of the unit
+__global__ void k_flat_check(const uint32_t* __restrict__ ctl, uint32_t* __restrict__ status) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && ctl[CTL_LISTOVF]) atomicMax(status, (uint32_t)DS_INTERNAL_CAPACITY);
+}
+
+// every function starts as "declined": the flat passes overwrite the ones they lower
 __global__ void k_par_init(const opusfe_node* __restrict__ nodes, const uint32_t* __restrict__ def_nodes, uint32_t n_defs, const DefCnt* __restrict__ def_excl, FuncIr* __restrict__ out,
-                           uint32_t* __restrict__ n_bodies, const uint8_t* __restrict__ skip) {
+                           uint32_t* __restrict__ n_bodies, const uint8_t* __restrict__ skip, FnInfo* __restrict__ fninfo, uint32_t* __restrict__ fb) {
     const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= n_defs) return;
     const uint32_t dn = def_nodes[d];
@@ -1694,6 +1969,7 @@ __global__ void k_par_init(const opusfe_node* __restrict__ nodes, const uint32_t
     const bool body = k == D_Function && !(skip && skip[d]);      // (a skipped function is left like an extern: no blocks)
     FuncIr r{}; r.def_node = dn; r.func = def_excl[d].funcs; r.status = body ? (uint32_t)DS_FALLBACK : (uint32_t)DS_OK;
     out[r.func] = r;
+    if (fninfo) { fninfo[r.func] = FnInfo{}; fb[r.func] = 0; }
     if (body) atomicAdd(n_bodies, 1u);
 }
 

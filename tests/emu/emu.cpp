@@ -271,28 +271,64 @@ void emu_lower(EmuUnit& E) {
         uint32_t* dbo = exact<uint32_t>(cap[2] + 1); uint32_t* dc = exact<uint32_t>(cap[4]);
         TypeRec* dty = exact<TypeRec>(n_gtypes + cap[3]); SemErr* de = nullptr;
         memcpy(dty, gtypes, (size_t)n_gtypes * sizeof(TypeRec));
-        emu_launch(par::k_par_init, grid_for(n_defs, 256), 256, nodes, def_nodes, n_defs, (const DefCnt*)def_excl.data(), R->funcs.data(), &n_bodies, (const uint8_t*)nullptr);
+        std::vector<par::FnInfo> fninfo(n_funcs); std::vector<uint32_t> fbw(n_funcs);
+        emu_launch(par::k_par_init, grid_for(n_defs, 256), 256, nodes, def_nodes, n_defs, (const DefCnt*)def_excl.data(), R->funcs.data(), &n_bodies, (const uint8_t*)nullptr, fninfo.data(), fbw.data());
         par::ParArgs PA{};
         PA.def_nodes = def_nodes; PA.n_defs = n_defs; PA.n_nodes = n_nodes; PA.def_excl = def_excl.data(); PA.undefined_flag = undefined_flag.data(); PA.user_syms = &user_syms;
         PA.pp_base = pp_base; PA.out = R->funcs.data(); PA.status = lstatus;
         PA.counters = counters; PA.overflow = (uint32_t*)(counters + par::CTR_COUNT); PA.err_counter = (uint32_t*)(counters + par::CTR_COUNT + 1);
         PA.cap_vars = cap[0]; PA.cap_instrs = cap[1]; PA.cap_bbs = cap[2]; PA.cap_types = cap[3]; PA.cap_cargs = cap[4]; PA.cap_errs = ~0ull;     // (the dense diagnostics block below has the sparse capacity)
         PA.vars = dv; PA.instrs = di; PA.bb_offsets = dbo; PA.cargs = dc; PA.types_out = dty;
-        PA.list = nullptr; PA.n_list = n_defs; PA.nmax = getenv("EMU_PAR_NMAX") ? (uint32_t)atoi(getenv("EMU_PAR_NMAX")) : 2048u; PA.maxdef = getenv("EMU_PAR_MAXDEF") ? (uint32_t)atoi(getenv("EMU_PAR_MAXDEF")) : 256u; PA.climb = getenv("EMU_PAR_CLIMB") ? 1u : 0u;
+        PA.list = nullptr; PA.n_list = n_defs; PA.nmax = getenv("EMU_PAR_NMAX") ? (uint32_t)atoi(getenv("EMU_PAR_NMAX")) : 2048u; PA.maxdef = getenv("EMU_PAR_MAXDEF") ? (uint32_t)atoi(getenv("EMU_PAR_MAXDEF")) : 256u;
         S.types = gtypes;
         if (!seq_only) {
+            // the flat passes of lower_par.h in the product's order (run_lower), every list and per-node array an exact-size heap block
+            par::FlatArgs X{};
+            uint32_t* ctl = exact<uint32_t>(par::CTL_WORDS);
+            X.ctl = ctl; X.fninfo = fninfo.data(); X.fb = fbw.data();
+            emu_launch(par::k_flat_kind_hist, grid_for(n_nodes, 256), 256, nodes, n_nodes, ctl);
+            emu_launch(par::k_flat_offsets, 1, 1, ctl);
+            const uint32_t n_list = ctl[par::CTL_OFF + par::KC_ACTIVE];
+            X.st = exact<uint32_t>(n_nodes); X.ref = exact<uint32_t>(n_nodes); X.rvi = exact<uint32_t>(n_nodes); X.rt = exact<uint64_t>(n_nodes); X.cnt = exact<uint64_t>(2ull * n_nodes);
+            X.tail = exact<uint8_t>(2ull * n_nodes); X.pe = exact<uint16_t>(n_nodes); X.sz = exact<uint16_t>(n_nodes); X.cg = exact<uint16_t>(n_nodes); X.pa = exact<uint16_t>(n_nodes);
+            X.wnext = exact<uint16_t>(n_nodes); X.whead = exact<uint16_t>(n_nodes); X.fn_of = exact<uint32_t>(n_nodes);
+            X.order = exact<uint32_t>(n_list); X.wl0 = exact<uint32_t>(n_list); X.wl1 = exact<uint32_t>(n_list);
+            memset(X.fn_of, 0xFF, 4ull * n_nodes);
+            // (everything else a pass reads was written by an earlier pass: poison, so that a read of an unwritten word shows)
+            memset(X.st, 0xA5, 4ull * n_nodes); memset(X.ref, 0xA5, 4ull * n_nodes); memset(X.whead, 0xA5, 2ull * n_nodes); memset(X.wnext, 0xA5, 2ull * n_nodes);
+            memset(X.rt, 0xFF, 8ull * n_nodes); memset(X.cnt, 0, 16ull * n_nodes); memset(X.tail, 0, 2ull * n_nodes); memset(X.rvi, 0, 4ull * n_nodes);      // as run_lower clears them
             const size_t lds = par::lds_bytes(PA.nmax, PA.maxdef, 1);
             par::g_emu_lds = (uint32_t*)malloc(lds);
             memset(par::g_emu_lds, 0xA5, lds);
-            emu_launch(par::k_lower_par, n_defs, 1, S, PA);
+            emu_launch(par::k_flat_pre, n_defs, 1, S, PA, X);
             free(par::g_emu_lds); par::g_emu_lds = nullptr;
+#define EMU_CLASSES(K, ...) do { emu_launch(par::K<0>, 1, 1, __VA_ARGS__); emu_launch(par::K<1>, 1, 1, __VA_ARGS__); emu_launch(par::K<2>, 1, 1, __VA_ARGS__); emu_launch(par::K<3>, 1, 1, __VA_ARGS__); \
+                                     emu_launch(par::K<4>, 1, 1, __VA_ARGS__); emu_launch(par::K<5>, 1, 1, __VA_ARGS__); emu_launch(par::K<6>, 1, 1, __VA_ARGS__); emu_launch(par::K<7>, 1, 1, __VA_ARGS__); } while (0)
+            uint32_t rounds = 0;
+            for (uint32_t r = 0; r < par::FLAT_MAX_ROUNDS; r++) {
+                uint32_t any = 0;
+                for (uint32_t c = 0; c < par::KC_ACTIVE; c++) any |= ctl[par::CTL_ROUNDS + r * par::KC_ACTIVE + c];
+                if (!any) break;
+                // (as run_lower: the class kernels while many nodes are ready, the one kernel that holds every class for the tail)
+                uint64_t ready = 0;
+                for (uint32_t c = 0; c < par::KC_ACTIVE; c++) ready += ctl[par::CTL_ROUNDS + r * par::KC_ACTIVE + c];
+                if (ready <= (getenv("EMU_FLAT_TAIL") ? (uint64_t)atoi(getenv("EMU_FLAT_TAIL")) : 64u)) emu_launch(par::k_flat_count<par::KC_ANY>, 1, 1, S, PA, X, r);
+                else EMU_CLASSES(k_flat_count, S, PA, X, r);
+                rounds = r + 1;
+            }
+            emu_launch(par::k_flat_scan, grid_for(n_defs, 256), 256, S, PA, X);
+            emu_launch(par::k_flat_rv, 1, 1, PA, X);
+            EMU_CLASSES(k_flat_emit, S, PA, X);
+            if (ctl[par::CTL_LISTOVF]) lstatus[0] = DS_INTERNAL_CAPACITY;
+            if (getenv("EMU_VERBOSE")) fprintf(stderr, "flat lowering: %u rounds, %u listed nodes of %u\n", rounds, n_list, n_nodes);
+            free(ctl); free(X.st); free(X.ref); free(X.rvi); free(X.rt); free(X.cnt); free(X.tail); free(X.pe); free(X.sz); free(X.cg); free(X.pa); free(X.wnext); free(X.whead); free(X.fn_of);
+            free(X.order); free(X.wl0); free(X.wl1);
         }
         emu_launch(k_fb_mark, grid_for(n_defs, 256), 256, (const FuncIr*)R->funcs.data(), n_funcs, def_nodes, n_defs, n_nodes, (const DefCnt*)def_excl.data(), nodes, fb_flag.data(), fbx.data());
         FbIdx fbt{0, 0};
         for (uint32_t i = 0; i < n_funcs; i++) { FbIdx c = fbx[i]; fbx[i] = fbt; fbt = OpAddFbIdx()(fbt, c); }
         const uint32_t fb_nodes = fbt.nodes, fb_funcs = fbt.funcs;
         R->n_fallback = fb_funcs;
-        if (getenv("EMU_VERBOSE")) fprintf(stderr, "type fixpoint: %llu functions, %.1f rounds each, %.1f rounds per active node (node-weighted), active %llu of %llu nodes\n", (unsigned long long)par::g_emu_stat[0], (double)par::g_emu_stat[1] / (par::g_emu_stat[0] ? par::g_emu_stat[0] : 1), (double)par::g_emu_stat[2] / (par::g_emu_stat[3] ? par::g_emu_stat[3] : 1), (unsigned long long)par::g_emu_stat[3], (unsigned long long)par::g_emu_stat[4]);
         if (getenv("EMU_VERBOSE")) { fprintf(stderr, "functions lowered by the sequential machine: %u of %u\n", fb_funcs, n_funcs); for (auto& fr : R->funcs) if (fr.status == par::DS_FALLBACK) fprintf(stderr, "  function %u (node %u): declined at lower_par.h:%u\n", fr.func, fr.def_node, fr.pad); }
         if (getenv("EMU_REQUIRE_PAR") && fb_funcs) { fprintf(stderr, "emu: %u functions fell back\n", fb_funcs); u.status = OPUSFE_ERR_INTERNAL; cleanup_only = true; }
         LowerBuffers B{};
