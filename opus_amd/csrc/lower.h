@@ -1732,21 +1732,20 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
         HIP_TRY(hipMemsetAsync(ctx->d_status + WL_BODIES, 0, sizeof(uint32_t), st));
         HIP_TRY(hipMemcpyAsync(R->d_types, gtypes, (size_t)n_gtypes * sizeof(TypeRec), hipMemcpyDeviceToDevice, st));
         TempList tmp2(ctx);       // the machine's sparse regions and the per-node state of the flat passes live for one attempt
-        // per-node state of the flat passes (lower_par.h FlatArgs): 58 B per node + three lists of 4 B per node
+        // per-node state of the flat passes (lower_par.h FlatArgs): 32 + 16 + 2 + 2 + 4 B per node + two lists of 4 B per node
         par::FlatArgs X{};
-        const uint64_t n_list = (uint64_t)n_nodes + 64 * par::KC_ACTIVE;
+        const uint64_t n_list = (uint64_t)n_nodes + n_nodes / 4 + 1024;      // every listed node, and stage 1 of every `for` (a loop is four nodes or more)
         X.ctl = tmp2.get<uint32_t>(par::CTL_WORDS);
         X.fninfo = tmp2.get<par::FnInfo>(n_funcs); X.fb = tmp2.get<uint32_t>(n_funcs);
-        X.st = tmp2.get<uint32_t>(n_nodes); X.ref = tmp2.get<uint32_t>(n_nodes); X.rvi = tmp2.get<uint32_t>(n_nodes); X.rt = tmp2.get<uint64_t>(n_nodes); X.cnt = tmp2.get<uint64_t>(2ull * n_nodes);
-        X.tail = tmp2.get<uint8_t>(2ull * n_nodes); X.pe = tmp2.get<uint16_t>(n_nodes); X.sz = tmp2.get<uint16_t>(n_nodes); X.cg = tmp2.get<uint16_t>(n_nodes); X.pa = tmp2.get<uint16_t>(n_nodes);
-        X.wnext = tmp2.get<uint16_t>(n_nodes); X.whead = tmp2.get<uint16_t>(n_nodes); X.fn_of = tmp2.get<uint32_t>(n_nodes);
-        X.order = tmp2.get<uint32_t>(n_list); X.wl0 = tmp2.get<uint32_t>(n_list); X.wl1 = tmp2.get<uint32_t>(n_list);
+        X.rec = tmp2.get<par::NodeRec>(n_nodes); X.cnt = tmp2.get<uint64_t>(2ull * n_nodes); X.tail = tmp2.get<uint8_t>(2ull * n_nodes); X.cg = tmp2.get<uint16_t>(n_nodes);
+        X.key = tmp2.get<uint16_t>(n_nodes); X.key1 = tmp2.get<uint16_t>(n_nodes);
+        X.order = tmp2.get<uint32_t>(n_list); X.sched = tmp2.get<uint32_t>(n_list);
+        HIP_TRY(hipMemsetAsync(X.key, 0xFF, (size_t)n_nodes * sizeof(uint16_t), st));      // NONE16: not listed
+        HIP_TRY(hipMemsetAsync(X.key1, 0xFF, (size_t)n_nodes * sizeof(uint16_t), st));
         HIP_TRY(hipMemsetAsync(X.ctl, 0, par::CTL_WORDS * sizeof(uint32_t), st));
-        HIP_TRY(hipMemsetAsync(X.fn_of, 0xFF, (size_t)n_nodes * sizeof(uint32_t), st));
-        HIP_TRY(hipMemsetAsync(X.rt, 0xFF, (size_t)n_nodes * sizeof(uint64_t), st));      // DESC_NONE
+        HIP_TRY(hipMemsetAsync(X.rec, 0xFF, (size_t)n_nodes * sizeof(par::NodeRec), st));      // result type none, function NONE
         HIP_TRY(hipMemsetAsync(X.cnt, 0, (size_t)n_nodes * 2 * sizeof(uint64_t), st));
         HIP_TRY(hipMemsetAsync(X.tail, 0, (size_t)n_nodes * 2, st));
-        HIP_TRY(hipMemsetAsync(X.rvi, 0, (size_t)n_nodes * sizeof(uint32_t), st));
         LAUNCH(ctx, "par_init", par::k_par_init, grid_for(n_defs, 256), 256, u->d_nodes, u->d_def_nodes, n_defs, def_excl, R->d_funcs, ctx->d_status + WL_BODIES, (const uint8_t*)def_skip, X.fninfo, X.fb);
         par::ParArgs PA{};
         PA.def_nodes = u->d_def_nodes; PA.n_defs = n_defs; PA.n_nodes = n_nodes; PA.def_excl = def_excl; PA.undefined_flag = undefined_flag; PA.user_syms = user_syms;
@@ -1809,8 +1808,6 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
             // k_flat_pre: one launch per half-octave size class (scan.h order_class_of_size): the LDS a workgroup reserves is sized for the
             // largest function of its class, so at most a third of it is unused.  Functions of 2048 nodes and more, and the ones the
             // flat path declines, go through the sequential machine.
-            LAUNCH(ctx, "flat_kind_hist", par::k_flat_kind_hist, std::min<unsigned>(grid_for(n_nodes, 256), 4096u), 256, (const opusfe_node*)u->d_nodes, n_nodes, X.ctl);
-            LAUNCH(ctx, "flat_offsets", par::k_flat_offsets, 1, 64, X.ctl);
             static const char* const NAMES[12] = {"lower_pre_64", "lower_pre_96", "lower_pre_128", "lower_pre_192", "lower_pre_256", "lower_pre_384", "lower_pre_512",
                                                   "lower_pre_768", "lower_pre_1024", "lower_pre_1536", "lower_pre_2048", "lower_pre"};
             const uint32_t c_top = order_class_of_size(2047), c_small = order_class_of_size(63);     // classes above c_top: sequential machine
@@ -1824,7 +1821,7 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
                 a.nmax = (uint32_t)order_class_lo(c + 1) - 1u; if (a.nmax < 63) a.nmax = 63;
                 a.maxdef = a.nmax / 8 < 32 ? 32 : a.nmax / 8;
                 // any number of waves per workgroup: the one that keeps the most functions resident among those that fill the
-                // CU's wave slots to within one wave (4 SIMDs x OPUSFE_PAR_WAVES; LDS is allocated in 1280-byte granules)
+                // CU's wave slots to within one wave (4 SIMDs x OPUSFE_PAR_WAVES = 32; LDS is allocated in 1280-byte granules)
                 uint32_t best_waves = 0;
                 uint32_t resident[17] = {0};
                 for (uint32_t w = 1; w <= 16; w++) {
@@ -1843,47 +1840,71 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
                 HIP_TRY(hipGetLastError());
                 prof_end(ctx);
             }
-            // The rounds of the count pass: one launch per kind class and round over that round's ready list.  How many rounds there
-            // are is the longest dependency chain of any function; the host looks at the list lengths every few rounds.
-            const unsigned rgrid = std::min<unsigned>(grid_for(n_nodes, 256), 2048u);
-            auto launch_classes = [&](auto kernel_of_class, auto... extra) {
-                kernel_of_class(std::integral_constant<int, 0>(), extra...); kernel_of_class(std::integral_constant<int, 1>(), extra...);
-                kernel_of_class(std::integral_constant<int, 2>(), extra...); kernel_of_class(std::integral_constant<int, 3>(), extra...);
-                kernel_of_class(std::integral_constant<int, 4>(), extra...); kernel_of_class(std::integral_constant<int, 5>(), extra...);
-                kernel_of_class(std::integral_constant<int, 6>(), extra...); kernel_of_class(std::integral_constant<int, 7>(), extra...);
-            };
-            auto count_round = [&](auto cls, uint32_t r) {
-                hipLaunchKernelGGL(par::k_flat_count<decltype(cls)::value>, dim3(rgrid), dim3(256), 0, st, S, PA, X, r);
-            };
-            uint32_t hcnt[par::KC_ACTIVE];
-            uint32_t rounds_run = 0;
-            bool tail = false;      // few ready nodes left: one small launch per round that holds every class
-            for (uint32_t r = 0; r < par::FLAT_MAX_ROUNDS;) {
-                const uint32_t chunk = tail ? 32u : 4u;
-                prof_begin(ctx, tail ? "lower_count_tail" : "lower_count");
-                for (uint32_t k = 0; k < chunk && r < par::FLAT_MAX_ROUNDS; k++, r++) {
-                    if (tail) hipLaunchKernelGGL(par::k_flat_count<par::KC_ANY>, dim3(64), dim3(256), 0, st, S, PA, X, r);
-                    else launch_classes(count_round, r);
-                }
+            // The schedule: every node's (round, class) bin was written by k_flat_pre; a counting sort makes the lists of the count pass.
+            {
+                const uint32_t per_block = 1u << 16;
+                const unsigned sgrid = grid_for(n_nodes, per_block);
+                const size_t slds = (size_t)(par::SCHED_BINS + par::KC_ACTIVE) * sizeof(uint32_t);
+                HIP_TRY(hipFuncSetAttribute((const void*)par::k_sched_pass<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
+                HIP_TRY(hipFuncSetAttribute((const void*)par::k_sched_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
+                prof_begin(ctx, "sched_hist");
+                hipLaunchKernelGGL(par::k_sched_pass<false>, dim3(sgrid), dim3(1024), slds, st, X, n_nodes, per_block, (uint32_t)n_list);
                 HIP_TRY(hipGetLastError());
                 prof_end(ctx);
-                rounds_run = r;
-                HIP_TRY(hipMemcpyAsync(hcnt, X.ctl + par::CTL_ROUNDS + (size_t)r * par::KC_ACTIVE, sizeof hcnt, hipMemcpyDeviceToHost, st));
-                HIP_TRY(hipStreamSynchronize(st));
-                prof_collect(ctx);
-                uint64_t ready = 0;
-                for (uint32_t c = 0; c < par::KC_ACTIVE; c++) ready += hcnt[c];
-                if (!ready) break;
-                tail = ready <= (1u << 16);
+                LAUNCH(ctx, "sched_scan", par::k_sched_scan, 1, 1024, X.ctl);
+                prof_begin(ctx, "sched_scatter");
+                hipLaunchKernelGGL(par::k_sched_pass<true>, dim3(sgrid), dim3(1024), slds, st, X, n_nodes, per_block, (uint32_t)n_list);
+                HIP_TRY(hipGetLastError());
+                prof_end(ctx);
             }
+            // The count pass: one launch per (round, class) of the schedule, in round order; a round with few nodes is one launch
+            // of the kernel that holds every class.  The host reads the table of list offsets once and knows every launch.
+            ctx->sched_off.resize(par::SCHED_BINS + 1);
+            // (the cursors: after the scatter, cursor[b] = the END of bin b, i.e. the exclusive offsets shifted by one bin; the offsets themselves are CTL_BINS)
+            HIP_TRY(hipMemcpyAsync(ctx->sched_off.data(), X.ctl + par::CTL_BINS, (par::SCHED_BINS + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            prof_collect(ctx);
+            const uint32_t* off = ctx->sched_off.data();
+            const uint32_t total = off[par::FLAT_MAX_ROUNDS * par::KC_ACTIVE];      // (behind it: the chained nodes, which no launch starts from)
+            auto count_class = [&](auto cls, uint32_t begin, uint32_t n) {
+                hipLaunchKernelGGL(par::k_flat_count<decltype(cls)::value>, dim3(std::min<unsigned>(grid_for(n, 256), 4096u)), dim3(256), 0, st, S, PA, X, begin, n);
+            };
+            uint32_t rounds_run = 0;
+            static const uint32_t any_below = getenv("OPUSFE_ANY_BELOW") ? (uint32_t)atoi(getenv("OPUSFE_ANY_BELOW")) : 4096u;      // TEMPORARY (tuning)
+            prof_begin(ctx, "lower_count");
+            for (uint32_t r = 0; r < par::FLAT_MAX_ROUNDS; r++) {
+                const uint32_t lo = off[r * par::KC_ACTIVE], hi = off[(r + 1) * par::KC_ACTIVE];
+                if (lo == total) break;
+                if (hi == lo) continue;
+                rounds_run = r + 1;
+                if (hi - lo <= any_below) { hipLaunchKernelGGL(par::k_flat_count<par::KC_ANY>, dim3(grid_for(hi - lo, 256)), dim3(256), 0, st, S, PA, X, lo, hi - lo); continue; }
+                const uint32_t* o = off + r * par::KC_ACTIVE;
+                if (o[1] > o[0]) count_class(std::integral_constant<int, 0>(), o[0], o[1] - o[0]);
+                if (o[2] > o[1]) count_class(std::integral_constant<int, 1>(), o[1], o[2] - o[1]);
+                if (o[3] > o[2]) count_class(std::integral_constant<int, 2>(), o[2], o[3] - o[2]);
+                if (o[4] > o[3]) count_class(std::integral_constant<int, 3>(), o[3], o[4] - o[3]);
+                if (o[5] > o[4]) count_class(std::integral_constant<int, 4>(), o[4], o[5] - o[4]);
+                if (o[6] > o[5]) count_class(std::integral_constant<int, 5>(), o[5], o[6] - o[5]);
+                if (o[7] > o[6]) count_class(std::integral_constant<int, 6>(), o[6], o[7] - o[6]);
+                if (o[8] > o[7]) count_class(std::integral_constant<int, 7>(), o[7], o[8] - o[7]);
+            }
+            HIP_TRY(hipGetLastError());
+            prof_end(ctx);
             R->n_rounds = rounds_run;
-            if (getenv("OPUSFE_ROUNDS_DUMP")) {
-                std::vector<uint32_t> hc((size_t)(rounds_run + 1) * par::KC_ACTIVE);
-                HIP_TRY(hipMemcpy(hc.data(), X.ctl + par::CTL_ROUNDS, hc.size() * 4, hipMemcpyDeviceToHost));
-                for (uint32_t r = 0; r <= rounds_run; r++) { uint64_t t = 0; for (int c = 0; c < 8; c++) t += hc[r * 8 + c]; if (r < 48 || r % 32 == 0) fprintf(stderr, "round %u: %llu ready (%u %u %u %u %u %u %u %u)\n", r, (unsigned long long)t, hc[r*8], hc[r*8+1], hc[r*8+2], hc[r*8+3], hc[r*8+4], hc[r*8+5], hc[r*8+6], hc[r*8+7]); }
-            }
-            LAUNCH(ctx, "lower_scan", par::k_flat_scan, grid_for((uint64_t)n_defs * 64, 256), 256, S, PA, X);
+            IrCnt* fn_tot = tmp2.get<IrCnt>(n_funcs + 1);      // per function: its totals, then (exclusive scan) its place; [n_funcs] = the sum
+            HIP_TRY(hipMemsetAsync(fn_tot, 0, ((size_t)n_funcs + 1) * sizeof(IrCnt), st));
+            LAUNCH(ctx, "lower_scan", par::k_flat_scan, grid_for((uint64_t)n_defs * 64, 256), 256, S, PA, X, fn_tot);
+            prof_begin(ctx, "lower_scan_funcs");
+            device_scan<true>(fn_tot, fn_tot, n_funcs, OpAddIrCnt(), IrCnt{0, 0, 0, 0, 0, 0}, (IrCnt*)scan_tmp, fn_tot + n_funcs, st);
+            prof_end(ctx);
+            LAUNCH(ctx, "lower_bases", par::k_flat_bases, grid_for(n_funcs, 256), 256, PA, X, (const IrCnt*)fn_tot, (const IrCnt*)(fn_tot + n_funcs), n_funcs);
             LAUNCH(ctx, "lower_rv", par::k_flat_rv, std::min<unsigned>(grid_for(n_nodes, 256), 4096u), 256, PA, X);
+            auto launch_classes = [&](auto kernel_of_class) {
+                kernel_of_class(std::integral_constant<int, 0>()); kernel_of_class(std::integral_constant<int, 1>()); kernel_of_class(std::integral_constant<int, 2>());
+                kernel_of_class(std::integral_constant<int, 3>()); kernel_of_class(std::integral_constant<int, 4>()); kernel_of_class(std::integral_constant<int, 5>());
+                kernel_of_class(std::integral_constant<int, 6>()); kernel_of_class(std::integral_constant<int, 7>());
+            };
+            const unsigned rgrid = std::min<unsigned>(grid_for(n_nodes, 256), 2048u);
             auto emit_class = [&](auto cls) {
                 hipLaunchKernelGGL(par::k_flat_emit<decltype(cls)::value>, dim3(rgrid), dim3(256), 0, st, S, PA, X);
             };

@@ -98,17 +98,27 @@ enum { KC_VARIABLE = 0, KC_INTEGER = 1, KC_OPERATOR = 2, KC_SIMPLE = 3, KC_STATE
 
 // The unit-wide per-node state of the flat passes (temporaries of one lowering; index = node index in the unit).
 struct FnInfo { uint32_t dn, nn, nargs, ret, sym_mix, pad0, pad1, pad2; };     // what a lane needs of its function (nn == 0: not on the flat path)
-enum : uint32_t { CTL_OFF = 0 /* KC_ACTIVE + 1 class offsets into the lists */, CTL_ORDER = 16 /* KC_ACTIVE counts: all nodes of a class */, CTL_DBG = 30, CTL_LISTOVF = 31 /* a list region was too small (never) */, CTL_HIST = 32 /* upper bounds by kind */,
-                  CTL_ROUNDS = 64 /* (MAX_ROUNDS + 2) x KC_ACTIVE list lengths: round r reads [r], appends to [r + 1] */, FLAT_MAX_ROUNDS = 2048,
-                  CTL_WORDS = CTL_ROUNDS + (FLAT_MAX_ROUNDS + 2) * KC_ACTIVE };
+// ctl[]: control words of one lowering.  The schedule of the count pass is a table of SCHED_BINS list lengths / offsets, one per
+// (round, kind class): bin = round * KC_ACTIVE + class.
+// (the last round of the table is no round: it holds the CHAINED nodes, which the count pass reaches through their operand and the
+// other passes through the class list)
+enum : uint32_t { FLAT_MAX_ROUNDS = 2047, SCHED_BINS = (FLAT_MAX_ROUNDS + 1) * KC_ACTIVE,
+                  CTL_OFF = 0 /* KC_ACTIVE + 1 class offsets into `order` */, CTL_ORDER = 16 /* KC_ACTIVE counts: all nodes of a class */, CTL_OCUR = 32 /* KC_ACTIVE cursors of the class list's scatter */, CTL_NSTAGE1 = 48 /* stage-1 entries: in the bins of KC_CONTROL, not in the class list */, CTL_DBG = 30, CTL_LISTOVF = 31 /* a list region was too small (never) */,
+                  CTL_BINS = 64 /* SCHED_BINS + 1: lengths, then exclusive offsets, of the schedule's bins */,
+                  CTL_CURSOR = CTL_BINS + SCHED_BINS + 64 /* SCHED_BINS: where the next block's nodes of a bin go */, CTL_WORDS = CTL_CURSOR + SCHED_BINS + 64 };
 enum : uint32_t { FB_NOFIT = 0xFFFFFFFEu };   // fb[]: the function counted, but its place in a result array is beyond the array (the host runs again)
+// What the visits read and write of a node, in ONE 32-byte record (one memory sector per node and per operand instead of one per field):
+// rt = type of the node's result (def slots: of the variable), st = state word, ref = name resolution / literal suffix / type id,
+// rvi = who created the result variable (then its id), pe = ENTER position in the Euler tour, sz = subtree size, pa = parent,
+// fn = function index (NONE: not a node of a function on the flat path).  The host fills the array with 0xFF: rt = none, fn = NONE.
+struct NodeRec { uint64_t rt; uint32_t st, ref, rvi; uint16_t pe, sz, pa, loc /* index in its function: node - loc = the function's first node */; uint32_t fn; };
+static_assert(sizeof(NodeRec) == 32, "NodeRec is one 32-byte sector");
 struct FlatArgs {
-    uint32_t* st; uint32_t* ref; uint32_t* rvi; uint64_t* rt; uint64_t* cnt; uint8_t* tail;
-    uint16_t* pe; uint16_t* sz; uint16_t* cg; uint16_t* pa; uint16_t* wnext; uint16_t* whead;
-    uint32_t* fn_of;          // function index of every node of a function on the flat path, else NONE
+    NodeRec* rec; uint64_t* cnt; uint8_t* tail; uint16_t* cg;
+    uint16_t* key; uint16_t* key1;     // schedule bin of every node (NONE16: not listed); key1: the bin of stage 1 of a `for` node
     FnInfo* fninfo; uint32_t* fb;      // per function: fb != 0 = declined (source line of the reason)
-    uint32_t* order;          // all nodes that are lowered, by kind class (regions CTL_OFF): the emit pass and the first round go through it
-    uint32_t* wl0; uint32_t* wl1;      // the ready lists of the rounds, same regions, used alternately
+    uint32_t* order;          // all nodes that are lowered, by kind class (regions CTL_OFF): the emit pass goes through it
+    uint32_t* sched;          // the same nodes by (round, class): the count pass goes through one round after the other
     uint32_t* ctl;
 };
 
@@ -133,6 +143,7 @@ enum { MAX_ARGS = 16, MAX_CALL_ARGS = 8 };
 
 // per-node state bits (st[])
 enum : uint32_t { ST_DONE = 1u, ST_STAGE1 = 2u /* for: the loop variable has its type */, ST_DIV = 4u, ST_DEAD = 8u, ST_CTX = 16u /* rank, depth and context assigned */, ST_HASBREAK = 32u, ST_CLAIM = 64u /* a lane is lowering it */,
+                  ST_CHAINED = 1u << 15 /* lowered by the lane that lowers its one operand, right behind it */,
                   ST_MODE_E = 1u << 8, ST_MODE_P = 2u << 8, ST_MODE_MASK = 3u << 8, ST_PT_SHIFT = 10, ST_DEREF = 1u << 12, ST_MUSTLV = 1u << 13,
                   ST_EXP_SHIFT = 16, ST_EXP_MASK = 15u << 16,
                   ST_PEND_SHIFT = 20, ST_PEND_ONE = 1u << 20, ST_PEND_MASK = 0xFFFu << 20 /* operands that are not lowered yet (type fixpoint) */ };
@@ -177,6 +188,11 @@ template <class T> struct GArr {
     G_AS T* p; uint32_t base;
     __device__ __forceinline__ G_AS T& operator[](uint32_t i) const { return p[base + i]; }
 };
+// a field of the nodes' records (NodeRec)
+template <class T, int OFF> struct RecArr {
+    G_AS uint8_t* p; uint32_t base;
+    __device__ __forceinline__ G_AS T& operator[](uint32_t i) const { return *(G_AS T*)(p + (((size_t)base + i) << 5) + OFF); }
+};
 #define NONE16 0xFFFFu
 struct NodeKn {      // kind | sub << 8 | nchild << 16 (the first word of the node record)
     const G_AS opusfe_node* p; uint32_t base;
@@ -189,7 +205,8 @@ struct Fn {
     SemView S; ParArgs A;
     uint32_t dn, nn, fidx, nargs, ret; uint64_t user_syms; uint32_t sym_mix /* file mix of symbol keys (sem.h NameKey) */;
     bool fb, emitting; G_AS uint32_t* fbp;     // fb: this lane declined the function (fbp[fidx] tells the other lanes)
-    GArr<uint64_t> rt, cnt; GArr<uint32_t> st, ref, rvi; GArr<uint16_t> pe, sz, cg, pa; GArr<uint8_t> tail;
+    RecArr<uint64_t, 0> rt; RecArr<uint32_t, 8> st; RecArr<uint32_t, 12> ref; RecArr<uint32_t, 16> rvi; RecArr<uint16_t, 20> pe; RecArr<uint16_t, 22> sz; RecArr<uint16_t, 24> pa;
+    GArr<uint64_t> cnt; GArr<uint16_t> cg; GArr<uint8_t> tail;
     NodeKn kn; NodeFc fc; NodeNx nx; NodePay pay;
     // emit bases
     uint32_t var_base, instr_base, bb_base, type_base, carg_base, n_vars_tot, n_instrs_tot, n_bbs_tot, n_types_tot, n_cargs_tot;
@@ -1246,51 +1263,21 @@ __host__ __device__ __forceinline__ uint32_t kind_class_of(uint32_t s, uint8_t k
     if (k == E_NamedCall) return KC_CALL;
     return KC_OTHER;
 }
-// upper bound of the same from the kind alone (sizes of the list regions); S_For can be listed twice in one round (stage 1, visit)
-__host__ __device__ __forceinline__ uint32_t kind_class_bound(uint8_t k) {
-    if (k == S_Expression || k == S_Assignment || k == S_VariableDefinition || k == S_Return) return KC_STATEMENT;
-    if (k == S_If || k == S_While || k == S_For || k == S_Break || k == S_Continue || k == X_Block || k == D_Function || k == X_FieldInit) return KC_CONTROL;
-    if (k < E_Integer || k > E_Parentheses) return KC_NONE;
-    return kind_class_of(ST_MODE_E, k);
-}
-__global__ void k_flat_kind_hist(const opusfe_node* __restrict__ nodes, uint32_t n_nodes, uint32_t* __restrict__ ctl) {
-#ifdef OPUSFE_EMU
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= n_nodes) return;
-    const uint8_t k = nodes[g].kind; const uint32_t c = kind_class_bound(k);
-    if (c < KC_ACTIVE) ctl[CTL_HIST + c] += k == S_For ? 2u : 1u;
-#else
-    __shared__ uint32_t h[KC_ACTIVE];
-    if (threadIdx.x < KC_ACTIVE) h[threadIdx.x] = 0;
-    __syncthreads();
-    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_nodes; g += (uint64_t)gridDim.x * blockDim.x) {
-        const uint8_t k = nodes[g].kind; const uint32_t c = kind_class_bound(k);
-        if (c < KC_ACTIVE) atomicAdd(&h[c], k == S_For ? 2u : 1u);
-    }
-    __syncthreads();
-    if (threadIdx.x < KC_ACTIVE && h[threadIdx.x]) atomicAdd(ctl + CTL_HIST + threadIdx.x, h[threadIdx.x]);
-#endif
-}
-__global__ void k_flat_offsets(uint32_t* __restrict__ ctl) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    uint32_t run = 0;
-    for (uint32_t c = 0; c < KC_ACTIVE; c++) { ctl[CTL_OFF + c] = run; run += (ctl[CTL_HIST + c] + 63u) & ~63u; }
-    ctl[CTL_OFF + KC_ACTIVE] = run;
-}
-
 // ---- the lane's function ----------------------------------------------------------------------------------------------------
 // false: the function is off the flat path (declined by an earlier visit)
 __device__ __forceinline__ bool make_fn(Fn& f, const SemView& S, const ParArgs& A, const FlatArgs& X, uint32_t g, uint32_t* local, bool emitting) {
-    const uint32_t fidx = gld(X.fn_of + g);
-    if (fidx == OPUSFE_NONE) return false;                   // (a node of a function that was declined while it was being listed)
+    // (only nodes of functions that k_flat_pre handed over are ever listed; the record itself says where the function starts, so
+    // the loads of the operands' records do not wait for the function's)
+    const uint64_t w3 = gld((const uint64_t*)(X.rec + g) + 3);
+    const uint32_t fidx = (uint32_t)(w3 >> 32), loc = (uint32_t)(w3 >> 16) & 0xFFFFu;
     const FnInfo I = gld(X.fninfo + fidx);
-    f.S = S; f.A = A; f.dn = I.dn; f.nn = I.nn; f.fidx = fidx; f.nargs = I.nargs; f.ret = I.ret; f.sym_mix = I.sym_mix; f.user_syms = *A.user_syms;
+    f.S = S; f.A = A; f.dn = g - loc; f.nn = I.nn; f.fidx = fidx; f.nargs = I.nargs; f.ret = I.ret; f.sym_mix = I.sym_mix; f.user_syms = *A.user_syms;
     f.fb = false; f.emitting = emitting; f.fbp = (G_AS uint32_t*)X.fb;
-    const uint32_t dn = I.dn;
-    f.rt = GArr<uint64_t>{(G_AS uint64_t*)X.rt, dn}; f.cnt = GArr<uint64_t>{(G_AS uint64_t*)X.cnt, 2u * dn};
-    f.st = GArr<uint32_t>{(G_AS uint32_t*)X.st, dn}; f.ref = GArr<uint32_t>{(G_AS uint32_t*)X.ref, dn}; f.rvi = GArr<uint32_t>{(G_AS uint32_t*)X.rvi, dn};
-    f.pe = GArr<uint16_t>{(G_AS uint16_t*)X.pe, dn}; f.sz = GArr<uint16_t>{(G_AS uint16_t*)X.sz, dn}; f.cg = GArr<uint16_t>{(G_AS uint16_t*)X.cg, dn}; f.pa = GArr<uint16_t>{(G_AS uint16_t*)X.pa, dn};
-    f.tail = GArr<uint8_t>{(G_AS uint8_t*)X.tail, 2u * dn};
+    const uint32_t dn = g - loc;
+    G_AS uint8_t* const rp = (G_AS uint8_t*)X.rec;
+    f.rt = RecArr<uint64_t, 0>{rp, dn}; f.st = RecArr<uint32_t, 8>{rp, dn}; f.ref = RecArr<uint32_t, 12>{rp, dn}; f.rvi = RecArr<uint32_t, 16>{rp, dn};
+    f.pe = RecArr<uint16_t, 20>{rp, dn}; f.sz = RecArr<uint16_t, 22>{rp, dn}; f.pa = RecArr<uint16_t, 24>{rp, dn};
+    f.cnt = GArr<uint64_t>{(G_AS uint64_t*)X.cnt, 2u * dn}; f.cg = GArr<uint16_t>{(G_AS uint16_t*)X.cg, dn}; f.tail = GArr<uint8_t>{(G_AS uint8_t*)X.tail, 2u * dn};
     const G_AS opusfe_node* nd = (const G_AS opusfe_node*)S.nodes.ptr();
     f.kn = NodeKn{nd, dn}; f.fc = NodeFc{nd, dn}; f.nx = NodeNx{nd, dn}; f.pay = NodePay{nd, dn};
     f.var_base = f.instr_base = f.bb_base = f.type_base = f.carg_base = 0;
@@ -1299,147 +1286,150 @@ __device__ __forceinline__ bool make_fn(Fn& f, const SemView& S, const ParArgs& 
     return gld(X.fb + fidx) == 0;
 }
 
-// ---- ready lists ------------------------------------------------------------------------------------------------------------
-// Appends node g to the list of class c that the next round reads (c >= KC_ACTIVE: nothing to append).  Called by ALL lanes of a
-// wave in converged control flow — the lanes that append to the same list share one atomic.  (Ballots inside divergent branches
-// are not an option: the compiler may hoist a convergent operation out of a branch or loop, and the mask then counts lanes that
-// never reached it.)
-__device__ __forceinline__ void wave_push(const FlatArgs& X, uint32_t* out, uint32_t* out_cnt, uint32_t c, uint32_t g) {
-#ifdef OPUSFE_EMU
-    if (c >= KC_ACTIVE) return;
-    const uint32_t at = out_cnt[c]++;
-    if (at >= X.ctl[CTL_OFF + c + 1] - X.ctl[CTL_OFF + c]) { fprintf(stderr, "emu: ready list of class %u overflows\n", c); abort(); }
-    out[X.ctl[CTL_OFF + c] + at] = g;
-#else
-    const uint32_t lane = __lane_id();
-    for (uint32_t k = 0; k < KC_ACTIVE; k++) {
-        const bool mine = c == k;
-        const uint64_t m = __ballot(mine);
-        if (m == 0) continue;                                // (uniform)
-        const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), n = (uint32_t)__popcll(m);
-        const int leader = __ffsll((long long)m) - 1;
-        uint32_t base = 0;
-        if (mine && rank == 0) base = atomicAdd(out_cnt + k, n);
-        base = (uint32_t)__shfl((int)base, leader);
-        if (mine) {
-            const uint32_t off = gld(X.ctl + CTL_OFF + k), cap = gld(X.ctl + CTL_OFF + k + 1) - off;
-            if (base + rank < cap) gst(out + off + base + rank, g); else atomicMax(X.ctl + CTL_LISTOVF, 1u);     // (cannot happen: the regions hold every node of the class)
-        }
-    }
-#endif
-}
-// what a finished node hands to the next round: up to two nodes that became ready (class, node), and a chain of waiters to release
-struct Ready { uint32_t c0, g0, c1, g1, waiters, dn; };
-// one operand (or awaited definition) of `node` is done: its class when that was the last one, else KC_NONE
-__device__ __forceinline__ uint32_t release(Fn& f, uint32_t node) {
-    const uint32_t old = at_sub(&f.st[node], (uint32_t)ST_PEND_ONE);
-    if ((old & ST_PEND_MASK) != ST_PEND_ONE) return KC_NONE;
-    return kind_class_of(old, KIND(f, node));
+// ---- the schedule of the count pass -------------------------------------------------------------------------------------
+// A node can be lowered once its operands, the definition of the local it reads and (an integer literal on the right of an
+// assignment) the left side are lowered.  k_flat_pre plays that through per function with counters in LDS — no visit, only "who
+// releases whom" — and gives every node the ROUND in which it is lowered; the count pass is then one launch per (round, class) over a
+// list that was sorted before it started: no atomic, no queue, no host look at a counter between rounds.
+// Sorting = counting sort of (bin, node) pairs with bin = round * KC_ACTIVE + class: k_sched_hist, k_sched_scan, k_sched_scatter.
+enum : uint32_t { SCHED_STAGE1 = 1u << 31 };      // list entry: stage 1 of a `for` node (its loop variable gets its type), not the node itself
+__device__ __forceinline__ bool single_operand(uint8_t k) {      // a node of this kind waits for ONE operand
+    return k == E_Parentheses || k == E_Negate || k == S_Expression || k == S_VariableDefinition || k == S_Return || k == E_Reference || k == E_MutableReference
+        || k == E_ArrayReference || k == E_MutableArrayReference || k == E_Dereference || k == E_Field || k == E_Cast || k == X_FieldInit;
 }
 // is node c an unsuffixed integer literal that takes its type from the left side of its assignment (generate_ir.rs:265-274, 514-549)?
 template <class F> __device__ __forceinline__ bool literal_waits_for_lhs(const F& f, uint32_t c) {
     const uint32_t s = f.st[c];
     return KIND(f, c) == E_Integer && !(s & ST_DEAD) && (s & ST_MODE_MASK) == ST_MODE_E && ((s & ST_EXP_MASK) >> ST_EXP_SHIFT) == EXP_ASSIGN && !(f.ref[c] & 0x8000u);
 }
-
-// a node of this kind waits for ONE operand: when that operand's lane finishes, everything the node reads was written by that lane
-__device__ __forceinline__ bool single_operand(uint8_t k) {
-    return k == E_Parentheses || k == E_Negate || k == S_Expression || k == S_VariableDefinition || k == S_Return || k == E_Reference || k == E_MutableReference
-        || k == E_ArrayReference || k == E_MutableArrayReference || k == E_Dereference || k == E_Field || k == E_Cast || k == X_FieldInit;
+// Both passes over the (bin, node) pairs: a block histograms its share in LDS (64 KB: one word per bin); HIST adds the non-empty bins
+// to the unit's table, SCATTER takes a range of every non-empty bin from the bin's cursor and deals it out to the block's nodes.
+template <bool SCATTER> __global__ __launch_bounds__(1024) void k_sched_pass(FlatArgs X, uint32_t n_nodes, uint32_t per_block, uint32_t cap) {
+#ifdef OPUSFE_EMU
+    // (one emulated lane: plain counting)
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    for (uint32_t g = 0; g < n_nodes; g++) for (int w = 0; w < 2; w++) {
+        const uint32_t k = w ? X.key1[g] : X.key[g];
+        if (k == NONE16) continue;
+        if (k >= SCHED_BINS) { X.ctl[CTL_LISTOVF] = 1; continue; }
+        if (!SCATTER) { X.ctl[CTL_BINS + k]++; if (w) X.ctl[CTL_NSTAGE1]++; }
+        else {
+            const uint32_t at = X.ctl[CTL_CURSOR + k]++;
+            if (at < cap) X.sched[at] = g | (w ? (uint32_t)SCHED_STAGE1 : 0u); else X.ctl[CTL_LISTOVF] = 1;
+            if (!w) { const uint32_t c = k % KC_ACTIVE, ao = X.ctl[CTL_OFF + c] + X.ctl[CTL_OCUR + c]++; if (ao < cap) X.order[ao] = g; else X.ctl[CTL_LISTOVF] = 1; }
+        }
+    }
+#else
+    extern __shared__ __align__(16) uint32_t sched_lds[];      // SCHED_BINS words, then KC_ACTIVE words (the class list)
+    uint32_t* const cls = sched_lds + SCHED_BINS;
+    for (uint32_t b = threadIdx.x; b < SCHED_BINS + KC_ACTIVE; b += blockDim.x) sched_lds[b] = 0;
+    __syncthreads();
+    const uint64_t lo = (uint64_t)blockIdx.x * per_block, hi = lo + per_block < n_nodes ? lo + per_block : n_nodes;
+    for (uint64_t g = lo + threadIdx.x; g < hi; g += blockDim.x) {
+        const uint32_t k = X.key[g], k1 = X.key1[g];
+        if (k != NONE16) { if (k < SCHED_BINS) atomicAdd(&sched_lds[k], 1u); else atomicMax(X.ctl + CTL_LISTOVF, 1u); }
+        if (k1 != NONE16) { if (k1 < SCHED_BINS) { atomicAdd(&sched_lds[k1], 1u); if (!SCATTER) atomicAdd(&cls[0], 1u); } else atomicMax(X.ctl + CTL_LISTOVF, 1u); }
+        if (SCATTER && k != NONE16 && k < SCHED_BINS) atomicAdd(&cls[k % KC_ACTIVE], 1u);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < SCHED_BINS; b += blockDim.x) {
+        const uint32_t c = sched_lds[b];
+        if (!c) continue;
+        if (!SCATTER) atomicAdd(X.ctl + CTL_BINS + b, c);
+        else sched_lds[b] = atomicAdd(X.ctl + CTL_CURSOR + b, c);      // the block's first slot of the bin
+    }
+    if (!SCATTER) { if (threadIdx.x == 0 && cls[0]) atomicAdd(X.ctl + CTL_NSTAGE1, cls[0]); return; }
+    if (threadIdx.x < KC_ACTIVE) { const uint32_t c = cls[threadIdx.x]; cls[threadIdx.x] = X.ctl[CTL_OFF + threadIdx.x] + (c ? atomicAdd(X.ctl + CTL_OCUR + threadIdx.x, c) : 0u); }
+    __syncthreads();
+    for (uint64_t g = lo + threadIdx.x; g < hi; g += blockDim.x) {
+        const uint32_t k = X.key[g], k1 = X.key1[g];
+        if (k != NONE16 && k < SCHED_BINS) {
+            const uint32_t at = atomicAdd(&sched_lds[k], 1u), ao = atomicAdd(&cls[k % KC_ACTIVE], 1u);
+            if (at < cap) X.sched[at] = (uint32_t)g; else atomicMax(X.ctl + CTL_LISTOVF, 1u);
+            if (ao < cap) X.order[ao] = (uint32_t)g; else atomicMax(X.ctl + CTL_LISTOVF, 1u);
+        }
+        if (k1 != NONE16 && k1 < SCHED_BINS) { const uint32_t at = atomicAdd(&sched_lds[k1], 1u); if (at < cap) X.sched[at] = (uint32_t)g | SCHED_STAGE1; else atomicMax(X.ctl + CTL_LISTOVF, 1u); }
+    }
+#endif
 }
-// One ready node: lower it (count pass) and say what it releases.  The lane goes on with the parent when that has become ready, waits
-// for this one operand only and is of a class this kernel holds (chains of parentheses, field accesses, ...: no round per link).
-template <int C> __device__ __forceinline__ void count_one(const SemView& S, const ParArgs& A, const FlatArgs& X, uint32_t g, Ready& R) {
+// lengths -> exclusive offsets (CTL_BINS, SCHED_BINS + 1 words) and the cursors of the scatter pass; the class list's regions
+// (CTL_OFF / CTL_ORDER: every node of a class, whatever its round; stage-1 entries are not nodes of their own).  One block.
+__global__ __launch_bounds__(1024) void k_sched_scan(uint32_t* __restrict__ ctl) {
+#ifdef OPUSFE_EMU
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    uint32_t clsn[KC_ACTIVE] = {0};
+    for (uint32_t b = 0; b < SCHED_BINS; b++) clsn[b % KC_ACTIVE] += ctl[CTL_BINS + b];
+    clsn[KC_CONTROL] -= ctl[CTL_NSTAGE1];
+    uint32_t run = 0;
+    for (uint32_t b = 0; b < SCHED_BINS; b++) { const uint32_t c = ctl[CTL_BINS + b]; ctl[CTL_BINS + b] = run; ctl[CTL_CURSOR + b] = run; run += c; }
+    ctl[CTL_BINS + SCHED_BINS] = run;
+    uint32_t o = 0;
+    for (uint32_t c = 0; c < KC_ACTIVE; c++) { ctl[CTL_OFF + c] = o; ctl[CTL_ORDER + c] = clsn[c]; ctl[CTL_OCUR + c] = 0; o += clsn[c]; }
+    ctl[CTL_OFF + KC_ACTIVE] = o;
+#else
+    __shared__ uint32_t part[1024];
+    __shared__ uint32_t clsn[KC_ACTIVE];
+    constexpr uint32_t PER = SCHED_BINS / 1024;      // (a multiple of KC_ACTIVE: a thread's bins are whole rounds)
+    const uint32_t t = threadIdx.x;
+    if (t < KC_ACTIVE) clsn[t] = 0;
+    __syncthreads();
+    uint32_t sum = 0;
+    for (uint32_t k = 0; k < PER; k++) { const uint32_t c = ctl[CTL_BINS + t * PER + k]; sum += c; if (c) atomicAdd(&clsn[(t * PER + k) % KC_ACTIVE], c); }
+    part[t] = sum;
+    __syncthreads();
+    if (t == 0) {
+        clsn[KC_CONTROL] -= ctl[CTL_NSTAGE1];
+        uint32_t run = 0; for (uint32_t k = 0; k < 1024; k++) { const uint32_t v = part[k]; part[k] = run; run += v; } ctl[CTL_BINS + SCHED_BINS] = run;
+        uint32_t o = 0;
+        for (uint32_t c = 0; c < KC_ACTIVE; c++) { ctl[CTL_OFF + c] = o; ctl[CTL_OCUR + c] = 0; o += clsn[c]; }
+        ctl[CTL_OFF + KC_ACTIVE] = o;
+    }
+    __syncthreads();
+    if (t < KC_ACTIVE) ctl[CTL_ORDER + t] = clsn[t];
+    uint32_t run = part[t];
+    for (uint32_t k = 0; k < PER; k++) { const uint32_t c = ctl[CTL_BINS + t * PER + k]; ctl[CTL_BINS + t * PER + k] = run; ctl[CTL_CURSOR + t * PER + k] = run; run += c; }
+#endif
+}
+
+// One scheduled node: lower it (count pass).  The lane goes on with the parent when the schedule chained it to this node.
+template <int C> __device__ __forceinline__ void count_one(const SemView& S, const ParArgs& A, const FlatArgs& X, uint32_t entry) {
     Fn f; uint32_t i;
-    if (!make_fn(f, S, A, X, g, &i, false)) return;
-    R.dn = f.dn;
+    if (!make_fn(f, S, A, X, entry & ~(uint32_t)SCHED_STAGE1, &i, false)) return;
+    if (C == KC_CONTROL || C == KC_ANY) {
+        if (entry & SCHED_STAGE1) {
+            // stage 1 of a `for`, scheduled behind the iteree: the loop variable gets its type (Q13), the body may go on
+            const Desc vt = for_variable_type(f, i);
+            if (failed(f)) return;
+            f.rt[i] = vt;
+            f.st[i] |= ST_STAGE1;
+            return;
+        }
+    }
     for (uint32_t guard = 0; guard <= f.nn; guard++) {
         const uint32_t s = f.st[i];
         if (s & (ST_DONE | ST_DEAD)) { inconsistent(f); return; }         // (a node is listed once)
-        const uint8_t kind = KIND(f, i);
-        if (C == KC_CONTROL || C == KC_ANY) {
-            if (kind == S_For && !(s & ST_STAGE1)) {
-                // stage 1, listed by the iteree: the loop variable gets its type (Q13), the body may go on; the node itself is lowered when
-                // everything below it is (the iteree's share of the operand count is given up here)
-                const Desc vt = for_variable_type(f, i);
-                if (failed(f)) return;
-                f.rt[i] = vt;
-                at_or(&f.st[i], (uint32_t)ST_STAGE1);
-                R.waiters = gld(X.whead + f.dn + i);
-                R.c0 = release(f, i); R.g0 = f.dn + i;
-                return;
-            }
-        }
-        if (guard == 0 && (s & ST_PEND_MASK)) { inconsistent(f); return; }
-        if (!visit<false, C>(f, i)) { fallback(f); return; }     // (an input that is not ready: the scheduler never lets this happen)
+        if (!visit<false, C>(f, i)) { fallback(f); return; }              // (an input that is not ready: the schedule never lets this happen)
         if (failed(f)) return;
-        at_or(&f.st[i], (uint32_t)ST_DONE);
-        if (C == KC_STATEMENT || C == KC_ANY) { if (kind == S_VariableDefinition) R.waiters = gld(X.whead + f.dn + i); }
+        f.st[i] |= ST_DONE;
         const uint32_t p = f.pa[i];
-        if (p == NONE16) return;
-        const uint8_t pk = KIND(f, p);
-        if (pk == S_Assignment && f.fc[p] == i) {                // the left side: an integer literal on the right takes its type from it
-            uint32_t c = f.nx[i];
-            while (c != NONE16 && (KIND(f, c) == E_Parentheses || KIND(f, c) == E_Negate)) c = f.fc[c];
-            if (c != NONE16 && literal_waits_for_lhs(f, c)) { R.c1 = release(f, c); R.g1 = f.dn + c; }
-        }
-        if (pk == S_For) {
-            uint32_t cond, tb, eb; blocks_of(f, p, &cond, &tb, &eb);
-            if (cond == i) { R.c0 = KC_CONTROL; R.g0 = f.dn + p; return; }      // stage 1 of the loop
-        }
-        const uint32_t pc = release(f, p);
-        if (pc >= KC_ACTIVE) return;                             // the parent waits for others
-        if ((C == KC_ANY || pc == (uint32_t)C) && single_operand(pk) && R.waiters == NONE16) { i = p; continue; }
-        R.c0 = pc; R.g0 = f.dn + p;
-        return;
+        if (p == NONE16 || !(f.st[p] & ST_CHAINED)) return;
+        i = p;
     }
 }
-// Round `round` reads the ready lists in wl0 (even rounds) or wl1 (odd rounds) and appends what becomes ready to the other one; round 0's
-// lists were written by k_flat_pre (the nodes that wait for nothing).  C == KC_ANY: every class in one launch (the long tail of rounds
-// with a few ready nodes each: one small launch per round instead of eight).
-template <int C> __global__ __launch_bounds__(256) void k_flat_count(SemView S, ParArgs A, FlatArgs X, uint32_t round) {
-    uint32_t* out = (round & 1u) ? X.wl0 : X.wl1;
-    uint32_t* out_cnt = X.ctl + CTL_ROUNDS + (round + 1) * KC_ACTIVE;
-#ifdef OPUSFE_EMU
-    const uint32_t lane = 0, W = 1;
-#else
-    const uint32_t lane = threadIdx.x & 63u, W = 64;
-#endif
-    for (uint32_t c = (C == KC_ANY ? 0u : (uint32_t)C); c < (C == KC_ANY ? (uint32_t)KC_ACTIVE : (uint32_t)C + 1u); c++) {
-        const uint32_t* in = ((round & 1u) ? X.wl1 : X.wl0) + X.ctl[CTL_OFF + c];
-        const uint32_t n = X.ctl[CTL_ROUNDS + round * KC_ACTIVE + c];
-        // (wave-uniform trip count: every lane of a wave reaches the appends below)
-        for (uint64_t base = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / W * W; base < n; base += (uint64_t)gridDim.x * blockDim.x) {
-            const uint64_t k = base + lane;
-            Ready R{KC_NONE, 0, KC_NONE, 0, NONE16, 0};
-            if (k < n) count_one<C>(S, A, X, in[k], R);
-            wave_push(X, out, out_cnt, R.c0, R.g0);
-            if (C != KC_INTEGER && C != KC_OPERATOR && C != KC_STATEMENT && C != KC_CONTROL) wave_push(X, out, out_cnt, R.c1, R.g1);      // (the left side of an assignment is never a literal, an operator or a statement)
-            if (C == KC_CONTROL || C == KC_STATEMENT || C == KC_ANY) {
-                // a definition has its type: the nodes that read the variable need not wait for it any longer
-                uint32_t w = R.waiters;
-#ifdef OPUSFE_EMU
-                while (w != NONE16) {
-#else
-                while (__ballot(w != NONE16) != 0) {
-#endif
-                    uint32_t cw = KC_NONE, gw = 0;
-                    if (w != NONE16) {
-                        const uint32_t old = at_sub((G_AS uint32_t*)X.st + R.dn + w, (uint32_t)ST_PEND_ONE);
-                        if ((old & ST_PEND_MASK) == ST_PEND_ONE) { gw = R.dn + w; cw = kind_class_of(old, gld(S.nodes.ptr() + gw).kind); }
-                        w = gld(X.wnext + R.dn + w);
-                    }
-                    wave_push(X, out, out_cnt, cw, gw);
-                }
-            }
-        }
-    }
+// One launch per (round, class) of the schedule: entries [begin, begin + n) of `sched`.  C == KC_ANY: a whole round with few nodes
+// in one launch (the bins of a round follow each other).
+template <int C> __global__ __launch_bounds__(256) void k_flat_count(SemView S, ParArgs A, FlatArgs X, uint32_t begin, uint32_t n) {
+    const uint32_t* in = X.sched + begin;
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) count_one<C>(S, A, X, in[k]);
 }
 
 // ---- scan: one wave per function ------------------------------------------------------------------------------------------
+// Exclusive scan of the event counters in Euler order, call-argument slots in node order; the function's totals go to `tot`.
+// A device-wide scan over the functions (definition order) then gives every function its place in the dense result arrays
+// (k_flat_bases): the layout is dense, in definition order, and the same from run to run.
 struct Cnt2x { uint64_t vt, ib; };      // v | t << 32, i | b << 32: the four counters of an event with 32 bits each
 struct OpAddCnt2x { __host__ __device__ Cnt2x operator()(Cnt2x a, Cnt2x b) const { return Cnt2x{a.vt + b.vt, a.ib + b.ib}; } };
-__global__ __launch_bounds__(256) void k_flat_scan(SemView S, ParArgs A, FlatArgs X) {
+__global__ __launch_bounds__(256) void k_flat_scan(SemView S, ParArgs A, FlatArgs X, IrCnt* __restrict__ tot) {
 #ifdef OPUSFE_EMU
     const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; const uint32_t lane = 0; constexpr uint32_t W = 1;
 #else
@@ -1452,80 +1442,93 @@ __global__ __launch_bounds__(256) void k_flat_scan(SemView S, ParArgs A, FlatArg
     const FnInfo I = gld(X.fninfo + fidx);
     if (I.nn == 0 || I.dn != dn) return;                     // not on the flat path: stays DS_FALLBACK (k_par_init)
     uint32_t why = gld(X.fb + fidx);
-    if (why == 0 && !(gld(X.st + dn) & ST_DONE)) why = __LINE__;      // the rounds ended before the function did
+    if (why == 0 && !(gld(&X.rec[dn].st) & ST_DONE)) why = __LINE__;      // (every scheduled node of a function that was not declined is lowered)
     const uint32_t nn = I.nn, ne = 2u * nn;
     uint64_t* cnt = X.cnt + 2ull * dn;
-    Cnt2x carry{0, 0};
+    uint16_t* cg = X.cg + dn;
+    // every lane owns a run of consecutive events (its loads do not wait for each other); the lanes' sums are scanned across the wave
+    const uint32_t per = (ne + W - 1) / W, lo = lane * per < ne ? lane * per : ne, hi = lo + per < ne ? lo + per : ne;
+    const uint32_t perc = (nn + W - 1) / W, loc = lane * perc < nn ? lane * perc : nn, hic = loc + perc < nn ? loc + perc : nn;
+    Cnt2x mine{0, 0}; uint32_t mine_cg = 0;
     if (why == 0) {
-        for (uint32_t base = 0; base < ne; base += W) {
-            const uint32_t p = base + lane;
-            const Cnt4 c = p < ne ? unpack4(cnt[p]) : Cnt4{0, 0, 0, 0};
-            const Cnt2x mine{(uint64_t)c.v | ((uint64_t)c.t << 32), (uint64_t)c.i | ((uint64_t)c.b << 32)};
-#ifdef OPUSFE_EMU
-            const Cnt2x incl = OpAddCnt2x()(carry, mine);
-            const Cnt2x excl = carry; carry = incl;
-#else
-            Cnt2x incl = wave_inclusive_scan(mine, OpAddCnt2x());
-            const Cnt2x excl{carry.vt + incl.vt - mine.vt, carry.ib + incl.ib - mine.ib};
-            const Cnt2x last{(uint64_t)__shfl((long long)incl.vt, 63), (uint64_t)__shfl((long long)incl.ib, 63)};
-            carry = OpAddCnt2x()(carry, last);
-#endif
-            if (p < ne) cnt[p] = pack4(Cnt4{(uint32_t)excl.vt & 0xFFFFu, (uint32_t)(excl.vt >> 32) & 0xFFFFu, (uint32_t)excl.ib & 0xFFFFu, (uint32_t)(excl.ib >> 32) & 0xFFFFu});
-        }
+        for (uint32_t p = lo; p < hi; p++) { const Cnt4 c = unpack4(cnt[p]); mine.vt += (uint64_t)c.v | ((uint64_t)c.t << 32); mine.ib += (uint64_t)c.i | ((uint64_t)c.b << 32); }
+        for (uint32_t p = loc; p < hic; p++) mine_cg += cg[p];
     }
-    // call-argument slots in node order
-    uint32_t cg_carry = 0;
-    if (why == 0) {
-        uint16_t* cg = X.cg + dn;
-        for (uint32_t base = 0; base < nn; base += W) {
-            const uint32_t p = base + lane;
-            const uint32_t mine = p < nn ? (uint32_t)cg[p] : 0u;
 #ifdef OPUSFE_EMU
-            const uint32_t excl = cg_carry; cg_carry += mine;
+    Cnt2x run{0, 0}; uint32_t run_cg = 0; const Cnt2x total = mine; const uint32_t total_cg = mine_cg;
 #else
-            const uint32_t incl = wave_inclusive_scan(mine, OpAddU32());
-            const uint32_t excl = cg_carry + incl - mine;
-            cg_carry += (uint32_t)__shfl((int)incl, 63);
+    const Cnt2x incl = wave_inclusive_scan(mine, OpAddCnt2x());
+    const uint32_t incl_cg = wave_inclusive_scan(mine_cg, OpAddU32());
+    Cnt2x run{incl.vt - mine.vt, incl.ib - mine.ib}; uint32_t run_cg = incl_cg - mine_cg;
+    const Cnt2x total{(uint64_t)__shfl((long long)incl.vt, 63), (uint64_t)__shfl((long long)incl.ib, 63)};
+    const uint32_t total_cg = (uint32_t)__shfl((int)incl_cg, 63);
 #endif
-            if (p < nn) cg[p] = (uint16_t)excl;
+    const uint32_t tv = (uint32_t)total.vt, tt = (uint32_t)(total.vt >> 32), ti = (uint32_t)total.ib, tb = (uint32_t)(total.ib >> 32);
+    // the packed 16-bit fields of an event must hold every prefix
+    if (why == 0 && (tv > 0xFFF0u || tt > 0xFFF0u || ti > 0xFFF0u || tb > 0xFFF0u || total_cg > 0xFFF0u)) why = __LINE__;
+    if (why == 0) {
+        for (uint32_t p = lo; p < hi; p++) {
+            const Cnt4 c = unpack4(cnt[p]);
+            cnt[p] = pack4(Cnt4{(uint32_t)run.vt & 0xFFFFu, (uint32_t)(run.vt >> 32) & 0xFFFFu, (uint32_t)run.ib & 0xFFFFu, (uint32_t)(run.ib >> 32) & 0xFFFFu});
+            run.vt += (uint64_t)c.v | ((uint64_t)c.t << 32); run.ib += (uint64_t)c.i | ((uint64_t)c.b << 32);
         }
+        for (uint32_t p = loc; p < hic; p++) { const uint32_t v = cg[p]; cg[p] = (uint16_t)run_cg; run_cg += v; }
     }
     if (lane != 0) return;
-    const uint32_t tv = (uint32_t)carry.vt, tt = (uint32_t)(carry.vt >> 32), ti = (uint32_t)carry.ib, tb = (uint32_t)(carry.ib >> 32);
-    // the packed 16-bit fields of an event must hold every prefix
-    if (why == 0 && (tv > 0xFFF0u || tt > 0xFFF0u || ti > 0xFFF0u || tb > 0xFFF0u || cg_carry > 0xFFF0u)) why = __LINE__;
     FuncIr r{};
     r.def_node = dn; r.func = fidx;
     if (why) { r.status = DS_FALLBACK; r.pad = why; X.fb[fidx] = why; A.out[fidx] = r; return; }
-    const Bases b = bump_allocate(A, tv, ti, tb, tt, cg_carry);
-    r.n_vars = tv; r.n_instrs = ti; r.n_bbs = tb; r.n_types = tt; r.n_cargs = cg_carry; r.n_errs = 0; r.status = DS_OK;
-    r.var_base = b.var_base; r.instr_base = b.instr_base; r.bb_base = b.bb_base; r.type_base = b.type_base; r.carg_base = b.carg_base;
+    r.n_vars = tv; r.n_instrs = ti; r.n_bbs = tb; r.n_types = tt; r.n_cargs = total_cg; r.n_errs = 0; r.status = DS_OK;
+    A.out[fidx] = r;                                           // (its bases: k_flat_bases)
+    tot[fidx] = IrCnt{tv, ti, tb, tt, total_cg, 0};
+}
+// the functions' places in the dense arrays from the exclusive scan of their totals; the bump counters (which the functions of the
+// sequential machine go on from, k_fb_bases) start at the flat path's totals
+__global__ void k_flat_bases(ParArgs A, FlatArgs X, const IrCnt* __restrict__ excl, const IrCnt* __restrict__ total, uint32_t n_funcs) {
+    const uint32_t fidx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (fidx == 0) {
+        const IrCnt t = *total;
+        A.counters[CTR_INSTR_BB] = (unsigned long long)t.instrs | ((unsigned long long)t.bbs << CTR_BB_SHIFT);
+        A.counters[CTR_VARS] = t.vars; A.counters[CTR_TYPES] = t.types; A.counters[CTR_CARGS] = t.cargs;
+        if (t.instrs > A.cap_instrs || t.bbs > A.cap_bbs || t.vars > A.cap_vars || t.types > A.cap_types || t.cargs > A.cap_cargs) atomicMax(A.overflow, 1u);
+    }
+    if (fidx >= n_funcs) return;
+    if (gld(X.fninfo + fidx).nn == 0 || gld(X.fb + fidx) != 0) return;
+    FuncIr r = A.out[fidx];
+    if (r.status != DS_OK) return;
+    const IrCnt e = excl[fidx];
+    r.var_base = e.vars; r.instr_base = e.instrs; r.bb_base = e.bbs; r.type_base = e.types; r.carg_base = e.cargs;
     A.out[fidx] = r;
-    if (!b.fits) X.fb[fidx] = FB_NOFIT;                      // the host runs again with arrays of the exact size
+    const bool fits = (uint64_t)e.instrs + r.n_instrs <= A.cap_instrs && (uint64_t)e.bbs + r.n_bbs <= A.cap_bbs && (uint64_t)e.vars + r.n_vars <= A.cap_vars
+                   && (uint64_t)e.types + r.n_types <= A.cap_types && (uint64_t)e.cargs + r.n_cargs <= A.cap_cargs;
+    if (!fits) X.fb[fidx] = FB_NOFIT;                        // nothing is written beyond an array; the host runs again with arrays of the exact size
 }
 
 // ---- result variables: every node learns the id of the variable that holds its result -----------------------------------
 // rvi[] after the count pass says who created it: the node's own event (event, offset), a local or an argument, or "the
 // result of node c" (references, parentheses, casts that did nothing).  One lane per node follows that to an id.
+__device__ __forceinline__ void resolve_rv(const ParArgs& A, const FlatArgs& X, const FnInfo& I, uint32_t g) {
+    const uint32_t dn = I.dn;
+    uint32_t r = gld(&X.rec[g].rvi);
+    uint32_t res = OPUSFE_NONE;
+    for (uint32_t guard = 0; guard <= I.nn + 2u; guard++) {
+        const uint32_t tag = r & RV_TAG;
+        if (tag == RV_RESOLVED) { res = r; break; }
+        if (tag == RV_OWN) { res = RV_RESOLVED | (unpack4(gld(X.cnt + 2ull * dn + ((r >> 12) & 0x1FFFFu))).v + (r & 0xFFFu)); break; }
+        if (tag == RV_ARG) { res = RV_RESOLVED | (I.nargs + (r & RV_VAL)); break; }
+        if (tag == RV_LOCAL) { r = gld(&X.rec[dn + (r & 0xFFFFu)].rvi); if ((r & RV_TAG) != RV_OWN && (r & RV_TAG) != RV_RESOLVED) break; continue; }      // the slot of the definition holds its variable
+        if (tag == RV_PASS) { r = gld(&X.rec[dn + (r & 0xFFFFu)].rvi); continue; }
+        break;
+    }
+    if (res == OPUSFE_NONE) { atomicMax(A.status, (uint32_t)DS_INTERNAL_CAPACITY); if (A.dbg) atomicMax(A.dbg, (uint32_t)__LINE__); return; }
+    gst(&X.rec[g].rvi, res);
+}
+// one lane per node of the unit (the records of nodes that are not on the flat path say fn = NONE)
 __global__ __launch_bounds__(256) void k_flat_rv(ParArgs A, FlatArgs X) {
     for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < A.n_nodes; g += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t fidx = gld(X.fn_of + g);
+        const uint32_t fidx = gld(&X.rec[g].fn);
         if (fidx == OPUSFE_NONE || gld(X.fb + fidx) != 0) continue;
-        const FnInfo I = gld(X.fninfo + fidx);
-        const uint32_t dn = I.dn;
-        uint32_t r = gld(X.rvi + g);
-        uint32_t res = OPUSFE_NONE;
-        for (uint32_t guard = 0; guard <= I.nn + 2u; guard++) {
-            const uint32_t tag = r & RV_TAG;
-            if (tag == RV_RESOLVED) { res = r; break; }
-            if (tag == RV_OWN) { res = RV_RESOLVED | (unpack4(gld(X.cnt + 2ull * dn + ((r >> 12) & 0x1FFFFu))).v + (r & 0xFFFu)); break; }
-            if (tag == RV_ARG) { res = RV_RESOLVED | (I.nargs + (r & RV_VAL)); break; }
-            if (tag == RV_LOCAL) { r = gld(X.rvi + dn + (r & 0xFFFFu)); if ((r & RV_TAG) != RV_OWN && (r & RV_TAG) != RV_RESOLVED) break; continue; }      // the slot of the definition holds its variable
-            if (tag == RV_PASS) { r = gld(X.rvi + dn + (r & 0xFFFFu)); continue; }
-            break;
-        }
-        if (res == OPUSFE_NONE) { atomicMax(A.status, (uint32_t)DS_INTERNAL_CAPACITY); if (A.dbg) atomicMax(A.dbg, (uint32_t)__LINE__); continue; }
-        gst(X.rvi + g, res);
+        resolve_rv(A, X, gld(X.fninfo + fidx), (uint32_t)g);
     }
 }
 
@@ -1551,17 +1554,17 @@ struct Pre {
     SemView S; ParArgs A;
     uint32_t dn, nn, fidx, nargs; uint64_t user_syms;
     lds_u32* kn; lds_u32* st; lds_u32* ref; lds_u32* rvi; lds_u32* pay;
-    lds_u16* fc; lds_u16* nx; lds_u16* pa; lds_u16* rk; lds_u16* sz; lds_u16* pe; lds_u16* cg; lds_u16* wnext;
+    lds_u16* fc; lds_u16* nx; lds_u16* pa; lds_u16* rk; lds_u16* sz; lds_u16* pe; lds_u16* cg; lds_u16* wnext; lds_u16* s1;
     DefEnt* defs; ArgEnt* args; lds_u32* misc; lds_u32* whead;
     uint32_t tid, nthreads;
 };
-enum { MI_FB = 0, MI_NDEFS = 1, MI_WHY = 7, MI_KHIST = 16 /* 2 x KC_ACTIVE words */, MI_KBASE = 32 /* 2 x KC_ACTIVE words: the function's place in the class lists */, MI_WORDS = 48 };
+enum { MI_FB = 0, MI_NDEFS = 1, MI_WHY = 7, MI_KHIST = 16 /* 2 x KC_ACTIVE words */, MI_KBASE = 32 /* KC_ACTIVE words: the function's place in the class list */, MI_QCNT = 40 /* 3 words: lengths of the schedule's queues */, MI_WORDS = 48 };
 
 __host__ __device__ inline size_t lds_bytes(uint32_t nmax, uint32_t maxdef, uint32_t nthreads) {
     (void)nthreads;
     size_t b = 0;
     b += 4ull * 5 * nmax;        // kn st ref rvi pay
-    b += 2ull * 8 * nmax;        // fc nx pa rk sz pe cg wnext
+    b += 2ull * 9 * nmax;        // fc nx pa rk sz pe cg wnext s1
     b = (b + 7) & ~(size_t)7;
     b += sizeof(DefEnt) * maxdef + sizeof(ArgEnt) * MAX_ARGS + 4 * MI_WORDS + 4ull * maxdef;
     return (b + 15) & ~(size_t)15;
@@ -1599,7 +1602,7 @@ __device__ __forceinline__ void pre_function(Pre& f, const FlatArgs& X) {
         f.fc[i] = (uint16_t)fc; f.nx[i] = (uint16_t)nx;
         f.pay[i] = n.payload;
         f.pa[i] = NONE16; f.st[i] = 0; f.ref[i] = (n.kind >= Y_Name && n.kind <= Y_Array) ? f.S.tid_of_node[f.dn + i] : 0u; f.rvi[i] = 0; f.cg[i] = 0; f.rk[i] = 0; f.sz[i] = 0; f.pe[i] = 0; f.wnext[i] = NONE16;
-        // (the unit-wide words that start empty — rt = none, cnt, tail, rvi = 0 — were cleared by the host; the names phase fills some in)
+        // (the event words that start empty — cnt, tail — were cleared by the host, the records filled with 0xFF: result type "none")
         if (f.A.undefined_flag[f.dn + i]) fallback(f);                                // UndefinedType somewhere in the function
     }
     if (par_sync_or(failed(f))) return;      // (uniform exit: every wave sees the same answer)
@@ -1710,7 +1713,7 @@ __device__ __forceinline__ void pre_function(Pre& f, const FlatArgs& X) {
             if (t.kind != T_Identifier) { fallback(f); break; }                         // a symbol as a variable name (sym_locals)
             ArgEnt e; e.hash = t.payload; e.low = t.low; e.len = t.len; e.pad = a; e.vt = d_ptr(f, PT_Mutable, d_id(TID(f, f.fc[a])));
             f.args[k++] = e;
-            gst(X.rt + dn + a, (uint64_t)e.vt);                                        // (the argument's node holds its type for the visits)
+            gst(&X.rec[dn + a].rt, (uint64_t)e.vt);                                        // (the argument's node holds its type for the visits)
             a = f.nx[a];
         }
         if (k != f.nargs) fallback(f);
@@ -1811,7 +1814,7 @@ __device__ __forceinline__ void pre_function(Pre& f, const FlatArgs& X) {
                 if (fr.nargs != NCH(f, i)) { fallback(f); continue; }                      // NoOverloadForFunction
                 uint32_t c = f.fc[i], a = fr.first_arg;
                 for (uint32_t q = 0; q < fr.nargs && c != NONE16; q++) { gst(X.cnt + 2ull * dn + POS_EXIT(f, c), (uint64_t)f.S.tid_of_node[f.S.nodes[a].first_child]); a = f.S.nodes[a].next; c = f.nx[c]; }
-                gst(X.rt + dn + i, (uint64_t)d_id(fr.ret));
+                gst(&X.rec[dn + i].rt, (uint64_t)d_id(fr.ret));
                 f.ref[i] = RF_CALL1 | only;
             }
             continue;
@@ -1830,7 +1833,7 @@ __device__ __forceinline__ void pre_function(Pre& f, const FlatArgs& X) {
             if (r == RF_NONE && nfn == 1) r = RF_FUNC | only;
         }
         if (r == RF_NONE || (k == E_NamedCall && ((r & RF_TAG) == RF_CONST || (r & RF_TAG) == RF_FUNC))) { fallback(f); continue; }
-        if ((r & RF_TAG) == RF_GLOBAL || (r & RF_TAG) == RF_CONST) gst(X.rt + dn + i, (uint64_t)d_id(f.S.globals[r & RF_VAL].type_id));    // fetched here, read by the visit
+        if ((r & RF_TAG) == RF_GLOBAL || (r & RF_TAG) == RF_CONST) gst(&X.rec[dn + i].rt, (uint64_t)d_id(f.S.globals[r & RF_VAL].type_id));    // fetched here, read by the visit
         f.ref[i] = r;
     }
     // operator calls and `for` reserve their call arguments too (user overloads only use them; sized for the worst case)
@@ -1853,51 +1856,103 @@ __device__ __forceinline__ void pre_function(Pre& f, const FlatArgs& X) {
         if (literal_waits_for_lhs(f, i)) lds_add(&f.st[i], (uint32_t)ST_PEND_ONE);
     }
     PAR_SYNC();
-    // ---- nodes by kind class: the function's place in the unit-wide class lists (`order`: every node that is lowered; wl0: the ones
-    //      that wait for nothing, the first round) ----
-    for (uint32_t k = tid; k < 2 * KC_ACTIVE; k += T) f.misc[MI_KHIST + k] = 0;
-    PAR_SYNC();
-    for (uint32_t i = tid; i < nn; i += T) {
-        const uint32_t s = f.st[i], c = kind_class_of(s, KIND(f, i));
-        if (c >= KC_ACTIVE) continue;
-        lds_add(&f.misc[MI_KHIST + c], 1u);
-        if (!(s & ST_PEND_MASK)) lds_add(&f.misc[MI_KHIST + KC_ACTIVE + c], 1u);
-    }
-    PAR_SYNC();
-    for (uint32_t k = tid; k < 2 * KC_ACTIVE; k += T) {
-        const uint32_t n = f.misc[MI_KHIST + k];
-        f.misc[MI_KBASE + k] = n ? atomicAdd(X.ctl + (k < KC_ACTIVE ? CTL_ORDER + k : CTL_ROUNDS + k - KC_ACTIVE), n) : 0u;
-    }
-    PAR_SYNC();
-    for (uint32_t k = tid; k < 2 * KC_ACTIVE; k += T) f.misc[MI_KHIST + k] = 0;
-    PAR_SYNC();
-    for (uint32_t i = tid; i < nn; i += T) {
-        const uint32_t s = f.st[i], c = kind_class_of(s, KIND(f, i));
-        if (c >= KC_ACTIVE) continue;
-        const uint32_t off = X.ctl[CTL_OFF + c], cap = X.ctl[CTL_OFF + c + 1] - off;
-        const uint32_t pos = f.misc[MI_KBASE + c] + lds_add(&f.misc[MI_KHIST + c], 1u);
-        if (pos < cap) gst(X.order + off + pos, dn + i); else fallback(f);
-        if (!(s & ST_PEND_MASK)) {
-            const uint32_t pos0 = f.misc[MI_KBASE + KC_ACTIVE + c] + lds_add(&f.misc[MI_KHIST + KC_ACTIVE + c], 1u);
-            if (pos0 < cap) gst(X.wl0 + off + pos0, dn + i); else fallback(f);
+    // ---- the schedule (see "the schedule of the count pass"): the dependency counters played through, round by round ----
+    // rk[] (free since the names phase) takes the round of every node, s1[] the round of stage 1 of a `for`; rvi[] (free too) holds
+    // two queues of nodes: the ones lowered in this round and the ones that became ready for the next (entry | Q_STAGE1: stage 1 of
+    // a `for`).  A node that is lowered releases what waited for it; a parent that waited for this one operand only and is of the
+    // same class is CHAINED: same round, same lane, not listed.  One barrier per round.
+    {
+        lds_u16* const q[2] = {(lds_u16*)f.rvi, (lds_u16*)f.rvi + f.A.nmax};
+        enum : uint32_t { Q_STAGE1 = 0x8000u };
+        for (uint32_t i = tid; i < nn; i += T) { f.rk[i] = NONE16; f.s1[i] = NONE16; }
+        if (tid == 0) { f.misc[MI_QCNT] = 0; f.misc[MI_QCNT + 1] = 0; f.misc[MI_QCNT + 2] = 0; }
+        PAR_SYNC();
+        for (uint32_t i = tid; i < nn; i += T) {
+            const uint32_t s = f.st[i];
+            if (!(s & (ST_DONE | ST_DEAD | ST_PEND_MASK))) q[0][lds_add(&f.misc[MI_QCNT], 1u)] = (uint16_t)i;
         }
+        PAR_SYNC();
+        for (uint32_t r = 0; r <= FLAT_MAX_ROUNDS; r++) {
+            const uint32_t n = f.misc[MI_QCNT + r % 3];
+            if (n == 0) break;
+            if (r == FLAT_MAX_ROUNDS || n > nn) { fallback(f); break; }      // a dependency chain longer than the schedule's table: the sequential machine
+            lds_u16* const cur = q[r & 1]; lds_u16* const nxt = q[(r + 1) & 1];
+            lds_u32* const nxt_cnt = &f.misc[MI_QCNT + (r + 1) % 3];
+            if (tid == 0) f.misc[MI_QCNT + (r + 2) % 3] = 0;                   // (read last in the round before this one)
+            auto ready = [&](uint32_t entry) { const uint32_t at = lds_add(nxt_cnt, 1u); if (at < f.A.nmax) nxt[at] = (uint16_t)entry; };
+            auto release = [&](uint32_t node) -> uint32_t { return lds_sub(&f.st[node], (uint32_t)ST_PEND_ONE); };
+            auto release_waiters = [&](uint32_t def_index) {
+                for (uint32_t w = f.whead[def_index], guard = 0; w != NONE16 && guard <= nn; guard++) { const uint32_t after = f.wnext[w]; if ((release(w) & ST_PEND_MASK) == ST_PEND_ONE) ready(w); w = after; }
+            };
+            for (uint32_t j = tid; j < n; j += T) {
+                const uint32_t entry = cur[j];
+                uint32_t i = entry & ~(uint32_t)Q_STAGE1;
+                if (entry & Q_STAGE1) {
+                    // stage 1: the loop variable has its type; the iteree's share of the operand count is given up
+                    f.s1[i] = (uint16_t)r;
+                    release_waiters(f.ref[i]);
+                    if ((release(i) & ST_PEND_MASK) == ST_PEND_ONE) ready(i);
+                    continue;
+                }
+                const uint32_t my_class = kind_class_of(f.st[i], KIND(f, i));
+                for (uint32_t guard = 0; guard <= nn; guard++) {
+                    f.rk[i] = (uint16_t)r;
+                    lds_or(&f.st[i], (uint32_t)ST_DONE);
+                    if (KIND(f, i) == S_VariableDefinition) release_waiters(f.ref[i]);
+                    const uint32_t p = f.pa[i];
+                    if (p == NONE16) break;
+                    const uint8_t pk = KIND(f, p);
+                    if (pk == S_Assignment && f.fc[p] == i) {                // the left side: an integer literal on the right takes its type from it
+                        uint32_t c = f.nx[i];
+                        while (c != NONE16 && (KIND(f, c) == E_Parentheses || KIND(f, c) == E_Negate)) c = f.fc[c];
+                        if (c != NONE16 && literal_waits_for_lhs(f, c) && (release(c) & ST_PEND_MASK) == ST_PEND_ONE) ready(c);
+                    }
+                    if (pk == S_For) {
+                        uint32_t cond, tb, eb; blocks_of(f, p, &cond, &tb, &eb);
+                        if (cond == i) { ready(p | Q_STAGE1); break; }            // stage 1 of the loop: next round
+                    }
+                    const uint32_t old = release(p);
+                    if ((old & ST_PEND_MASK) != ST_PEND_ONE) break;              // the parent waits for others
+                    if (!single_operand(pk) || kind_class_of(old, pk) != my_class) { ready(p); break; }
+                    lds_or(&f.st[p], (uint32_t)ST_CHAINED);
+                    i = p;
+                }
+            }
+            PAR_SYNC();
+        }
+        PAR_SYNC();
+        for (uint32_t i = tid; i < nn; i += T) f.rvi[i] = 0;                     // (the queues' words)
     }
     if (par_sync_or(failed(f))) return;
-    // ---- hand-over: the per-node words the flat passes read ----
+    // every node that is lowered must have its round
+    for (uint32_t i = tid; i < nn; i += T) {
+        const uint32_t c = kind_class_of(f.st[i], KIND(f, i));
+        if (c < KC_ACTIVE && (f.rk[i] == NONE16 || !(f.st[i] & ST_DONE) || (KIND(f, i) == S_For && f.s1[i] == NONE16))) fallback(f);
+    }
+    if (par_sync_or(failed(f))) return;
+    // ---- hand-over (nothing below declines the function: only nodes of functions that are handed over are ever listed) ----
+    // the per-node words the flat passes read: bytes 8..31 of the record (its result type was written above), the schedule bins
     for (uint32_t i = tid; i < nn; i += T) {
         const uint32_t g = dn + i;
-        gst(X.st + g, (uint32_t)f.st[i]); gst(X.ref + g, (uint32_t)f.ref[i]);
-        gst(X.pe + g, (uint16_t)f.pe[i]); gst(X.sz + g, (uint16_t)f.sz[i]); gst(X.cg + g, (uint16_t)f.cg[i]); gst(X.pa + g, (uint16_t)f.pa[i]);
-        gst(X.wnext + g, (uint16_t)f.wnext[i]);
-        gst(X.fn_of + g, f.fidx);
+        uint32_t s = f.st[i];
+        const uint32_t c = kind_class_of(s, KIND(f, i));
+        const bool listed = c < KC_ACTIVE;
+        // (the schedule's counters go; ST_DONE stays with the nodes that have nothing to lower, ST_CHAINED with the chained ones)
+        s &= ~(uint32_t)(ST_CLAIM | ST_PEND_MASK);
+        if (listed) s &= ~(uint32_t)ST_DONE;
+        uint64_t* const w = (uint64_t*)(X.rec + g);
+        gst(w + 1, (uint64_t)s | ((uint64_t)(uint32_t)f.ref[i] << 32));
+        gst(w + 2, (uint64_t)0 /* rvi */ | ((uint64_t)(uint16_t)f.pe[i] << 32) | ((uint64_t)(uint16_t)f.sz[i] << 48));
+        gst(w + 3, (uint64_t)(uint16_t)f.pa[i] | ((uint64_t)i << 16) | ((uint64_t)f.fidx << 32));
+        gst(X.cg + g, (uint16_t)f.cg[i]);
+        gst(X.key + g, (uint16_t)(listed ? ((s & ST_CHAINED) ? (uint32_t)FLAT_MAX_ROUNDS : (uint32_t)f.rk[i]) * KC_ACTIVE + c : (uint32_t)NONE16));
+        gst(X.key1 + g, (uint16_t)((listed && KIND(f, i) == S_For) ? (uint32_t)f.s1[i] * KC_ACTIVE + KC_CONTROL : (uint32_t)NONE16));
     }
     {
         const uint32_t nd = f.misc[MI_NDEFS];
         for (uint32_t k = tid; k < nd; k += T) {
             const DefEnt& d = f.defs[k];
-            const uint32_t slot = def_slot(f, d.node);
-            gst(X.whead + dn + slot, (uint16_t)f.whead[k]);
-            if (d.vt != DESC_NONE) gst(X.rt + dn + slot, (uint64_t)d.vt);
+            if (d.vt != DESC_NONE) gst(&X.rec[dn + def_slot(f, d.node)].rt, (uint64_t)d.vt);
         }
     }
     if (tid == 0) { FnInfo I{}; I.dn = dn; I.nn = nn; I.nargs = f.nargs; I.ret = f.S.funcs[f.fidx].ret; I.sym_mix = f.S.mix_of_def(dn); gst(X.fninfo + f.fidx, I); }
@@ -1905,7 +1960,7 @@ __device__ __forceinline__ void pre_function(Pre& f, const FlatArgs& X) {
 
 // One workgroup per function of `list` (definition indices).
 #ifndef OPUSFE_PAR_WAVES
-#define OPUSFE_PAR_WAVES 4
+#define OPUSFE_PAR_WAVES 8      // (53 VGPRs: eight waves per SIMD fit; measured 59 -> 48 ms per GB against four)
 #endif
 __global__ MACHINE_ATTR(OPUSFE_PAR_WAVES) __launch_bounds__(1024) void k_flat_pre(SemView S, ParArgs A, FlatArgs X) {
     const uint32_t slot = blockIdx.x;
@@ -1937,6 +1992,7 @@ __global__ MACHINE_ATTR(OPUSFE_PAR_WAVES) __launch_bounds__(1024) void k_flat_pr
     f.pe = (lds_u16*)base; base += 2u * nmax;
     f.cg = (lds_u16*)base; base += 2u * nmax;
     f.wnext = (lds_u16*)base; base += 2u * nmax;
+    f.s1 = (lds_u16*)base; base += 2u * nmax;
     base += (8u - (uint32_t)(uintptr_t)base % 8u) % 8u;
     f.defs = (DefEnt*)base; base += sizeof(DefEnt) * A.maxdef;
     f.args = (ArgEnt*)base; base += sizeof(ArgEnt) * MAX_ARGS;
@@ -1945,7 +2001,7 @@ __global__ MACHINE_ATTR(OPUSFE_PAR_WAVES) __launch_bounds__(1024) void k_flat_pr
     pre_function(f, X);
     PAR_SYNC();
     if (f.tid == 0) {
-        if (f.misc[MI_FB]) {       // declined: its nodes may be in the class lists already; the visits skip them (fb != 0)
+        if (f.misc[MI_FB]) {       // declined (before anything of it was listed)
             FuncIr r{}; r.def_node = dn; r.func = fidx; r.status = DS_FALLBACK; r.pad = f.misc[MI_WHY]; A.out[fidx] = r;
             FnInfo I{}; I.dn = dn; I.nn = 0; gst(X.fninfo + fidx, I);
             gst(X.fb + fidx, (uint32_t)f.misc[MI_WHY]);

@@ -21,6 +21,7 @@ struct opusfe_ctx {
     // second stream: the sequential lowering machine works through the few huge functions while the node-parallel kernels run
     hipStream_t stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string msg;
+    std::vector<uint32_t> sched_off;      // lower.h: the offsets of the count pass's schedule (host copy, kept for its capacity)
     // caching allocator: freed blocks are kept and reused so that steady-state calls never hipMalloc
     std::multimap<size_t, void*> free_blocks;
     std::map<void*, size_t> live_blocks;
