@@ -1732,20 +1732,17 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
         HIP_TRY(hipMemsetAsync(ctx->d_status + WL_BODIES, 0, sizeof(uint32_t), st));
         HIP_TRY(hipMemcpyAsync(R->d_types, gtypes, (size_t)n_gtypes * sizeof(TypeRec), hipMemcpyDeviceToDevice, st));
         TempList tmp2(ctx);       // the machine's sparse regions and the per-node state of the flat passes live for one attempt
-        // per-node state of the flat passes (lower_par.h FlatArgs): 32 + 16 + 2 + 2 + 4 B per node + two lists of 4 B per node
+        // per-node state of the flat passes (lower_par.h FlatArgs): 32 + 16 + 2 B per node, the list of the schedule (4 B per listed node)
         par::FlatArgs X{};
-        const uint64_t n_list = (uint64_t)n_nodes + n_nodes / 4 + 1024;      // every listed node, and stage 1 of every `for` (a loop is four nodes or more)
         X.ctl = tmp2.get<uint32_t>(par::CTL_WORDS);
         X.fninfo = tmp2.get<par::FnInfo>(n_funcs); X.fb = tmp2.get<uint32_t>(n_funcs);
-        X.rec = tmp2.get<par::NodeRec>(n_nodes); X.cnt = tmp2.get<uint64_t>(2ull * n_nodes); X.tail = tmp2.get<uint8_t>(2ull * n_nodes); X.cg = tmp2.get<uint16_t>(n_nodes);
-        X.key = tmp2.get<uint16_t>(n_nodes); X.key1 = tmp2.get<uint16_t>(n_nodes);
-        X.order = tmp2.get<uint32_t>(n_list); X.sched = tmp2.get<uint32_t>(n_list);
-        HIP_TRY(hipMemsetAsync(X.key, 0xFF, (size_t)n_nodes * sizeof(uint16_t), st));      // NONE16: not listed
-        HIP_TRY(hipMemsetAsync(X.key1, 0xFF, (size_t)n_nodes * sizeof(uint16_t), st));
+        X.rec = tmp2.get<par::NodeRec>(n_nodes); X.cnt = tmp2.get<uint64_t>(2ull * n_nodes); X.tail = tmp2.get<uint8_t>(2ull * n_nodes);
+        X.cg = (uint16_t*)slot_of_node; X.key1 = X.cg + n_nodes;      // (the type-slot numbers are not read any more: their block serves these two)
+        HIP_TRY(hipMemsetAsync(X.key1, 0xFF, (size_t)n_nodes * sizeof(uint16_t), st));      // NONE16: no stage 1
         HIP_TRY(hipMemsetAsync(X.ctl, 0, par::CTL_WORDS * sizeof(uint32_t), st));
         HIP_TRY(hipMemsetAsync(X.rec, 0xFF, (size_t)n_nodes * sizeof(par::NodeRec), st));      // result type none, function NONE
         HIP_TRY(hipMemsetAsync(X.cnt, 0, (size_t)n_nodes * 2 * sizeof(uint64_t), st));
-        HIP_TRY(hipMemsetAsync(X.tail, 0, (size_t)n_nodes * 2, st));
+        HIP_TRY(hipMemsetAsync(X.tail, 0xFF, (size_t)n_nodes * 2, st));                        // (until the schedule is sorted: every node's bin, NONE16 = not listed)
         LAUNCH(ctx, "par_init", par::k_par_init, grid_for(n_defs, 256), 256, u->d_nodes, u->d_def_nodes, n_defs, def_excl, R->d_funcs, ctx->d_status + WL_BODIES, (const uint8_t*)def_skip, X.fninfo, X.fb);
         par::ParArgs PA{};
         PA.def_nodes = u->d_def_nodes; PA.n_defs = n_defs; PA.n_nodes = n_nodes; PA.def_excl = def_excl; PA.undefined_flag = undefined_flag; PA.user_syms = user_syms;
@@ -1840,64 +1837,59 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
                 HIP_TRY(hipGetLastError());
                 prof_end(ctx);
             }
-            // The schedule: every node's (round, class) bin was written by k_flat_pre; a counting sort makes the lists of the count pass.
-            {
-                const uint32_t per_block = 1u << 16;
-                const unsigned sgrid = grid_for(n_nodes, per_block);
-                const size_t slds = (size_t)(par::SCHED_BINS + par::KC_ACTIVE) * sizeof(uint32_t);
-                HIP_TRY(hipFuncSetAttribute((const void*)par::k_sched_pass<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
-                HIP_TRY(hipFuncSetAttribute((const void*)par::k_sched_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
-                prof_begin(ctx, "sched_hist");
-                hipLaunchKernelGGL(par::k_sched_pass<false>, dim3(sgrid), dim3(1024), slds, st, X, n_nodes, per_block, (uint32_t)n_list);
-                HIP_TRY(hipGetLastError());
-                prof_end(ctx);
-                LAUNCH(ctx, "sched_scan", par::k_sched_scan, 1, 1024, X.ctl);
-                prof_begin(ctx, "sched_scatter");
-                hipLaunchKernelGGL(par::k_sched_pass<true>, dim3(sgrid), dim3(1024), slds, st, X, n_nodes, per_block, (uint32_t)n_list);
-                HIP_TRY(hipGetLastError());
-                prof_end(ctx);
-            }
-            // The count pass: one launch per (round, class) of the schedule, in round order; a round with few nodes is one launch
-            // of the kernel that holds every class.  The host reads the table of list offsets once and knows every launch.
+            // The schedule: every node's (class, round) bin was written by k_flat_pre; a counting sort makes the list that the count pass
+            // (one launch per class and round, in round order; a round with few nodes is one launch of the kernel that holds every
+            // class) and the emit pass (one launch per class) go through.  The host reads the table of offsets once and knows every launch.
+            const uint32_t per_block = 1u << 16;
+            const unsigned sgrid = grid_for(n_nodes, per_block);
+            const size_t slds = (size_t)(par::SCHED_BINS + par::KC_ACTIVE) * sizeof(uint32_t);
+            HIP_TRY(hipFuncSetAttribute((const void*)par::k_sched_pass<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
+            HIP_TRY(hipFuncSetAttribute((const void*)par::k_sched_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
+            prof_begin(ctx, "sched_hist");
+            hipLaunchKernelGGL(par::k_sched_pass<false>, dim3(sgrid), dim3(1024), slds, st, X, n_nodes, per_block, 0u);
+            HIP_TRY(hipGetLastError());
+            prof_end(ctx);
+            LAUNCH(ctx, "sched_scan", par::k_sched_scan, 1, 1024, X.ctl);
             ctx->sched_off.resize(par::SCHED_BINS + 1);
-            // (the cursors: after the scatter, cursor[b] = the END of bin b, i.e. the exclusive offsets shifted by one bin; the offsets themselves are CTL_BINS)
             HIP_TRY(hipMemcpyAsync(ctx->sched_off.data(), X.ctl + par::CTL_BINS, (par::SCHED_BINS + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             prof_collect(ctx);
             const uint32_t* off = ctx->sched_off.data();
-            const uint32_t total = off[par::FLAT_MAX_ROUNDS * par::KC_ACTIVE];      // (behind it: the chained nodes, which no launch starts from)
-            auto count_class = [&](auto cls, uint32_t begin, uint32_t n) {
-                hipLaunchKernelGGL(par::k_flat_count<decltype(cls)::value>, dim3(std::min<unsigned>(grid_for(n, 256), 4096u)), dim3(256), 0, st, S, PA, X, begin, n);
+            const uint32_t n_sched = off[par::SCHED_BINS];
+            X.sched = tmp2.get<uint32_t>((size_t)n_sched + 64); X.order = tmp2.get<uint32_t>((size_t)n_sched + 64);
+            prof_begin(ctx, "sched_scatter");
+            hipLaunchKernelGGL(par::k_sched_pass<true>, dim3(sgrid), dim3(1024), slds, st, X, n_nodes, per_block, n_sched);
+            HIP_TRY(hipGetLastError());
+            prof_end(ctx);
+            HIP_TRY(hipMemsetAsync(X.tail, 0, (size_t)n_nodes * 2, st));      // (the bins travelled in the tail bytes)
+            auto count_class = [&](auto cls, uint32_t r) {
+                constexpr int c = decltype(cls)::value;
+                const uint32_t begin = off[c * par::SCHED_R + r], n = off[c * par::SCHED_R + r + 1] - begin;
+                if (n) hipLaunchKernelGGL(par::k_flat_count<c>, dim3(std::min<unsigned>(grid_for(n, 256), 4096u)), dim3(256), 0, st, S, PA, X, begin, n);
             };
             uint32_t rounds_run = 0;
-            static const uint32_t any_below = getenv("OPUSFE_ANY_BELOW") ? (uint32_t)atoi(getenv("OPUSFE_ANY_BELOW")) : 4096u;      // TEMPORARY (tuning)
             prof_begin(ctx, "lower_count");
             for (uint32_t r = 0; r < par::FLAT_MAX_ROUNDS; r++) {
-                const uint32_t lo = off[r * par::KC_ACTIVE], hi = off[(r + 1) * par::KC_ACTIVE];
-                if (lo == total) break;
-                if (hi == lo) continue;
+                uint64_t n_round = 0;
+                for (uint32_t c = 0; c < par::KC_ACTIVE; c++) n_round += off[c * par::SCHED_R + r + 1] - off[c * par::SCHED_R + r];
+                if (!n_round) break;                               // (every function's rounds start at 0: the first empty round ends them all)
                 rounds_run = r + 1;
-                if (hi - lo <= any_below) { hipLaunchKernelGGL(par::k_flat_count<par::KC_ANY>, dim3(grid_for(hi - lo, 256)), dim3(256), 0, st, S, PA, X, lo, hi - lo); continue; }
-                const uint32_t* o = off + r * par::KC_ACTIVE;
-                if (o[1] > o[0]) count_class(std::integral_constant<int, 0>(), o[0], o[1] - o[0]);
-                if (o[2] > o[1]) count_class(std::integral_constant<int, 1>(), o[1], o[2] - o[1]);
-                if (o[3] > o[2]) count_class(std::integral_constant<int, 2>(), o[2], o[3] - o[2]);
-                if (o[4] > o[3]) count_class(std::integral_constant<int, 3>(), o[3], o[4] - o[3]);
-                if (o[5] > o[4]) count_class(std::integral_constant<int, 4>(), o[4], o[5] - o[4]);
-                if (o[6] > o[5]) count_class(std::integral_constant<int, 5>(), o[5], o[6] - o[5]);
-                if (o[7] > o[6]) count_class(std::integral_constant<int, 6>(), o[6], o[7] - o[6]);
-                if (o[8] > o[7]) count_class(std::integral_constant<int, 7>(), o[7], o[8] - o[7]);
+                if (n_round <= (1u << 16)) { hipLaunchKernelGGL(par::k_flat_count_round, dim3(grid_for(n_round, 256)), dim3(256), 0, st, S, PA, X, r); continue; }
+                count_class(std::integral_constant<int, 0>(), r); count_class(std::integral_constant<int, 1>(), r); count_class(std::integral_constant<int, 2>(), r);
+                count_class(std::integral_constant<int, 3>(), r); count_class(std::integral_constant<int, 4>(), r); count_class(std::integral_constant<int, 5>(), r);
+                count_class(std::integral_constant<int, 6>(), r); count_class(std::integral_constant<int, 7>(), r);
             }
             HIP_TRY(hipGetLastError());
             prof_end(ctx);
             R->n_rounds = rounds_run;
-            IrCnt* fn_tot = tmp2.get<IrCnt>(n_funcs + 1);      // per function: its totals, then (exclusive scan) its place; [n_funcs] = the sum
-            HIP_TRY(hipMemsetAsync(fn_tot, 0, ((size_t)n_funcs + 1) * sizeof(IrCnt), st));
+            IrCnt* fn_tot = tmp2.get<IrCnt>(n_funcs + 2);      // per function: its totals, then (exclusive scan) its place; [n_funcs] = the sum, [n_funcs + 1] = where the flat path's ranges start
+            HIP_TRY(hipMemsetAsync(fn_tot, 0, ((size_t)n_funcs + 2) * sizeof(IrCnt), st));
             LAUNCH(ctx, "lower_scan", par::k_flat_scan, grid_for((uint64_t)n_defs * 64, 256), 256, S, PA, X, fn_tot);
             prof_begin(ctx, "lower_scan_funcs");
             device_scan<true>(fn_tot, fn_tot, n_funcs, OpAddIrCnt(), IrCnt{0, 0, 0, 0, 0, 0}, (IrCnt*)scan_tmp, fn_tot + n_funcs, st);
             prof_end(ctx);
-            LAUNCH(ctx, "lower_bases", par::k_flat_bases, grid_for(n_funcs, 256), 256, PA, X, (const IrCnt*)fn_tot, (const IrCnt*)(fn_tot + n_funcs), n_funcs);
+            LAUNCH(ctx, "lower_reserve", par::k_flat_reserve, 1, 64, PA, (const IrCnt*)(fn_tot + n_funcs), fn_tot + n_funcs + 1);
+            LAUNCH(ctx, "lower_bases", par::k_flat_bases, grid_for(n_funcs, 256), 256, PA, X, (const IrCnt*)fn_tot, (const IrCnt*)(fn_tot + n_funcs + 1), n_funcs);
             LAUNCH(ctx, "lower_rv", par::k_flat_rv, std::min<unsigned>(grid_for(n_nodes, 256), 4096u), 256, PA, X);
             auto launch_classes = [&](auto kernel_of_class) {
                 kernel_of_class(std::integral_constant<int, 0>()); kernel_of_class(std::integral_constant<int, 1>()); kernel_of_class(std::integral_constant<int, 2>());

@@ -99,11 +99,11 @@ enum { KC_VARIABLE = 0, KC_INTEGER = 1, KC_OPERATOR = 2, KC_SIMPLE = 3, KC_STATE
 // The unit-wide per-node state of the flat passes (temporaries of one lowering; index = node index in the unit).
 struct FnInfo { uint32_t dn, nn, nargs, ret, sym_mix, pad0, pad1, pad2; };     // what a lane needs of its function (nn == 0: not on the flat path)
 // ctl[]: control words of one lowering.  The schedule of the count pass is a table of SCHED_BINS list lengths / offsets, one per
-// (round, kind class): bin = round * KC_ACTIVE + class.
-// (the last round of the table is no round: it holds the CHAINED nodes, which the count pass reaches through their operand and the
-// other passes through the class list)
-enum : uint32_t { FLAT_MAX_ROUNDS = 2047, SCHED_BINS = (FLAT_MAX_ROUNDS + 1) * KC_ACTIVE,
-                  CTL_OFF = 0 /* KC_ACTIVE + 1 class offsets into `order` */, CTL_ORDER = 16 /* KC_ACTIVE counts: all nodes of a class */, CTL_OCUR = 32 /* KC_ACTIVE cursors of the class list's scatter */, CTL_NSTAGE1 = 48 /* stage-1 entries: in the bins of KC_CONTROL, not in the class list */, CTL_DBG = 30, CTL_LISTOVF = 31 /* a list region was too small (never) */,
+// (kind class, round): bin = class * SCHED_R + round.  A class's bins follow each other, so the nodes of a class — what the emit
+// pass goes through — are one range of the list, and (class, round) — one launch of the count pass — is a range inside it.
+// (The last round of a class is no round: it holds the CHAINED nodes, which the count pass reaches through their operand.)
+enum : uint32_t { SCHED_R = 2048, FLAT_MAX_ROUNDS = SCHED_R - 1, SCHED_BINS = KC_ACTIVE * SCHED_R,
+                  CTL_OCUR = 16 /* KC_ACTIVE cursors: the end of every class's part of `order` */, CTL_DBG = 30, CTL_LISTOVF = 31 /* a list was too small (never) */,
                   CTL_BINS = 64 /* SCHED_BINS + 1: lengths, then exclusive offsets, of the schedule's bins */,
                   CTL_CURSOR = CTL_BINS + SCHED_BINS + 64 /* SCHED_BINS: where the next block's nodes of a bin go */, CTL_WORDS = CTL_CURSOR + SCHED_BINS + 64 };
 enum : uint32_t { FB_NOFIT = 0xFFFFFFFEu };   // fb[]: the function counted, but its place in a result array is beyond the array (the host runs again)
@@ -115,10 +115,12 @@ struct NodeRec { uint64_t rt; uint32_t st, ref, rvi; uint16_t pe, sz, pa, loc /*
 static_assert(sizeof(NodeRec) == 32, "NodeRec is one 32-byte sector");
 struct FlatArgs {
     NodeRec* rec; uint64_t* cnt; uint8_t* tail; uint16_t* cg;
-    uint16_t* key; uint16_t* key1;     // schedule bin of every node (NONE16: not listed); key1: the bin of stage 1 of a `for` node
+    uint16_t* key1;           // the schedule bin of stage 1 of a `for` node (NONE16: none).  The bin of the node itself travels in its two
+                              // `tail` bytes (NONE16: not listed), which are cleared again before the count pass writes them.
     FnInfo* fninfo; uint32_t* fb;      // per function: fb != 0 = declined (source line of the reason)
-    uint32_t* order;          // all nodes that are lowered, by kind class (regions CTL_OFF): the emit pass goes through it
-    uint32_t* sched;          // the same nodes by (round, class): the count pass goes through one round after the other
+    uint32_t* sched;          // every node that is lowered, by (class, round), and stage 1 of every `for` (entry | SCHED_STAGE1): the count pass
+    uint32_t* order;          // every node that is lowered, by class and within a class in node order (blocks of 64 K nodes): the emit pass, which
+                              // then meets a function's nodes together.  Class c starts where it starts in `sched` and ends at ctl[CTL_OCUR + c].
     uint32_t* ctl;
 };
 
@@ -1305,18 +1307,19 @@ template <class F> __device__ __forceinline__ bool literal_waits_for_lhs(const F
 // Both passes over the (bin, node) pairs: a block histograms its share in LDS (64 KB: one word per bin); HIST adds the non-empty bins
 // to the unit's table, SCATTER takes a range of every non-empty bin from the bin's cursor and deals it out to the block's nodes.
 template <bool SCATTER> __global__ __launch_bounds__(1024) void k_sched_pass(FlatArgs X, uint32_t n_nodes, uint32_t per_block, uint32_t cap) {
+    const uint16_t* const key = (const uint16_t*)X.tail;
 #ifdef OPUSFE_EMU
     // (one emulated lane: plain counting)
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     for (uint32_t g = 0; g < n_nodes; g++) for (int w = 0; w < 2; w++) {
-        const uint32_t k = w ? X.key1[g] : X.key[g];
+        const uint32_t k = w ? X.key1[g] : key[g];
         if (k == NONE16) continue;
         if (k >= SCHED_BINS) { X.ctl[CTL_LISTOVF] = 1; continue; }
-        if (!SCATTER) { X.ctl[CTL_BINS + k]++; if (w) X.ctl[CTL_NSTAGE1]++; }
+        if (!SCATTER) X.ctl[CTL_BINS + k]++;
         else {
             const uint32_t at = X.ctl[CTL_CURSOR + k]++;
             if (at < cap) X.sched[at] = g | (w ? (uint32_t)SCHED_STAGE1 : 0u); else X.ctl[CTL_LISTOVF] = 1;
-            if (!w) { const uint32_t c = k % KC_ACTIVE, ao = X.ctl[CTL_OFF + c] + X.ctl[CTL_OCUR + c]++; if (ao < cap) X.order[ao] = g; else X.ctl[CTL_LISTOVF] = 1; }
+            if (!w) { const uint32_t ao = X.ctl[CTL_OCUR + k / SCHED_R]++; if (ao < cap) X.order[ao] = g; else X.ctl[CTL_LISTOVF] = 1; }
         }
     }
 #else
@@ -1326,10 +1329,9 @@ template <bool SCATTER> __global__ __launch_bounds__(1024) void k_sched_pass(Fla
     __syncthreads();
     const uint64_t lo = (uint64_t)blockIdx.x * per_block, hi = lo + per_block < n_nodes ? lo + per_block : n_nodes;
     for (uint64_t g = lo + threadIdx.x; g < hi; g += blockDim.x) {
-        const uint32_t k = X.key[g], k1 = X.key1[g];
-        if (k != NONE16) { if (k < SCHED_BINS) atomicAdd(&sched_lds[k], 1u); else atomicMax(X.ctl + CTL_LISTOVF, 1u); }
-        if (k1 != NONE16) { if (k1 < SCHED_BINS) { atomicAdd(&sched_lds[k1], 1u); if (!SCATTER) atomicAdd(&cls[0], 1u); } else atomicMax(X.ctl + CTL_LISTOVF, 1u); }
-        if (SCATTER && k != NONE16 && k < SCHED_BINS) atomicAdd(&cls[k % KC_ACTIVE], 1u);
+        const uint32_t k = key[g], k1 = X.key1[g];
+        if (k != NONE16) { if (k < SCHED_BINS) { atomicAdd(&sched_lds[k], 1u); if (SCATTER) atomicAdd(&cls[k / SCHED_R], 1u); } else atomicMax(X.ctl + CTL_LISTOVF, 1u); }
+        if (k1 != NONE16) { if (k1 < SCHED_BINS) atomicAdd(&sched_lds[k1], 1u); else atomicMax(X.ctl + CTL_LISTOVF, 1u); }
     }
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < SCHED_BINS; b += blockDim.x) {
@@ -1338,13 +1340,13 @@ template <bool SCATTER> __global__ __launch_bounds__(1024) void k_sched_pass(Fla
         if (!SCATTER) atomicAdd(X.ctl + CTL_BINS + b, c);
         else sched_lds[b] = atomicAdd(X.ctl + CTL_CURSOR + b, c);      // the block's first slot of the bin
     }
-    if (!SCATTER) { if (threadIdx.x == 0 && cls[0]) atomicAdd(X.ctl + CTL_NSTAGE1, cls[0]); return; }
-    if (threadIdx.x < KC_ACTIVE) { const uint32_t c = cls[threadIdx.x]; cls[threadIdx.x] = X.ctl[CTL_OFF + threadIdx.x] + (c ? atomicAdd(X.ctl + CTL_OCUR + threadIdx.x, c) : 0u); }
+    if (!SCATTER) return;
+    if (threadIdx.x < KC_ACTIVE) { const uint32_t c = cls[threadIdx.x]; cls[threadIdx.x] = c ? atomicAdd(X.ctl + CTL_OCUR + threadIdx.x, c) : 0u; }
     __syncthreads();
     for (uint64_t g = lo + threadIdx.x; g < hi; g += blockDim.x) {
-        const uint32_t k = X.key[g], k1 = X.key1[g];
+        const uint32_t k = key[g], k1 = X.key1[g];
         if (k != NONE16 && k < SCHED_BINS) {
-            const uint32_t at = atomicAdd(&sched_lds[k], 1u), ao = atomicAdd(&cls[k % KC_ACTIVE], 1u);
+            const uint32_t at = atomicAdd(&sched_lds[k], 1u), ao = atomicAdd(&cls[k / SCHED_R], 1u);
             if (at < cap) X.sched[at] = (uint32_t)g; else atomicMax(X.ctl + CTL_LISTOVF, 1u);
             if (ao < cap) X.order[ao] = (uint32_t)g; else atomicMax(X.ctl + CTL_LISTOVF, 1u);
         }
@@ -1352,42 +1354,26 @@ template <bool SCATTER> __global__ __launch_bounds__(1024) void k_sched_pass(Fla
     }
 #endif
 }
-// lengths -> exclusive offsets (CTL_BINS, SCHED_BINS + 1 words) and the cursors of the scatter pass; the class list's regions
-// (CTL_OFF / CTL_ORDER: every node of a class, whatever its round; stage-1 entries are not nodes of their own).  One block.
+// lengths -> exclusive offsets (CTL_BINS, SCHED_BINS + 1 words) and the cursors of the scatter pass.  One block.
 __global__ __launch_bounds__(1024) void k_sched_scan(uint32_t* __restrict__ ctl) {
 #ifdef OPUSFE_EMU
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    uint32_t clsn[KC_ACTIVE] = {0};
-    for (uint32_t b = 0; b < SCHED_BINS; b++) clsn[b % KC_ACTIVE] += ctl[CTL_BINS + b];
-    clsn[KC_CONTROL] -= ctl[CTL_NSTAGE1];
     uint32_t run = 0;
     for (uint32_t b = 0; b < SCHED_BINS; b++) { const uint32_t c = ctl[CTL_BINS + b]; ctl[CTL_BINS + b] = run; ctl[CTL_CURSOR + b] = run; run += c; }
     ctl[CTL_BINS + SCHED_BINS] = run;
-    uint32_t o = 0;
-    for (uint32_t c = 0; c < KC_ACTIVE; c++) { ctl[CTL_OFF + c] = o; ctl[CTL_ORDER + c] = clsn[c]; ctl[CTL_OCUR + c] = 0; o += clsn[c]; }
-    ctl[CTL_OFF + KC_ACTIVE] = o;
+    for (uint32_t c = 0; c < KC_ACTIVE; c++) ctl[CTL_OCUR + c] = ctl[CTL_BINS + c * SCHED_R];
 #else
     __shared__ uint32_t part[1024];
-    __shared__ uint32_t clsn[KC_ACTIVE];
-    constexpr uint32_t PER = SCHED_BINS / 1024;      // (a multiple of KC_ACTIVE: a thread's bins are whole rounds)
+    constexpr uint32_t PER = SCHED_BINS / 1024;
     const uint32_t t = threadIdx.x;
-    if (t < KC_ACTIVE) clsn[t] = 0;
-    __syncthreads();
     uint32_t sum = 0;
-    for (uint32_t k = 0; k < PER; k++) { const uint32_t c = ctl[CTL_BINS + t * PER + k]; sum += c; if (c) atomicAdd(&clsn[(t * PER + k) % KC_ACTIVE], c); }
+    for (uint32_t k = 0; k < PER; k++) sum += ctl[CTL_BINS + t * PER + k];
     part[t] = sum;
     __syncthreads();
-    if (t == 0) {
-        clsn[KC_CONTROL] -= ctl[CTL_NSTAGE1];
-        uint32_t run = 0; for (uint32_t k = 0; k < 1024; k++) { const uint32_t v = part[k]; part[k] = run; run += v; } ctl[CTL_BINS + SCHED_BINS] = run;
-        uint32_t o = 0;
-        for (uint32_t c = 0; c < KC_ACTIVE; c++) { ctl[CTL_OFF + c] = o; ctl[CTL_OCUR + c] = 0; o += clsn[c]; }
-        ctl[CTL_OFF + KC_ACTIVE] = o;
-    }
+    if (t == 0) { uint32_t run = 0; for (uint32_t k = 0; k < 1024; k++) { const uint32_t v = part[k]; part[k] = run; run += v; } ctl[CTL_BINS + SCHED_BINS] = run; }
     __syncthreads();
-    if (t < KC_ACTIVE) ctl[CTL_ORDER + t] = clsn[t];
     uint32_t run = part[t];
-    for (uint32_t k = 0; k < PER; k++) { const uint32_t c = ctl[CTL_BINS + t * PER + k]; ctl[CTL_BINS + t * PER + k] = run; ctl[CTL_CURSOR + t * PER + k] = run; run += c; }
+    for (uint32_t k = 0; k < PER; k++) { const uint32_t c = ctl[CTL_BINS + t * PER + k]; ctl[CTL_BINS + t * PER + k] = run; ctl[CTL_CURSOR + t * PER + k] = run; if ((t * PER + k) % SCHED_R == 0) ctl[CTL_OCUR + (t * PER + k) / SCHED_R] = run; run += c; }
 #endif
 }
 
@@ -1416,11 +1402,26 @@ template <int C> __device__ __forceinline__ void count_one(const SemView& S, con
         i = p;
     }
 }
-// One launch per (round, class) of the schedule: entries [begin, begin + n) of `sched`.  C == KC_ANY: a whole round with few nodes
-// in one launch (the bins of a round follow each other).
-template <int C> __global__ __launch_bounds__(256) void k_flat_count(SemView S, ParArgs A, FlatArgs X, uint32_t begin, uint32_t n) {
+// One launch per (class, round) of the schedule: entries [begin, begin + n) of `sched`.
+#ifndef OPUSFE_FLAT_WAVES
+#define OPUSFE_FLAT_WAVES 0
+#endif
+#if OPUSFE_FLAT_WAVES
+#define FLAT_ATTR __attribute__((amdgpu_waves_per_eu(OPUSFE_FLAT_WAVES)))
+#else
+#define FLAT_ATTR
+#endif
+template <int C> __global__ FLAT_ATTR __launch_bounds__(256) void k_flat_count(SemView S, ParArgs A, FlatArgs X, uint32_t begin, uint32_t n) {
     const uint32_t* in = X.sched + begin;
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) count_one<C>(S, A, X, in[k]);
+}
+// a whole round with few nodes in one launch: the round's bin of every class
+__global__ __launch_bounds__(256) void k_flat_count_round(SemView S, ParArgs A, FlatArgs X, uint32_t round) {
+    for (uint32_t c = 0; c < KC_ACTIVE; c++) {
+        const uint32_t begin = X.ctl[CTL_BINS + c * SCHED_R + round], n = X.ctl[CTL_BINS + c * SCHED_R + round + 1] - begin;
+        const uint32_t* in = X.sched + begin;
+        for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) count_one<KC_ANY>(S, A, X, in[k]);
+    }
 }
 
 // ---- scan: one wave per function ------------------------------------------------------------------------------------------
@@ -1482,25 +1483,26 @@ __global__ __launch_bounds__(256) void k_flat_scan(SemView S, ParArgs A, FlatArg
     A.out[fidx] = r;                                           // (its bases: k_flat_bases)
     tot[fidx] = IrCnt{tv, ti, tb, tt, total_cg, 0};
 }
-// the functions' places in the dense arrays from the exclusive scan of their totals; the bump counters (which the functions of the
-// sequential machine go on from, k_fb_bases) start at the flat path's totals
-__global__ void k_flat_bases(ParArgs A, FlatArgs X, const IrCnt* __restrict__ excl, const IrCnt* __restrict__ total, uint32_t n_funcs) {
+// The functions' places in the dense arrays: the flat path takes ONE range of every array (its totals, with one atomic per array on the
+// bump counters that the functions of the sequential machine use too, k_fb_bases — they may run beside this on the second stream),
+// and every function its place inside that range from the exclusive scan of the functions' totals.
+__global__ void k_flat_reserve(ParArgs A, const IrCnt* __restrict__ total, IrCnt* __restrict__ origin) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const IrCnt t = *total;
+    const Bases b = bump_allocate(A, t.vars, t.instrs, t.bbs, t.types, t.cargs);      // (raises `overflow` when the range does not fit)
+    *origin = IrCnt{b.var_base, b.instr_base, b.bb_base, b.type_base, b.carg_base, 0};
+}
+__global__ void k_flat_bases(ParArgs A, FlatArgs X, const IrCnt* __restrict__ excl, const IrCnt* __restrict__ origin, uint32_t n_funcs) {
     const uint32_t fidx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (fidx == 0) {
-        const IrCnt t = *total;
-        A.counters[CTR_INSTR_BB] = (unsigned long long)t.instrs | ((unsigned long long)t.bbs << CTR_BB_SHIFT);
-        A.counters[CTR_VARS] = t.vars; A.counters[CTR_TYPES] = t.types; A.counters[CTR_CARGS] = t.cargs;
-        if (t.instrs > A.cap_instrs || t.bbs > A.cap_bbs || t.vars > A.cap_vars || t.types > A.cap_types || t.cargs > A.cap_cargs) atomicMax(A.overflow, 1u);
-    }
     if (fidx >= n_funcs) return;
     if (gld(X.fninfo + fidx).nn == 0 || gld(X.fb + fidx) != 0) return;
     FuncIr r = A.out[fidx];
     if (r.status != DS_OK) return;
-    const IrCnt e = excl[fidx];
-    r.var_base = e.vars; r.instr_base = e.instrs; r.bb_base = e.bbs; r.type_base = e.types; r.carg_base = e.cargs;
+    const IrCnt e = excl[fidx], o = *origin;
+    const uint64_t vb = (uint64_t)o.vars + e.vars, ib = (uint64_t)o.instrs + e.instrs, bb = (uint64_t)o.bbs + e.bbs, tb = (uint64_t)o.types + e.types, cb = (uint64_t)o.cargs + e.cargs;
+    r.var_base = (uint32_t)vb; r.instr_base = (uint32_t)ib; r.bb_base = (uint32_t)bb; r.type_base = (uint32_t)tb; r.carg_base = (uint32_t)cb;
     A.out[fidx] = r;
-    const bool fits = (uint64_t)e.instrs + r.n_instrs <= A.cap_instrs && (uint64_t)e.bbs + r.n_bbs <= A.cap_bbs && (uint64_t)e.vars + r.n_vars <= A.cap_vars
-                   && (uint64_t)e.types + r.n_types <= A.cap_types && (uint64_t)e.cargs + r.n_cargs <= A.cap_cargs;
+    const bool fits = ib + r.n_instrs <= A.cap_instrs && bb + r.n_bbs <= A.cap_bbs && vb + r.n_vars <= A.cap_vars && tb + r.n_types <= A.cap_types && cb + r.n_cargs <= A.cap_cargs;
     if (!fits) X.fb[fidx] = FB_NOFIT;                        // nothing is written beyond an array; the host runs again with arrays of the exact size
 }
 
@@ -1533,13 +1535,13 @@ __global__ __launch_bounds__(256) void k_flat_rv(ParArgs A, FlatArgs X) {
 }
 
 // ---- emit -----------------------------------------------------------------------------------------------------------------
-template <int C> __global__ __launch_bounds__(256) void k_flat_emit(SemView S, ParArgs A, FlatArgs X) {
-    constexpr uint32_t c = C == KC_ANY ? 0u : (uint32_t)C;
-    const uint32_t* in = X.order + X.ctl[CTL_OFF + c];
-    const uint32_t n = X.ctl[CTL_ORDER + c];
+template <int C> __global__ FLAT_ATTR __launch_bounds__(256) void k_flat_emit(SemView S, ParArgs A, FlatArgs X) {
+    const uint32_t begin = X.ctl[CTL_BINS + (uint32_t)C * SCHED_R], n = X.ctl[CTL_OCUR + (uint32_t)C] - begin;      // every node of the class, the chained ones too
+    const uint32_t* in = X.order + begin;
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t entry = in[k];
         Fn f; uint32_t i;
-        if (!make_fn(f, S, A, X, in[k], &i, true)) continue;
+        if (!make_fn(f, S, A, X, entry, &i, true)) continue;
         const FuncIr r = gld(A.out + f.fidx);
         f.var_base = r.var_base; f.instr_base = r.instr_base; f.bb_base = r.bb_base; f.type_base = r.type_base; f.carg_base = r.carg_base;
         f.n_vars_tot = r.n_vars; f.n_instrs_tot = r.n_instrs; f.n_bbs_tot = r.n_bbs; f.n_types_tot = r.n_types; f.n_cargs_tot = r.n_cargs;
@@ -1945,8 +1947,8 @@ __device__ __forceinline__ void pre_function(Pre& f, const FlatArgs& X) {
         gst(w + 2, (uint64_t)0 /* rvi */ | ((uint64_t)(uint16_t)f.pe[i] << 32) | ((uint64_t)(uint16_t)f.sz[i] << 48));
         gst(w + 3, (uint64_t)(uint16_t)f.pa[i] | ((uint64_t)i << 16) | ((uint64_t)f.fidx << 32));
         gst(X.cg + g, (uint16_t)f.cg[i]);
-        gst(X.key + g, (uint16_t)(listed ? ((s & ST_CHAINED) ? (uint32_t)FLAT_MAX_ROUNDS : (uint32_t)f.rk[i]) * KC_ACTIVE + c : (uint32_t)NONE16));
-        gst(X.key1 + g, (uint16_t)((listed && KIND(f, i) == S_For) ? (uint32_t)f.s1[i] * KC_ACTIVE + KC_CONTROL : (uint32_t)NONE16));
+        gst((uint16_t*)(X.tail + 2ull * g), (uint16_t)(listed ? c * SCHED_R + ((s & ST_CHAINED) ? (uint32_t)FLAT_MAX_ROUNDS : (uint32_t)f.rk[i]) : (uint32_t)NONE16));
+        gst(X.key1 + g, (uint16_t)((listed && KIND(f, i) == S_For) ? (uint32_t)KC_CONTROL * SCHED_R + f.s1[i] : (uint32_t)NONE16));
     }
     {
         const uint32_t nd = f.misc[MI_NDEFS];

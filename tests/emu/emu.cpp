@@ -287,49 +287,47 @@ void emu_lower(EmuUnit& E) {
             uint32_t* ctl = exact<uint32_t>(par::CTL_WORDS);
             X.ctl = ctl; X.fninfo = fninfo.data(); X.fb = fbw.data();
             X.rec = exact<par::NodeRec>(n_nodes); X.cnt = exact<uint64_t>(2ull * n_nodes); X.tail = exact<uint8_t>(2ull * n_nodes); X.cg = exact<uint16_t>(n_nodes);
-            X.key = exact<uint16_t>(n_nodes); X.key1 = exact<uint16_t>(n_nodes);
-            memset(X.key, 0xFF, 2ull * n_nodes); memset(X.key1, 0xFF, 2ull * n_nodes);
-            // (everything else a pass reads was written by an earlier pass: poison, so that a read of an unwritten word shows)
+            X.key1 = exact<uint16_t>(n_nodes);
+            memset(X.key1, 0xFF, 2ull * n_nodes); memset(X.tail, 0xFF, 2ull * n_nodes);      // (the bins of the schedule: NONE16 = none)
             memset((void*)X.rec, 0xFF, sizeof(par::NodeRec) * (size_t)n_nodes); memset(X.cg, 0xA5, 2ull * n_nodes);
-            memset(X.cnt, 0, 16ull * n_nodes); memset(X.tail, 0, 2ull * n_nodes);      // as run_lower clears them
+            memset(X.cnt, 0, 16ull * n_nodes);      // as run_lower clears them
             const size_t lds = par::lds_bytes(PA.nmax, PA.maxdef, 1);
             par::g_emu_lds = (uint32_t*)malloc(lds);
             memset(par::g_emu_lds, 0xA5, lds);
             emu_launch(par::k_flat_pre, n_defs, 1, S, PA, X);
             free(par::g_emu_lds); par::g_emu_lds = nullptr;
-            // the schedule: counting sort of the (round, class) bins, then one launch per bin in round order (run_lower's plan)
+            // the schedule: counting sort of the (class, round) bins, then one launch per bin in round order (run_lower's plan)
             emu_launch(par::k_sched_pass<false>, 1, 1, X, n_nodes, n_nodes, 0u);
             emu_launch(par::k_sched_scan, 1, 1, ctl);
-            const uint32_t n_all = ctl[par::CTL_BINS + par::SCHED_BINS], n_list = ctl[par::CTL_OFF + par::KC_ACTIVE];
-            const uint32_t n_sched = ctl[par::CTL_BINS + par::FLAT_MAX_ROUNDS * par::KC_ACTIVE];      // (behind it: the chained nodes)
-            X.sched = exact<uint32_t>(n_all); X.order = exact<uint32_t>(n_list);
-            emu_launch(par::k_sched_pass<true>, 1, 1, X, n_nodes, n_nodes, n_all);
             const uint32_t* off = ctl + par::CTL_BINS;
+            const uint32_t n_sched = off[par::SCHED_BINS], n_list = n_sched;
+            X.sched = exact<uint32_t>(n_sched); X.order = exact<uint32_t>(n_sched);
+            emu_launch(par::k_sched_pass<true>, 1, 1, X, n_nodes, n_nodes, n_sched);
+            memset(X.tail, 0, 2ull * n_nodes);
             const uint32_t any_below = getenv("EMU_FLAT_TAIL") ? (uint32_t)atoi(getenv("EMU_FLAT_TAIL")) : 64u;
             uint32_t rounds = 0;
             for (uint32_t r = 0; r < par::FLAT_MAX_ROUNDS; r++) {
-                const uint32_t lo = off[r * par::KC_ACTIVE], hi = off[(r + 1) * par::KC_ACTIVE];
-                if (lo == n_sched) break;
-                if (hi == lo) continue;
+                uint64_t n_round = 0;
+                for (uint32_t c = 0; c < par::KC_ACTIVE; c++) n_round += off[c * par::SCHED_R + r + 1] - off[c * par::SCHED_R + r];
+                if (!n_round) break;
                 rounds = r + 1;
-                if (hi - lo <= any_below) { emu_launch(par::k_flat_count<par::KC_ANY>, 1, 1, S, PA, X, lo, hi - lo); continue; }
-                const uint32_t* o = off + r * par::KC_ACTIVE;
-                emu_launch(par::k_flat_count<0>, 1, 1, S, PA, X, o[0], o[1] - o[0]); emu_launch(par::k_flat_count<1>, 1, 1, S, PA, X, o[1], o[2] - o[1]);
-                emu_launch(par::k_flat_count<2>, 1, 1, S, PA, X, o[2], o[3] - o[2]); emu_launch(par::k_flat_count<3>, 1, 1, S, PA, X, o[3], o[4] - o[3]);
-                emu_launch(par::k_flat_count<4>, 1, 1, S, PA, X, o[4], o[5] - o[4]); emu_launch(par::k_flat_count<5>, 1, 1, S, PA, X, o[5], o[6] - o[5]);
-                emu_launch(par::k_flat_count<6>, 1, 1, S, PA, X, o[6], o[7] - o[6]); emu_launch(par::k_flat_count<7>, 1, 1, S, PA, X, o[7], o[8] - o[7]);
+                if (n_round <= any_below) { emu_launch(par::k_flat_count_round, 1, 1, S, PA, X, r); continue; }
+#define EMU_COUNT(C) emu_launch(par::k_flat_count<C>, 1, 1, S, PA, X, off[C * par::SCHED_R + r], off[C * par::SCHED_R + r + 1] - off[C * par::SCHED_R + r])
+                EMU_COUNT(0); EMU_COUNT(1); EMU_COUNT(2); EMU_COUNT(3); EMU_COUNT(4); EMU_COUNT(5); EMU_COUNT(6); EMU_COUNT(7);
             }
 #define EMU_CLASSES(K, ...) do { emu_launch(par::K<0>, 1, 1, __VA_ARGS__); emu_launch(par::K<1>, 1, 1, __VA_ARGS__); emu_launch(par::K<2>, 1, 1, __VA_ARGS__); emu_launch(par::K<3>, 1, 1, __VA_ARGS__); \
                                      emu_launch(par::K<4>, 1, 1, __VA_ARGS__); emu_launch(par::K<5>, 1, 1, __VA_ARGS__); emu_launch(par::K<6>, 1, 1, __VA_ARGS__); emu_launch(par::K<7>, 1, 1, __VA_ARGS__); } while (0)
             std::vector<IrCnt> fn_tot(n_funcs + 1, IrCnt{0, 0, 0, 0, 0, 0});
             emu_launch(par::k_flat_scan, grid_for(n_defs, 256), 256, S, PA, X, fn_tot.data());
             { IrCnt run{0, 0, 0, 0, 0, 0}; for (uint32_t k = 0; k < n_funcs; k++) { const IrCnt c = fn_tot[k]; fn_tot[k] = run; run = OpAddIrCnt()(run, c); } fn_tot[n_funcs] = run; }
-            emu_launch(par::k_flat_bases, grid_for(n_funcs, 256), 256, PA, X, (const IrCnt*)fn_tot.data(), (const IrCnt*)(fn_tot.data() + n_funcs), n_funcs);
+            fn_tot.push_back(IrCnt{0, 0, 0, 0, 0, 0});
+            emu_launch(par::k_flat_reserve, 1, 1, PA, (const IrCnt*)(fn_tot.data() + n_funcs), fn_tot.data() + n_funcs + 1);
+            emu_launch(par::k_flat_bases, grid_for(n_funcs, 256), 256, PA, X, (const IrCnt*)fn_tot.data(), (const IrCnt*)(fn_tot.data() + n_funcs + 1), n_funcs);
             emu_launch(par::k_flat_rv, 1, 1, PA, X);
             EMU_CLASSES(k_flat_emit, S, PA, X);
             if (ctl[par::CTL_LISTOVF]) lstatus[0] = DS_INTERNAL_CAPACITY;
             if (getenv("EMU_VERBOSE")) fprintf(stderr, "flat lowering: %u rounds, %u listed nodes of %u\n", rounds, n_list, n_nodes);
-            free(ctl); free(X.rec); free(X.cnt); free(X.tail); free(X.cg); free(X.key); free(X.key1); free(X.order); free(X.sched);
+            free(ctl); free(X.rec); free(X.cnt); free(X.tail); free(X.cg); free(X.key1); free(X.sched); free(X.order);
         }
         emu_launch(k_fb_mark, grid_for(n_defs, 256), 256, (const FuncIr*)R->funcs.data(), n_funcs, def_nodes, n_defs, n_nodes, (const DefCnt*)def_excl.data(), nodes, fb_flag.data(), fbx.data());
         FbIdx fbt{0, 0};
