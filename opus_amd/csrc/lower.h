@@ -1660,7 +1660,7 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
     HIP_TRY(hipStreamSynchronize(st));
     prof_collect(ctx);
     R->n_funcs = n_funcs; R->n_globals = n_globals; R->n_gtypes = n_gtypes;
-    // Diagnostic switches exist only in a -DOPUSFE_DIAG build (tools/par_*.sh): the shipped library has one behaviour.
+    // The diagnostic switch exists only in a -DOPUSFE_DIAG build (tools/build_diag.sh): the shipped library has one behaviour.
 #ifdef OPUSFE_DIAG
     static const bool seq_only = getenv("OPUSFE_LOWER_SEQ") != nullptr;     // everything through the sequential machine
 #else

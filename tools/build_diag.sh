@@ -1,6 +1,6 @@
 #!/bin/bash
-# Builds opus_amd/_build/libopusfe_diag.so with -DOPUSFE_DIAG: the diagnostic switches of run_lower (OPUSFE_PAR_STOP, OPUSFE_PAR_ROUNDS,
-# OPUSFE_PAR_CLIMB, OPUSFE_PAR_SHAPE, OPUSFE_PAR_SLACK, OPUSFE_LOWER_SEQ) exist only in this build; the tools/par_*.sh scripts load it
+# Builds opus_amd/_build/libopusfe_diag.so with -DOPUSFE_DIAG: the diagnostic switch of run_lower (OPUSFE_LOWER_SEQ: every function through
+# the sequential machine) exists only in this build; load it
 # through OPUSFE_LIB.  The shipped libopusfe.so reads none of them.
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)

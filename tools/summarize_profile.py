@@ -61,13 +61,14 @@ for r in stats:
     if fetch[k][0] and write[k][0]:
         name = k[2:] if k.startswith("k_") else k
         traffic["kernels"][name] = {"fetch": fetch[k][1] / fetch[k][0] * 1e3, "write": write[k][1] / write[k][0] * 1e3, "avg_ms": float(r["AverageNs"]) / 1e6}
-# bench.py prices the node-parallel lowering as ONE kernel "lower_par" (k_lower_par<THREADS>, one launch per size class):
-# per-launch averages over all its instantiations
-par = [(k, fetch[k], write[k], r) for r in stats for k in [short(r["Name"])] if k.startswith("par::k_lower_par") and fetch[k][0] and write[k][0]]
-if par:
-    calls = sum(int(r["Calls"]) for _, _, _, r in par)
-    traffic["kernels"]["lower_par"] = {"fetch": sum(f[1] for _, f, _, _ in par) / sum(f[0] for _, f, _, _ in par) * 1e3,
-                                       "write": sum(w[1] for _, _, w, _ in par) / sum(w[0] for _, _, w, _ in par) * 1e3,
-                                       "avg_ms": sum(float(r["AverageNs"]) * int(r["Calls"]) for _, _, _, r in par) / calls / 1e6, "calls": calls}
+# bench.py prices the flat lowering as ONE unit per step, "lower_flat" (all kernels of lower_par.h): traffic and time per STEP, summed
+# over every launch of every one of its kernels (steps = the launches of k_flat_scan, one per step)
+flat = [(k, fetch[k], write[k], r) for r in stats for k in [short(r["Name"])] if (k.startswith("par::k_flat_") or k.startswith("par::k_sched_")) and fetch[k][0] and write[k][0]]
+scan = [x for x in flat if x[0].startswith("par::k_flat_scan")]
+if flat and scan:
+    steps_f, steps_w, steps_t = scan[0][1][0], scan[0][2][0], int(scan[0][3]["Calls"])
+    traffic["kernels"]["lower_flat"] = {"fetch": sum(f[1] for _, f, _, _ in flat) / steps_f * 1e3, "write": sum(w[1] for _, _, w, _ in flat) / steps_w * 1e3,
+                                        "avg_ms": sum(float(r["TotalDurationNs"]) for _, _, _, r in flat) / steps_t / 1e6, "calls": sum(int(r["Calls"]) for _, _, _, r in flat),
+                                        "note": "per step: every launch of every kernel of the flat lowering"}
 json.dump(traffic, open(os.path.join("profiles", f"{tag}_traffic.json"), "w"), indent=1)
 print(open(os.path.join("profiles", f"{tag}_summary.md")).read())
