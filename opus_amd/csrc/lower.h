@@ -1809,9 +1809,13 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
                                                   "lower_pre_768", "lower_pre_1024", "lower_pre_1536", "lower_pre_2048", "lower_pre"};
             const uint32_t c_top = order_class_of_size(2047), c_small = order_class_of_size(63);     // classes above c_top: sequential machine
             int name_i = 10;
+            // (a small unit — BASELINE configuration 2 — is one launch of the largest shape: ten launches of a few functions each are ten
+            // times the latency of one function)
+            const bool one_launch = n_funcs <= 1024;
             for (uint32_t c = c_top; c >= c_small; c--, name_i--) {
                 // the smallest launch takes every class up to c_small
-                const uint32_t lo = class_end[c + 1], hi = c == c_small ? n_defs : class_end[c];
+                const uint32_t lo = class_end[c + 1], hi = (c == c_small || one_launch) ? n_defs : class_end[c];
+                if (one_launch && c != c_top) break;
                 if (hi <= lo) continue;
                 par::ParArgs a = PA;
                 a.list = order + lo; a.n_list = hi - lo;
@@ -1867,13 +1871,14 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
                 const uint32_t begin = off[c * par::SCHED_R + r], n = off[c * par::SCHED_R + r + 1] - begin;
                 if (n) hipLaunchKernelGGL(par::k_flat_count<c>, dim3(std::min<unsigned>(grid_for(n, 256), 4096u)), dim3(256), 0, st, S, PA, X, begin, n);
             };
-            uint32_t rounds_run = 0;
+            auto round_nodes = [&](uint32_t r) { uint64_t n = 0; for (uint32_t c = 0; c < par::KC_ACTIVE; c++) n += off[c * par::SCHED_R + r + 1] - off[c * par::SCHED_R + r]; return n; };
+            // (every function's rounds start at 0: the first empty round ends them all); the tail = the rounds from which on none has more than 2048 nodes
+            uint32_t rounds_run = 0, tail_from = 0;
+            while (rounds_run < par::FLAT_MAX_ROUNDS && round_nodes(rounds_run)) { if (round_nodes(rounds_run) > 2048u) tail_from = rounds_run + 1; rounds_run++; }
             prof_begin(ctx, "lower_count");
-            for (uint32_t r = 0; r < par::FLAT_MAX_ROUNDS; r++) {
-                uint64_t n_round = 0;
-                for (uint32_t c = 0; c < par::KC_ACTIVE; c++) n_round += off[c * par::SCHED_R + r + 1] - off[c * par::SCHED_R + r];
-                if (!n_round) break;                               // (every function's rounds start at 0: the first empty round ends them all)
-                rounds_run = r + 1;
+            for (uint32_t r = 0; r < rounds_run; r++) {
+                const uint64_t n_round = round_nodes(r);
+                if (r >= tail_from && rounds_run - r >= 2) { hipLaunchKernelGGL(par::k_flat_count_tail, dim3(1), dim3(512), 0, st, S, PA, X, r, rounds_run); break; }
                 if (n_round <= (1u << 16)) { hipLaunchKernelGGL(par::k_flat_count_round, dim3(grid_for(n_round, 256)), dim3(256), 0, st, S, PA, X, r); continue; }
                 count_class(std::integral_constant<int, 0>(), r); count_class(std::integral_constant<int, 1>(), r); count_class(std::integral_constant<int, 2>(), r);
                 count_class(std::integral_constant<int, 3>(), r); count_class(std::integral_constant<int, 4>(), r); count_class(std::integral_constant<int, 5>(), r);

@@ -1415,6 +1415,18 @@ template <int C> __global__ FLAT_ATTR __launch_bounds__(256) void k_flat_count(S
     const uint32_t* in = X.sched + begin;
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) count_one<C>(S, A, X, in[k]);
 }
+// The tail of the schedule — rounds [r0, r1) with few nodes each — in ONE launch of ONE workgroup: a barrier between two rounds instead
+// of a kernel boundary (what a round writes leaves through this CU's L1; the workgroup-scope barrier orders it for the CU's other waves).
+__global__ __launch_bounds__(512) void k_flat_count_tail(SemView S, ParArgs A, FlatArgs X, uint32_t r0, uint32_t r1) {
+    for (uint32_t round = r0; round < r1; round++) {
+        for (uint32_t c = 0; c < KC_ACTIVE; c++) {
+            const uint32_t begin = X.ctl[CTL_BINS + c * SCHED_R + round], n = X.ctl[CTL_BINS + c * SCHED_R + round + 1] - begin;
+            const uint32_t* in = X.sched + begin;
+            for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) count_one<KC_ANY>(S, A, X, in[k]);
+        }
+        PAR_SYNC();
+    }
+}
 // a whole round with few nodes in one launch: the round's bin of every class
 __global__ __launch_bounds__(256) void k_flat_count_round(SemView S, ParArgs A, FlatArgs X, uint32_t round) {
     for (uint32_t c = 0; c < KC_ACTIVE; c++) {

@@ -305,12 +305,13 @@ void emu_lower(EmuUnit& E) {
             emu_launch(par::k_sched_pass<true>, 1, 1, X, n_nodes, n_nodes, n_sched);
             memset(X.tail, 0, 2ull * n_nodes);
             const uint32_t any_below = getenv("EMU_FLAT_TAIL") ? (uint32_t)atoi(getenv("EMU_FLAT_TAIL")) : 64u;
-            uint32_t rounds = 0;
-            for (uint32_t r = 0; r < par::FLAT_MAX_ROUNDS; r++) {
-                uint64_t n_round = 0;
-                for (uint32_t c = 0; c < par::KC_ACTIVE; c++) n_round += off[c * par::SCHED_R + r + 1] - off[c * par::SCHED_R + r];
-                if (!n_round) break;
-                rounds = r + 1;
+            auto round_nodes = [&](uint32_t r) { uint64_t n = 0; for (uint32_t c = 0; c < par::KC_ACTIVE; c++) n += off[c * par::SCHED_R + r + 1] - off[c * par::SCHED_R + r]; return n; };
+            uint32_t rounds = 0, tail_from = 0;
+            const uint32_t tail_below = getenv("EMU_FLAT_TAILKERNEL") ? (uint32_t)atoi(getenv("EMU_FLAT_TAILKERNEL")) : 16u;
+            while (rounds < par::FLAT_MAX_ROUNDS && round_nodes(rounds)) { if (round_nodes(rounds) > tail_below) tail_from = rounds + 1; rounds++; }
+            for (uint32_t r = 0; r < rounds; r++) {
+                const uint64_t n_round = round_nodes(r);
+                if (r >= tail_from && rounds - r >= 2) { emu_launch(par::k_flat_count_tail, 1, 1, S, PA, X, r, rounds); break; }
                 if (n_round <= any_below) { emu_launch(par::k_flat_count_round, 1, 1, S, PA, X, r); continue; }
 #define EMU_COUNT(C) emu_launch(par::k_flat_count<C>, 1, 1, S, PA, X, off[C * par::SCHED_R + r], off[C * par::SCHED_R + r + 1] - off[C * par::SCHED_R + r])
                 EMU_COUNT(0); EMU_COUNT(1); EMU_COUNT(2); EMU_COUNT(3); EMU_COUNT(4); EMU_COUNT(5); EMU_COUNT(6); EMU_COUNT(7);
