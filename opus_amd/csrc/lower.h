@@ -1751,6 +1751,9 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
         PA.cap_vars = cap[0]; PA.cap_instrs = cap[1]; PA.cap_bbs = cap[2]; PA.cap_types = cap[3]; PA.cap_cargs = cap[4]; PA.cap_errs = cap[5];
         PA.vars = R->d_vars; PA.instrs = R->d_instrs; PA.bb_offsets = R->d_bb_offsets; PA.cargs = R->d_cargs; PA.types_out = R->d_types;
         PA.dbg = X.ctl + par::CTL_DBG;
+#ifdef OPUSFE_DIAG
+        { static const char* sp = getenv("OPUSFE_PRE_STOP"); PA.stop_phase = sp ? (uint32_t)atoi(sp) : 0u; }
+#endif
         S.types = gtypes;
         // The sequential machine on the functions flagged in `flag` (sparse regions laid out by `idx`), then their places in the
         // dense arrays and the compaction into them; all on stream `ms`.
@@ -1879,7 +1882,12 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
             for (uint32_t r = 0; r < rounds_run; r++) {
                 const uint64_t n_round = round_nodes(r);
                 if (r >= tail_from && rounds_run - r >= 2) { hipLaunchKernelGGL(par::k_flat_count_tail, dim3(1), dim3(512), 0, st, S, PA, X, r, rounds_run); break; }
-                if (n_round <= (1u << 16)) { hipLaunchKernelGGL(par::k_flat_count_round, dim3(grid_for(n_round, 256)), dim3(256), 0, st, S, PA, X, r); continue; }
+#ifdef OPUSFE_DIAG
+                static const uint64_t round_nodes_max = getenv("OPUSFE_FLAT_ROUND_NODES") ? (uint64_t)atoll(getenv("OPUSFE_FLAT_ROUND_NODES")) : (1u << 22);
+#else
+                constexpr uint64_t round_nodes_max = 1u << 22;      // (measured: 38.9 ms at 64 K, 37.8 at 4 M: the classes of a round overlap inside one launch)
+#endif
+                if (n_round <= round_nodes_max) { hipLaunchKernelGGL(par::k_flat_count_round, dim3(std::min<unsigned>(grid_for(n_round, 256), 4096u)), dim3(256), 0, st, S, PA, X, r); continue; }
                 count_class(std::integral_constant<int, 0>(), r); count_class(std::integral_constant<int, 1>(), r); count_class(std::integral_constant<int, 2>(), r);
                 count_class(std::integral_constant<int, 3>(), r); count_class(std::integral_constant<int, 4>(), r); count_class(std::integral_constant<int, 5>(), r);
                 count_class(std::integral_constant<int, 6>(), r); count_class(std::integral_constant<int, 7>(), r);

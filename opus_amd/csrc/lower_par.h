@@ -90,6 +90,7 @@ struct ParArgs {
     uint64_t cap_vars, cap_instrs, cap_bbs, cap_types, cap_cargs, cap_errs;
     opusfe_variable* vars; opusfe_instr* instrs; uint32_t* bb_offsets; uint32_t* cargs; TypeRec* types_out;
     uint32_t* dbg;            // source line of the consistency check that failed (diagnostics of DS_INTERNAL_CAPACITY)
+    uint32_t stop_phase;      // -DOPUSFE_DIAG builds (tools/pre_phases.sh): k_flat_pre leaves after phase n and declines the function; 0 = run everything
 };
 
 // Kind class of a node: neighbouring lanes lower the same kind of node, and every class has a kernel of its own that contains
@@ -170,11 +171,13 @@ inline uint32_t lds_add(lds_u32* p, uint32_t v) { const uint32_t o = *p; *p = o 
 inline uint32_t lds_sub(lds_u32* p, uint32_t v) { const uint32_t o = *p; *p = o - v; return o; }
 inline uint32_t lds_or(lds_u32* p, uint32_t v) { const uint32_t o = *p; *p = o | v; return o; }
 inline uint32_t lds_and(lds_u32* p, uint32_t v) { const uint32_t o = *p; *p = o & v; return o; }
+inline uint32_t lds_max(lds_u32* p, uint32_t v) { const uint32_t o = *p; if (v > o) *p = v; return o; }
 #else
 __device__ __forceinline__ uint32_t lds_add(lds_u32* p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ uint32_t lds_sub(lds_u32* p, uint32_t v) { return __hip_atomic_fetch_add(p, 0u - v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ uint32_t lds_or(lds_u32* p, uint32_t v) { return __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ uint32_t lds_and(lds_u32* p, uint32_t v) { return __hip_atomic_fetch_and(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ uint32_t lds_max(lds_u32* p, uint32_t v) { return __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 #endif
 
 // ---- the function a lane works in (flat passes) ----------------------------------------------------------------------
@@ -1572,7 +1575,7 @@ struct Pre {
     DefEnt* defs; ArgEnt* args; lds_u32* misc; lds_u32* whead;
     uint32_t tid, nthreads;
 };
-enum { MI_FB = 0, MI_NDEFS = 1, MI_WHY = 7, MI_KHIST = 16 /* 2 x KC_ACTIVE words */, MI_KBASE = 32 /* KC_ACTIVE words: the function's place in the class list */, MI_QCNT = 40 /* 3 words: lengths of the schedule's queues */, MI_WORDS = 48 };
+enum { MI_FB = 0, MI_NDEFS = 1, MI_WHY = 7, MI_KHIST = 16 /* 2 x KC_ACTIVE words */, MI_KBASE = 32 /* KC_ACTIVE words: the function's place in the class list */, MI_QCNT = 40 /* length of the schedule's queue */, MI_WORDS = 48 };
 
 __host__ __device__ inline size_t lds_bytes(uint32_t nmax, uint32_t maxdef, uint32_t nthreads) {
     (void)nthreads;
@@ -1622,6 +1625,9 @@ __device__ __forceinline__ void pre_function(Pre& f, const FlatArgs& X) {
     if (par_sync_or(failed(f))) return;      // (uniform exit: every wave sees the same answer)
     for (uint32_t i = tid; i < nn; i += T) { uint32_t guard = 0; for (uint32_t c = f.fc[i]; c != NONE16 && guard <= nn; c = f.nx[c], guard++) f.pa[c] = (uint16_t)i; if (guard > nn) fallback(f); }
     if (par_sync_or(failed(f))) return;
+#ifdef OPUSFE_DIAG
+    if (f.A.stop_phase == 1) { fallback(f); return; }
+#endif
     // Subtree sizes, depths and "dead" marks by one walk up the ancestor chain per node (the nodes arrive in creation order, not
     // pre-order, so none of this is index arithmetic).  Level-synchronous fixpoints did the same in height-of-the-tree rounds of
     // barrier + sweep each (3.7 + 5.8 ms per 256 MB); a walk is depth steps for the one node, with no barrier at all.
@@ -1639,6 +1645,9 @@ __device__ __forceinline__ void pre_function(Pre& f, const FlatArgs& X) {
         if (dead) f.st[i] = ST_DEAD;
     }
     if (par_sync_or(failed(f))) return;
+#ifdef OPUSFE_DIAG
+    if (f.A.stop_phase == 2) { fallback(f); return; }
+#endif
     // every parent hands its children their offset from its own rank (1 + the sizes of the children before them)
     for (uint32_t p = tid; p < nn; p += T) {
         f.sz[p] = (uint16_t)(1u + f.rvi[p]);
@@ -1661,6 +1670,9 @@ __device__ __forceinline__ void pre_function(Pre& f, const FlatArgs& X) {
     for (uint32_t i = tid; i < nn; i += T) { const uint32_t r = f.rvi[i]; f.rvi[i] = 0; f.rk[i] = (uint16_t)r; f.pe[i] = (uint16_t)(2u * r - f.pe[i]); }
     if (tid == 0) f.st[0] |= ST_CTX;
     PAR_SYNC();
+#ifdef OPUSFE_DIAG
+    if (f.A.stop_phase == 3) { fallback(f); return; }
+#endif
     // Evaluation context (mode, pointer kind, expected type) of every node: a function of its parent's kind and of its place among
     // the children, except under `-e`, `(e)` and `e.f`, which pass (part of) their own context on: those wait until their parent has it (one more
     // round per nesting level of such nodes).
@@ -1718,6 +1730,9 @@ __device__ __forceinline__ void pre_function(Pre& f, const FlatArgs& X) {
         if (!par_sync_or(progress)) break;
     }
     if (failed(f)) return;
+#ifdef OPUSFE_DIAG
+    if (f.A.stop_phase == 4) { fallback(f); return; }
+#endif
     // ---- arguments and local definitions ----
     if (tid == 0) {
         uint32_t a = f.fc[0], k = 0;
@@ -1783,6 +1798,9 @@ __device__ __forceinline__ void pre_function(Pre& f, const FlatArgs& X) {
         for (uint32_t a = tid; a < f.nargs; a += T) for (uint32_t b = 0; b < a; b++) { const ArgEnt& x = f.args[a]; const ArgEnt& y = f.args[b]; if (x.hash == y.hash && x.len == y.len && bytes_eq(f.S, x.low, y.low, x.len)) fallback(f); }
     }
     PAR_SYNC();
+#ifdef OPUSFE_DIAG
+    if (f.A.stop_phase == 5) { fallback(f); return; }
+#endif
     // ---- names ----
     // A use of a local whose type is not known yet (`var x = e`, `for x in e`) WAITS for the definition: one more pending operand,
     // and a place in the definition's waiter chain (whead / wnext), which the visit of the definition walks.
@@ -1857,6 +1875,9 @@ __device__ __forceinline__ void pre_function(Pre& f, const FlatArgs& X) {
         if (k == S_For) f.cg[i] = 3;
     }
     if (par_sync_or(failed(f))) return;
+#ifdef OPUSFE_DIAG
+    if (f.A.stop_phase == 6) { fallback(f); return; }
+#endif
     // ---- what every node waits for ----
     for (uint32_t i = tid; i < nn; i += T) {
         const uint32_t s = f.st[i];
@@ -1870,74 +1891,84 @@ __device__ __forceinline__ void pre_function(Pre& f, const FlatArgs& X) {
         if (literal_waits_for_lhs(f, i)) lds_add(&f.st[i], (uint32_t)ST_PEND_ONE);
     }
     PAR_SYNC();
-    // ---- the schedule (see "the schedule of the count pass"): the dependency counters played through, round by round ----
-    // rk[] (free since the names phase) takes the round of every node, s1[] the round of stage 1 of a `for`; rvi[] (free too) holds
-    // two queues of nodes: the ones lowered in this round and the ones that became ready for the next (entry | Q_STAGE1: stage 1 of
-    // a `for`).  A node that is lowered releases what waited for it; a parent that waited for this one operand only and is of the
-    // same class is CHAINED: same round, same lane, not listed.  One barrier per round.
+#ifdef OPUSFE_DIAG
+    if (f.A.stop_phase == 7) { fallback(f); return; }
+#endif
+    // ---- the schedule (see "the schedule of the count pass"): the dependency counters played through ----
+    // round(node) = 1 + the latest round of what it waits for (operands, the awaited definition, the left side; a CHAINED parent —
+    // waits for this one operand only, same class — takes its operand's round: same lane, not listed).  No barrier per round: who
+    // lowers a node hands `its round + 1` to everything that waits for the node (a running maximum, acc[] = pay[], free since the names
+    // phase) and counts itself off; the lane whose count-off is the LAST one knows the maximum is final and goes on with that node at
+    // once — up the tree, across kind classes.  Only where ONE node releases SEVERAL (the uses of a variable) the others go to a queue
+    // (rvi[], free too) that the workgroup drains in phases: a barrier per fan-out generation, not per round.
     {
-        lds_u16* const q[2] = {(lds_u16*)f.rvi, (lds_u16*)f.rvi + f.A.nmax};
-        enum : uint32_t { Q_STAGE1 = 0x8000u };
-        for (uint32_t i = tid; i < nn; i += T) { f.rk[i] = NONE16; f.s1[i] = NONE16; }
-        if (tid == 0) { f.misc[MI_QCNT] = 0; f.misc[MI_QCNT + 1] = 0; f.misc[MI_QCNT + 2] = 0; }
+        lds_u32* const acc = f.pay;
+        lds_u16* const q = (lds_u16*)f.rvi;
+        const uint32_t qcap = 2u * f.A.nmax;
+        for (uint32_t i = tid; i < nn; i += T) { f.rk[i] = NONE16; f.s1[i] = NONE16; acc[i] = 0; }
+        if (tid == 0) f.misc[MI_QCNT] = 0;
         PAR_SYNC();
+        auto push = [&](uint32_t entry) { const uint32_t at = lds_add(&f.misc[MI_QCNT], 1u); if (at < qcap) q[at] = (uint16_t)entry; else fallback(f); };
+        // `node` need not wait for something lowered in round r - 1 any longer; true: that was the last thing it waited for
+        auto arrive = [&](uint32_t node, uint32_t r) -> bool { lds_max(&acc[node], r); return (lds_sub(&f.st[node], (uint32_t)ST_PEND_ONE) & ST_PEND_MASK) == ST_PEND_ONE; };
+        auto release_waiters = [&](uint32_t def_index, uint32_t r) {
+            for (uint32_t w = f.whead[def_index], guard = 0; w != NONE16 && guard <= nn; guard++) { const uint32_t after = f.wnext[w]; if (arrive(w, r)) push(w); w = after; }
+        };
         for (uint32_t i = tid; i < nn; i += T) {
             const uint32_t s = f.st[i];
-            if (!(s & (ST_DONE | ST_DEAD | ST_PEND_MASK))) q[0][lds_add(&f.misc[MI_QCNT], 1u)] = (uint16_t)i;
+            if (!(s & (ST_DONE | ST_DEAD | ST_PEND_MASK))) push(i);
         }
-        PAR_SYNC();
-        for (uint32_t r = 0; r <= FLAT_MAX_ROUNDS; r++) {
-            const uint32_t n = f.misc[MI_QCNT + r % 3];
-            if (n == 0) break;
-            if (r == FLAT_MAX_ROUNDS || n > nn) { fallback(f); break; }      // a dependency chain longer than the schedule's table: the sequential machine
-            lds_u16* const cur = q[r & 1]; lds_u16* const nxt = q[(r + 1) & 1];
-            lds_u32* const nxt_cnt = &f.misc[MI_QCNT + (r + 1) % 3];
-            if (tid == 0) f.misc[MI_QCNT + (r + 2) % 3] = 0;                   // (read last in the round before this one)
-            auto ready = [&](uint32_t entry) { const uint32_t at = lds_add(nxt_cnt, 1u); if (at < f.A.nmax) nxt[at] = (uint16_t)entry; };
-            auto release = [&](uint32_t node) -> uint32_t { return lds_sub(&f.st[node], (uint32_t)ST_PEND_ONE); };
-            auto release_waiters = [&](uint32_t def_index) {
-                for (uint32_t w = f.whead[def_index], guard = 0; w != NONE16 && guard <= nn; guard++) { const uint32_t after = f.wnext[w]; if ((release(w) & ST_PEND_MASK) == ST_PEND_ONE) ready(w); w = after; }
-            };
-            for (uint32_t j = tid; j < n; j += T) {
-                const uint32_t entry = cur[j];
-                uint32_t i = entry & ~(uint32_t)Q_STAGE1;
-                if (entry & Q_STAGE1) {
-                    // stage 1: the loop variable has its type; the iteree's share of the operand count is given up
-                    f.s1[i] = (uint16_t)r;
-                    release_waiters(f.ref[i]);
-                    if ((release(i) & ST_PEND_MASK) == ST_PEND_ONE) ready(i);
-                    continue;
-                }
-                const uint32_t my_class = kind_class_of(f.st[i], KIND(f, i));
+        uint32_t done = 0;
+        for (uint32_t phase = 0; phase <= nn + 1; phase++) {
+            PAR_SYNC();
+            const uint32_t n = f.misc[MI_QCNT] < qcap ? f.misc[MI_QCNT] : qcap;
+            if (n == done) break;
+            PAR_SYNC();                                          // (every lane has read the length before the next pushes move it)
+            for (uint32_t j = done + tid; j < n; j += T) {
+                uint32_t i = q[j];
+                uint32_t r = acc[i];
+                uint32_t my_class = kind_class_of(f.st[i], KIND(f, i));
                 for (uint32_t guard = 0; guard <= nn; guard++) {
+                    if (r >= FLAT_MAX_ROUNDS) { fallback(f); break; }      // a dependency chain longer than the schedule's table: the sequential machine
                     f.rk[i] = (uint16_t)r;
                     lds_or(&f.st[i], (uint32_t)ST_DONE);
-                    if (KIND(f, i) == S_VariableDefinition) release_waiters(f.ref[i]);
+                    if (KIND(f, i) == S_VariableDefinition) release_waiters(f.ref[i], r + 1);
                     const uint32_t p = f.pa[i];
                     if (p == NONE16) break;
                     const uint8_t pk = KIND(f, p);
-                    if (pk == S_Assignment && f.fc[p] == i) {                // the left side: an integer literal on the right takes its type from it
+                    if (pk == S_Assignment && f.fc[p] == i) {            // the left side: an integer literal on the right takes its type from it
                         uint32_t c = f.nx[i];
                         while (c != NONE16 && (KIND(f, c) == E_Parentheses || KIND(f, c) == E_Negate)) c = f.fc[c];
-                        if (c != NONE16 && literal_waits_for_lhs(f, c) && (release(c) & ST_PEND_MASK) == ST_PEND_ONE) ready(c);
+                        if (c != NONE16 && literal_waits_for_lhs(f, c) && arrive(c, r + 1)) push(c);
                     }
-                    if (pk == S_For) {
-                        uint32_t cond, tb, eb; blocks_of(f, p, &cond, &tb, &eb);
-                        if (cond == i) { ready(p | Q_STAGE1); break; }            // stage 1 of the loop: next round
-                    }
-                    const uint32_t old = release(p);
-                    if ((old & ST_PEND_MASK) != ST_PEND_ONE) break;              // the parent waits for others
-                    if (!single_operand(pk) || kind_class_of(old, pk) != my_class) { ready(p); break; }
-                    lds_or(&f.st[p], (uint32_t)ST_CHAINED);
+                    bool iteree = false;
+                    if (pk == S_For) { uint32_t cond, tb, eb; blocks_of(f, p, &cond, &tb, &eb); iteree = cond == i; }
+                    bool last;
+                    if (iteree) {
+                        // stage 1 of the loop is the round behind its iteree — the loop variable gets its type, the body may go on; the
+                        // loop itself is lowered behind stage 1 and everything below it
+                        const uint32_t r1 = r + 1;
+                        if (r1 >= FLAT_MAX_ROUNDS) { fallback(f); break; }
+                        f.s1[p] = (uint16_t)r1;
+                        release_waiters(f.ref[p], r1 + 1);
+                        last = arrive(p, r1 + 1);
+                    } else last = arrive(p, r + 1);
+                    if (!last) break;                                    // the parent waits for others: the lane that counts off last goes on with it
+                    const uint32_t pc = kind_class_of(f.st[p], pk);
+                    if (pk != S_For && single_operand(pk) && pc == my_class) lds_or(&f.st[p], (uint32_t)ST_CHAINED);      // same round, same lane
+                    else { r = acc[p]; my_class = pc; }
                     i = p;
                 }
             }
-            PAR_SYNC();
+            done = n;
         }
         PAR_SYNC();
-        for (uint32_t i = tid; i < nn; i += T) f.rvi[i] = 0;                     // (the queues' words)
+        for (uint32_t i = tid; i < nn; i += T) f.rvi[i] = 0;             // (the queue's words)
     }
     if (par_sync_or(failed(f))) return;
+#ifdef OPUSFE_DIAG
+    if (f.A.stop_phase == 8) { fallback(f); return; }
+#endif
     // every node that is lowered must have its round
     for (uint32_t i = tid; i < nn; i += T) {
         const uint32_t c = kind_class_of(f.st[i], KIND(f, i));

@@ -15,7 +15,7 @@ for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
         k = r["Kernel_Name"].split("(")[0][-40:]
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
 with open(out + "/summary.txt", "w") as o:
-    for k, d in sorted(agg.items(), key=lambda kv: -sum(kv[1].values()))[:8]:
+    for k, d in sorted(agg.items(), key=lambda kv: -sum(kv[1].values()))[:40]:
         o.write(k + "\n")
         for c, v in sorted(d.items()): o.write(f"    {c:28s} {v:.4g}\n")
 print(open(out + "/summary.txt").read())
