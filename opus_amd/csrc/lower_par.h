@@ -1462,34 +1462,40 @@ __global__ __launch_bounds__(256) void k_flat_scan(SemView S, ParArgs A, FlatArg
     const uint32_t nn = I.nn, ne = 2u * nn;
     uint64_t* cnt = X.cnt + 2ull * dn;
     uint16_t* cg = X.cg + dn;
-    // every lane owns a run of consecutive events (its loads do not wait for each other); the lanes' sums are scanned across the wave
-    const uint32_t per = (ne + W - 1) / W, lo = lane * per < ne ? lane * per : ne, hi = lo + per < ne ? lo + per : ne;
-    const uint32_t perc = (nn + W - 1) / W, loc = lane * perc < nn ? lane * perc : nn, hic = loc + perc < nn ? loc + perc : nn;
-    Cnt2x mine{0, 0}; uint32_t mine_cg = 0;
+    // 64 consecutive events per step, one per lane (whole lines in, whole lines out), scanned across the wave; the carry goes on
+    Cnt2x carry{0, 0}; uint32_t carry_cg = 0;
     if (why == 0) {
-        for (uint32_t p = lo; p < hi; p++) { const Cnt4 c = unpack4(cnt[p]); mine.vt += (uint64_t)c.v | ((uint64_t)c.t << 32); mine.ib += (uint64_t)c.i | ((uint64_t)c.b << 32); }
-        for (uint32_t p = loc; p < hic; p++) mine_cg += cg[p];
-    }
+        for (uint32_t base = 0; base < ne; base += W) {
+            const uint32_t p = base + lane;
+            const Cnt4 c = p < ne ? unpack4(cnt[p]) : Cnt4{0, 0, 0, 0};
+            const Cnt2x mine{(uint64_t)c.v | ((uint64_t)c.t << 32), (uint64_t)c.i | ((uint64_t)c.b << 32)};
 #ifdef OPUSFE_EMU
-    Cnt2x run{0, 0}; uint32_t run_cg = 0; const Cnt2x total = mine; const uint32_t total_cg = mine_cg;
+            const Cnt2x excl = carry; carry = OpAddCnt2x()(carry, mine);
 #else
-    const Cnt2x incl = wave_inclusive_scan(mine, OpAddCnt2x());
-    const uint32_t incl_cg = wave_inclusive_scan(mine_cg, OpAddU32());
-    Cnt2x run{incl.vt - mine.vt, incl.ib - mine.ib}; uint32_t run_cg = incl_cg - mine_cg;
-    const Cnt2x total{(uint64_t)__shfl((long long)incl.vt, 63), (uint64_t)__shfl((long long)incl.ib, 63)};
-    const uint32_t total_cg = (uint32_t)__shfl((int)incl_cg, 63);
+            const Cnt2x incl = wave_inclusive_scan(mine, OpAddCnt2x());
+            const Cnt2x excl{carry.vt + incl.vt - mine.vt, carry.ib + incl.ib - mine.ib};
+            carry.vt += (uint64_t)__shfl((long long)incl.vt, 63); carry.ib += (uint64_t)__shfl((long long)incl.ib, 63);
 #endif
+            // (a prefix beyond 16 bits is cut here and caught by the totals below: the function is declined, nothing reads these words)
+            if (p < ne) cnt[p] = pack4(Cnt4{(uint32_t)excl.vt & 0xFFFFu, (uint32_t)(excl.vt >> 32) & 0xFFFFu, (uint32_t)excl.ib & 0xFFFFu, (uint32_t)(excl.ib >> 32) & 0xFFFFu});
+        }
+        for (uint32_t base = 0; base < nn; base += W) {
+            const uint32_t p = base + lane;
+            const uint32_t mine = p < nn ? (uint32_t)cg[p] : 0u;
+#ifdef OPUSFE_EMU
+            const uint32_t excl = carry_cg; carry_cg += mine;
+#else
+            const uint32_t incl = wave_inclusive_scan(mine, OpAddU32());
+            const uint32_t excl = carry_cg + incl - mine;
+            carry_cg += (uint32_t)__shfl((int)incl, 63);
+#endif
+            if (p < nn) cg[p] = (uint16_t)excl;
+        }
+    }
+    const Cnt2x total = carry; const uint32_t total_cg = carry_cg;
     const uint32_t tv = (uint32_t)total.vt, tt = (uint32_t)(total.vt >> 32), ti = (uint32_t)total.ib, tb = (uint32_t)(total.ib >> 32);
     // the packed 16-bit fields of an event must hold every prefix
     if (why == 0 && (tv > 0xFFF0u || tt > 0xFFF0u || ti > 0xFFF0u || tb > 0xFFF0u || total_cg > 0xFFF0u)) why = __LINE__;
-    if (why == 0) {
-        for (uint32_t p = lo; p < hi; p++) {
-            const Cnt4 c = unpack4(cnt[p]);
-            cnt[p] = pack4(Cnt4{(uint32_t)run.vt & 0xFFFFu, (uint32_t)(run.vt >> 32) & 0xFFFFu, (uint32_t)run.ib & 0xFFFFu, (uint32_t)(run.ib >> 32) & 0xFFFFu});
-            run.vt += (uint64_t)c.v | ((uint64_t)c.t << 32); run.ib += (uint64_t)c.i | ((uint64_t)c.b << 32);
-        }
-        for (uint32_t p = loc; p < hic; p++) { const uint32_t v = cg[p]; cg[p] = (uint16_t)run_cg; run_cg += v; }
-    }
     if (lane != 0) return;
     FuncIr r{};
     r.def_node = dn; r.func = fidx;
