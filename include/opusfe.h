@@ -244,12 +244,15 @@ int opusfe_copy_tokens(opusfe_unit* unit, opusfe_token* dst, uint64_t cap, uint6
    (generate_ir.rs:58-98 `variables`, `bbs`, `function`; llvm.rs:355-420 walks exactly these) ----
    Ids: variables and basic blocks are numbered per function from 0 (dst/a/b and Jump/Branch/Phi targets are those local
    numbers; add var_base / bb_base of the function for the global arrays); type ids index OPUSFE_A_TYPES directly.
-   LAYOUT: OPUSFE_A_VARIABLES / _BB_OFFSETS / _INSTRS / _CALL_ARGS and the function-local part of OPUSFE_A_TYPES are DENSE BUT
-   UNORDERED: every function takes its place with an atomic add when its sizes are known, so the order of the functions inside
-   these arrays (hence every *_base, and the ids of function-local types) is the order in which they finished.  It differs from
-   run to run and between the first attempt and the exact-size retry.  Only what is reached through a function's bases is
-   stable: the function's own records, its local numbering, and OPUSFE_A_FUNCTIONS itself (definition order).  Do not hash,
-   cache or diff the raw arrays; compare per function (opus_amd/ir_view.py does). */
+   LAYOUT: OPUSFE_A_VARIABLES / _BB_OFFSETS / _INSTRS / _CALL_ARGS and the function-local part of OPUSFE_A_TYPES are DENSE.  The
+   functions that the flat lowering takes (lower_par.h; all of a well-typed generated source but the ones of 2048 nodes and
+   more) lie in DEFINITION ORDER in one range of every array — their places are an exclusive scan of their sizes — and that
+   part is the same from run to run.  The functions of the sequential machine (oversized ones, and whatever the flat path
+   declines: any function with a diagnostic) take their places with an atomic add each, before or behind that range, in the
+   order in which they finish: their *_base fields (and the ids of their local types) can differ from run to run.  What is
+   reached through a function's bases is always stable: the function's own records, its local numbering, and
+   OPUSFE_A_FUNCTIONS itself (definition order).  Compare per function (opus_amd/ir_view.py does) unless
+   opusfe_lowering_stats says that no function took the sequential machine. */
 typedef struct opusfe_function_ir {      /* one per Definition::Function / extern, in definition order; n_bbs == 0: extern */
     uint32_t def_node;                   /* root node of the definition */
     uint32_t func;                       /* index into OPUSFE_A_SIGNATURES */

@@ -12,8 +12,8 @@ def ensure():
     return CLI
 
 
-def dump_many(sources, what):
-    """[(status, text)] for every source (bytes)."""
+def dump_many(sources, what, env=None):
+    """[(status, text)] for every source (bytes); env: extra environment of the emulator (its EMU_* switches)."""
     ensure()
     out = []
     with tempfile.TemporaryDirectory() as d:
@@ -24,7 +24,7 @@ def dump_many(sources, what):
                 f.write(s)
             paths.append(p)
         for lo in range(0, len(paths), 200):
-            r = subprocess.run([CLI, str(what)] + paths[lo:lo + 200], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            r = subprocess.run([CLI, str(what)] + paths[lo:lo + 200], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env) if env else None)
             if r.returncode != 0:
                 raise RuntimeError(f"emu_cli failed (sanitizer?) rc={r.returncode}\n{r.stderr.decode(errors='replace')[-4000:]}")
             data = r.stdout

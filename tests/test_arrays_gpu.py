@@ -154,6 +154,28 @@ def test_lowering_stats_and_memory_held(fe):
     assert v.dump_ir() == O.dump(big, O.IR)
 
 
+def test_flat_lowering_lays_functions_out_in_definition_order_and_reproducibly(fe):
+    """opusfe.h LAYOUT: the functions of the flat lowering tile one range of every dense array in definition order (a scan of their
+    sizes, no atomics), so two lowerings of one unit give byte-identical arrays when nothing takes the sequential machine"""
+    src = O.generate(41, 600_000)
+    u = fe.get_definitions(src)
+    assert u.compile_source() == 0
+    par, seq = u.lowering_stats()
+    assert seq == 0 and par > 100
+    which = (V.A_FUNCTIONS, V.A_VARIABLES, V.A_BB_OFFSETS, V.A_INSTRS, V.A_CALL_ARGS, V.A_TYPES)
+    first = [u.array(w).tobytes() for w in which]
+    f = u.array(V.A_FUNCTIONS)
+    body = f[f["n_bbs"] > 0]
+    for base, n in (("var_base", "n_vars"), ("instr_base", "n_instrs"), ("bb_base", "n_bbs"), ("type_base", "n_types"), ("call_arg_base", "n_call_args")):
+        b, k = body[base].astype(np.int64), body[n].astype(np.int64)
+        assert b[0] == 0 and (b[1:] == (b + k)[:-1]).all(), base      # definition order: every function starts where the one before it ends
+    assert u.compile_source() == 0
+    assert [u.array(w).tobytes() for w in which] == first
+    w = fe.get_definitions(src)
+    assert w.compile_source() == 0
+    assert [w.array(x).tobytes() for x in which] == first
+
+
 def test_parent_array(fe):
     """OPUSFE_A_PARENTS: the upward link of every node, built on request; the inverse of the first_child / next chains"""
     src = O.generate(34, 300_000)

@@ -84,6 +84,17 @@ def test_emu_ir_generated_and_deep():
     compare_ir([O.generate(1, 4096), O.generate(2, 70000), O.generate(3, 2 << 20, flags=1)])
 
 
+def test_emu_flat_lowering_launch_plans():
+    """the flat lowering (lower_par.h) under the launch plans run_lower chooses between — one kernel per kind class and round, one kernel
+    for a whole round, one workgroup for the tail of the schedule — and with every function REQUIRED on the flat path: same IR text"""
+    cases = [O.generate(5, 30000), O.generate(6, 300000)]
+    want = [O.dump(c, O.IR) for c in cases]
+    for env in ({"EMU_REQUIRE_PAR": "1"}, {"EMU_REQUIRE_PAR": "1", "EMU_FLAT_TAIL": "100000000"}, {"EMU_REQUIRE_PAR": "1", "EMU_FLAT_TAILKERNEL": "100000000"},
+                {"EMU_FLAT_TAIL": "0", "EMU_FLAT_TAILKERNEL": "0"}):
+        got = E.dump_many(cases, 2, env=env)
+        assert [g for g in got] == [(0, w) for w in want], env
+
+
 def test_emu_ir_big_function_spill_paths():
     """every LDS-resident table of the two machines overflows into its sparse global region (AddressSanitizer watches)"""
     compare_ir([big_function().encode(), big_function(70, 40, 300, 20).encode()])
