@@ -55,7 +55,8 @@ try:
     sha = hashlib.sha1(open(opus_amd.library_path(), "rb").read()).hexdigest()
 except Exception:
     sha = None
-traffic = {"tag": tag, "source_bytes": int(float(m.group(1))) if m else None, "unit": "bytes per launch", "library_sha1": sha, "kernels": {}}
+traffic = {"tag": tag, "source_bytes": int(float(m.group(1))) if m else 1000000000,      # (bench.py's default)
+           "unit": "bytes per launch", "library_sha1": sha, "kernels": {}}
 for r in stats:
     k = short(r["Name"])
     if fetch[k][0] and write[k][0]:
