@@ -1556,19 +1556,26 @@ __global__ __launch_bounds__(256) void k_flat_rv(ParArgs A, FlatArgs X) {
 }
 
 // ---- emit -----------------------------------------------------------------------------------------------------------------
-template <int C> __global__ FLAT_ATTR __launch_bounds__(256) void k_flat_emit(SemView S, ParArgs A, FlatArgs X) {
+template <int C> __device__ __forceinline__ void emit_one(const SemView& S, const ParArgs& A, const FlatArgs& X, uint32_t entry) {
+    Fn f; uint32_t i;
+    if (!make_fn(f, S, A, X, entry, &i, true)) return;
+    const FuncIr r = gld(A.out + f.fidx);
+    f.var_base = r.var_base; f.instr_base = r.instr_base; f.bb_base = r.bb_base; f.type_base = r.type_base; f.carg_base = r.carg_base;
+    f.n_vars_tot = r.n_vars; f.n_instrs_tot = r.n_instrs; f.n_bbs_tot = r.n_bbs; f.n_types_tot = r.n_types; f.n_cargs_tot = r.n_cargs;
+    visit<true, C>(f, i);
+}
+// entries [lo, lo + step), [lo + stride, ...) ... of class C's part of `order`
+template <int C> __device__ __forceinline__ void emit_class(const SemView& S, const ParArgs& A, const FlatArgs& X, uint64_t first, uint64_t stride) {
     const uint32_t begin = X.ctl[CTL_BINS + (uint32_t)C * SCHED_R], n = X.ctl[CTL_OCUR + (uint32_t)C] - begin;      // every node of the class, the chained ones too
     const uint32_t* in = X.order + begin;
-    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t entry = in[k];
-        Fn f; uint32_t i;
-        if (!make_fn(f, S, A, X, entry, &i, true)) continue;
-        const FuncIr r = gld(A.out + f.fidx);
-        f.var_base = r.var_base; f.instr_base = r.instr_base; f.bb_base = r.bb_base; f.type_base = r.type_base; f.carg_base = r.carg_base;
-        f.n_vars_tot = r.n_vars; f.n_instrs_tot = r.n_instrs; f.n_bbs_tot = r.n_bbs; f.n_types_tot = r.n_types; f.n_cargs_tot = r.n_cargs;
-        visit<true, C>(f, i);
-    }
+    for (uint64_t k = first; k < n; k += stride) emit_one<C>(S, A, X, in[k]);
 }
+template <int C> __global__ FLAT_ATTR __launch_bounds__(256) void k_flat_emit(SemView S, ParArgs A, FlatArgs X) {
+    emit_class<C>(S, A, X, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, (uint64_t)gridDim.x * blockDim.x);
+}
+// (All classes in ONE launch, the blocks dealt to the classes in proportion to their node counts so that they walk the node-ordered lists at
+// the same relative pace and share what they fetch, was measured: 35.3 ms against 26.0 for the eight launches — the kernel then has the
+// registers and the code of its largest class.)
 
 // ======================================================================================================================
 // k_flat_pre: what is local to a function by nature (one workgroup per function, one lane per node, state in LDS)
