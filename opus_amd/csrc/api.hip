@@ -118,7 +118,7 @@ void run_lexer(opusfe_ctx* ctx, opusfe_unit* u, int force_dents) {
     uint32_t* out_off = tmp.get<uint32_t>(G);
     uint32_t* seg_flag = tmp.get<uint32_t>(G);
     uint32_t* seg_excl = prev;      // (prev is dead behind k_final, which writes seg_flag; the segment scan then writes seg_excl)
-    uint32_t* scan_tmp32 = tmp.get<uint32_t>((G + SCAN_TILE - 1) / SCAN_TILE + 1);
+    uint64_t* scan_scr = tmp.get<uint64_t>(chained_scan_words(G));      // (the single-pass scans' tile words, scan.h)
     FileTok ft{};
     if (grp && T > 0) {
         // which file every token belongs to, the first token of every file, and (behind the depth scan) the depth in front of every file
@@ -132,18 +132,18 @@ void run_lexer(opusfe_ctx* ctx, opusfe_unit* u, int force_dents) {
     if (T > 0) {
         LAUNCH(ctx, "tok_delta", k_tok_delta, grid_for(T, 256), 256, raw, T, depth, force_dents, (uint64_t)TK_NO_PREV, ft);
         prof_begin(ctx, "scan_depth");
-        device_scan<false>(depth, depth, T, OpAddI32(), (int32_t)0, (int32_t*)scan_tmp32, (int32_t*)nullptr, st);
+        device_scan_chained<false>(depth, depth, T, OpAddI32(), (int32_t)0, scan_scr, (int32_t*)nullptr, status, st);
         prof_end(ctx);
         HIP_TRY(hipMemcpyAsync(ctx->d_status + W_ENDDEPTH, depth + (T - 1), 4, hipMemcpyDeviceToDevice, st));      // (opusfe_unit_end_state)
         if (ft.n) LAUNCH(ctx, "file_base", k_file_base, grid_for(ft.n, 256), 256, (const int32_t*)depth, ft.first_tok, ft.n, (int32_t*)ft.base);
     }
     LAUNCH(ctx, "tok_gap", k_gap, grid_for(G, 256), 256, src, n, raw, T, depth, gapval, (int32_t)0, ft);
     prof_begin(ctx, "scan_indent");
-    device_scan<true>(gapval, prev, G, OpLast(), (uint32_t)0, scan_tmp32, (uint32_t*)nullptr, st);
+    device_scan_chained<true>(gapval, prev, G, OpLast(), (uint32_t)0, scan_scr, (uint32_t*)nullptr, status, st);
     prof_end(ctx);
     LAUNCH(ctx, "tok_dent_count", k_dent_count, grid_for(G, 256), 256, gapval, prev, T, cnt, ft, (const int32_t*)depth);
     prof_begin(ctx, "scan_tokoff");
-    device_scan<true>(cnt, out_off, G, OpAddU32(), (uint32_t)0, scan_tmp32, ctx->d_status + W_FINTOK, st);
+    device_scan_chained<true>(cnt, out_off, G, OpAddU32(), (uint32_t)0, scan_scr, ctx->d_status + W_FINTOK, status, st);
     prof_end(ctx);
     fetch_status(ctx);
     const uint32_t total = ctx->h_status[W_FINTOK];
@@ -154,7 +154,7 @@ void run_lexer(opusfe_ctx* ctx, opusfe_unit* u, int force_dents) {
         LAUNCH(ctx, "file_lex_flags", k_file_lex_flags, grid_for(grp->n_files, 256), 256, ft.first_tok, (const uint32_t*)gapval, grp->n_files, (const uint32_t*)grp->d_fstatus, grp->d_flags);
     if (T > 0) {
         prof_begin(ctx, "scan_seg");
-        device_scan<true>(seg_flag, seg_excl, T, OpAddU32(), (uint32_t)0, scan_tmp32, ctx->d_status + W_NSEG, st);
+        device_scan_chained<true>(seg_flag, seg_excl, T, OpAddU32(), (uint32_t)0, scan_scr, ctx->d_status + W_NSEG, status, st);
         prof_end(ctx);
     }
     fetch_status(ctx);

@@ -1588,11 +1588,12 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
     uint32_t* slot_of_node = tmp.get<uint32_t>(n_nodes);
     LAUNCH(ctx, "sem_type_flags", k_sem_type_flags, grid_for(n_nodes, 256), 256, u->d_nodes, n_nodes, slot_of_node);
     prof_begin(ctx, "sem_scan_types");
-    device_scan<true>(slot_of_node, slot_of_node, n_nodes, OpAddU32(), (uint32_t)0, scan_tmp, ctx->d_status + WL_GT, st);
+    device_scan_chained<true>(slot_of_node, slot_of_node, n_nodes, OpAddU32(), (uint32_t)0, (uint64_t*)scan_tmp, ctx->d_status + WL_GT, ctx->d_status + WL_STATUS, st);      // (scan_tmp: 32 B per 2048 elements, the single-pass scan needs 8 per 4096)
     prof_end(ctx);
     HIP_TRY(hipMemcpyAsync(ctx->h_status, ctx->d_status, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     prof_collect(ctx);
+    if (ctx->h_status[WL_STATUS] >= DS_INTERNAL_CAPACITY) { u->status = OPUSFE_ERR_INTERNAL; ctx->msg = "type-slot scan: a tile never saw its predecessors (scan.h)"; return; }
     const uint32_t n_funcs = ctx->h_status[WL_DEFTOT], n_globals = ctx->h_status[WL_DEFTOT + 1], n_named = ctx->h_status[WL_DEFTOT + 3];
     // global type ids: primitives, one per structured parse-tree type / `type` definition, then the pointer-to-primitive table
     const uint32_t n_gt0 = TP_COUNT + ctx->h_status[WL_GT];
