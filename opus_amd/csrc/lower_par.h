@@ -1575,7 +1575,8 @@ template <int C> __global__ FLAT_ATTR __launch_bounds__(256) void k_flat_emit(Se
 }
 // (All classes in ONE launch, the blocks dealt to the classes in proportion to their node counts so that they walk the node-ordered lists at
 // the same relative pace and share what they fetch, was measured: 35.3 ms against 26.0 for the eight launches — the kernel then has the
-// registers and the code of its largest class.)
+// registers and the code of its largest class.  One launch over ALL nodes in node order, one lane per node with the whole visitor —
+// neighbouring lanes on neighbouring records, no list — was measured too: 63 ms.  The pass is bound by divergence, not by what it fetches.)
 
 // ======================================================================================================================
 // k_flat_pre: what is local to a function by nature (one workgroup per function, one lane per node, state in LDS)
@@ -1588,7 +1589,8 @@ struct Pre {
     DefEnt* defs; ArgEnt* args; lds_u32* misc; lds_u32* whead;
     uint32_t tid, nthreads;
 };
-enum { MI_FB = 0, MI_NDEFS = 1, MI_WHY = 7, MI_KHIST = 16 /* 2 x KC_ACTIVE words */, MI_KBASE = 32 /* KC_ACTIVE words: the function's place in the class list */, MI_QCNT = 40 /* length of the schedule's queue */, MI_WORDS = 48 };
+enum { MI_FB = 0, MI_NDEFS = 1, MI_WHY = 7, MI_KHIST = 16 /* 2 x KC_ACTIVE words */, MI_KBASE = 32 /* KC_ACTIVE words: the function's place in the class list */, MI_QCNT = 40 /* length of the schedule's queue */,
+       MI_BUCKET = 48 /* 64 words: heads of the definitions' hash chains (index + 1, 0 = empty; DefEnt.pad links on) */, MI_WORDS = 112 };
 
 __host__ __device__ inline size_t lds_bytes(uint32_t nmax, uint32_t maxdef, uint32_t nthreads) {
     (void)nthreads;
@@ -1602,12 +1604,16 @@ __host__ __device__ inline size_t lds_bytes(uint32_t nmax, uint32_t maxdef, uint
 __device__ __forceinline__ void fallback_at(Pre& f, uint32_t line) { if (!f.misc[MI_FB]) f.misc[MI_WHY] = line; f.misc[MI_FB] = 1; }
 __device__ __forceinline__ bool failed(const Pre& f) { return f.misc[MI_FB] != 0; }
 __device__ __forceinline__ opusfe_node ND(const Pre& f, uint32_t i) { return f.S.nodes[f.dn + i]; }
+__device__ __forceinline__ uint32_t def_bucket(uint32_t hash) { return (hash * 0x9E3779B1u) >> 26; }
 // definition of identifier token `t` visible at node `use`: RF_LOCAL | index, RF_ARG | index, or RF_NONE
 __device__ __forceinline__ uint32_t find_local(const Pre& f, const opusfe_token& t, uint32_t use_node) {
+    // (the definitions hang in 64 hash chains: a name looks at the few that share its bucket, not at every definition of the function;
+    // at most one definition of a name is in scope at a use — shadowing is declined — so the order inside a chain does not matter)
     const uint32_t nd = f.misc[MI_NDEFS], use = RANK(f, use_node);
-    for (uint32_t k = 0; k < nd; k++) {
-        const DefEnt& d = f.defs[k];
-        if (d.hash == t.payload && d.len == t.len && d.dpoint <= use && use < d.send && bytes_eq(f.S, d.low, t.low, t.len)) return RF_LOCAL | k;
+    for (uint32_t k1 = f.misc[MI_BUCKET + def_bucket(t.payload)], guard = 0; k1 != 0 && guard <= nd; guard++) {
+        const DefEnt& d = f.defs[k1 - 1];
+        if (d.hash == t.payload && d.len == t.len && d.dpoint <= use && use < d.send && bytes_eq(f.S, d.low, t.low, t.len)) return RF_LOCAL | (k1 - 1);
+        k1 = d.pad;
     }
     for (uint32_t k = 0; k < f.nargs; k++) {
         const ArgEnt& a = f.args[k];
@@ -1621,7 +1627,7 @@ __device__ __forceinline__ uint32_t def_slot(const Pre& f, uint32_t i) { return 
 
 __device__ __forceinline__ void pre_function(Pre& f, const FlatArgs& X) {
     const uint32_t nn = f.nn, tid = f.tid, T = f.nthreads, dn = f.dn;
-    if (tid == 0) { for (uint32_t k = 0; k < MI_WORDS; k++) f.misc[k] = 0; }
+    for (uint32_t k = tid; k < MI_WORDS; k += T) f.misc[k] = 0;
     PAR_SYNC();
     // ---- structure ----
     for (uint32_t i = tid; i < nn; i += T) {
@@ -1780,6 +1786,14 @@ __device__ __forceinline__ void pre_function(Pre& f, const FlatArgs& X) {
                 d.dpoint = k == S_VariableDefinition ? RANK_END(f, i) : RANK(f, i) + 1;
                 d.send = RANK_END(f, blk);
                 if (k == E_VariableDefinition) { if (f.fc[i] == NONE16) { fallback(f); continue; } d.vt = d_ptr(f, PT_Mutable, d_id(TID(f, f.fc[i]))); }
+            }
+            {   // into its hash chain
+                lds_u32* const head = &f.misc[MI_BUCKET + def_bucket(d.hash)];
+#ifdef OPUSFE_EMU
+                d.pad = *head; *head = slot + 1;
+#else
+                d.pad = __hip_atomic_exchange(head, slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
             }
             f.defs[slot] = d;
             f.whead[slot] = NONE16;
