@@ -705,6 +705,13 @@ __device__ __forceinline__ Desc for_variable_type(Fn& f, uint32_t i) {
     return d_id(fn_arg_type(f, cf, 1));
 }
 
+// Node i diverges (every path through it returns).  A block diverges if one of its statements does: the statement leaves a mark in the
+// block's ref word, which a block has no other use for (every writer stores the same value, so plain stores do).
+__device__ __forceinline__ void set_div(Fn& f, uint32_t i) {
+    f.st[i] |= ST_DIV;
+    const uint32_t p = f.pa[i];
+    if (p != NONE16 && KIND(f, p) == X_Block) f.ref[p] = 1u;
+}
 // Lowers node i: all events it owns.  Returns false when an input is not ready yet (count pass only).
 template <int C> __device__ __forceinline__ constexpr bool has_class(int c) { return C == KC_ANY || C == c; }
 template <bool EMIT, int C> __device__ __forceinline__ bool visit(Fn& f, uint32_t i) {
@@ -739,9 +746,9 @@ template <bool EMIT, int C> __device__ __forceinline__ bool visit(Fn& f, uint32_
                 return true;
             }
             case X_Block: { if (!has_class<C>(KC_CONTROL)) return true;
-                uint32_t div = 0;
-                for (uint32_t c = f.fc[i]; c != NONE16; c = f.nx[c]) div |= f.st[c] & ST_DIV;
-                if (!EMIT) f.st[i] |= div;
+                // diverges if one of its statements does: the statement said so in this node's ref word (set_div) — walking the
+                // statements here is a chain of dependent loads as long as the block, and was what every late round waited for
+                if (!EMIT && f.ref[i]) set_div(f, i);
                 return true;
             }
             case S_Expression: return true;
@@ -775,7 +782,7 @@ template <bool EMIT, int C> __device__ __forceinline__ bool visit(Fn& f, uint32_
                 Val<EMIT> fin = autocast<EMIT>(f, e, child_val<EMIT>(f, c), c, d_id(f.ret));
                 e.ins(f, I_Return, 0, fin.var);
                 close_slot(f, e);
-                if (!EMIT) f.st[i] |= ST_DIV;
+                if (!EMIT) set_div(f, i);
                 return true;
             }
             case S_If: case S_While: case S_For: { if (!has_class<C>(KC_CONTROL)) return true;
@@ -863,7 +870,7 @@ template <bool EMIT, int C> __device__ __forceinline__ bool visit(Fn& f, uint32_
                     if (kind == S_If) div = tdiv && ediv;
                     else if (kind == S_For) div = ediv;
                     else div = ediv || (KIND(f, f.fc[i]) == E_Bool && SUB(f, f.fc[i]) && !(f.st[i] & ST_HASBREAK));
-                    if (div) f.st[i] |= ST_DIV;
+                    if (div) set_div(f, i);
                 }
                 return true;
             }
