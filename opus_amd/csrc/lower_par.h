@@ -678,6 +678,23 @@ template <class F> __device__ __forceinline__ void blocks_of(const F& f, uint32_
     if (KIND(f, s) == S_For && SUB(f, s)) c = f.nx[c];
     *cond = c; *then_b = f.nx[c]; *else_b = f.nx[*then_b];
 }
+// Who waits for node i in the schedule of the count pass: its parent — except that an `if` / `while` / `for` does not wait for its
+// blocks (all it took from them was whether they diverge, which k_flat_pre knows from the structure); they report to the nearest
+// enclosing block or the function instead, so that the function is still lowered behind everything in it (its epilogue looks at
+// the last thing emitted).  The rounds of the count pass are then as deep as the expressions, not as the nesting of the statements.
+template <class F> __device__ __forceinline__ uint32_t wait_target(const F& f, uint32_t i) {
+    uint32_t p = f.pa[i];
+    if (p == NONE16) return NONE16;
+    const uint8_t pk = KIND(f, p);
+    if (pk == S_If || pk == S_While || pk == S_For) {
+        uint32_t cond, tb, eb; blocks_of(f, p, &cond, &tb, &eb);
+        if (i != cond && (i == tb || i == eb)) {
+            uint32_t guard = 0;
+            do { p = f.pa[p]; guard++; } while (p != NONE16 && KIND(f, p) != X_Block && KIND(f, p) != D_Function && guard < 4096);
+        }
+    }
+    return p;
+}
 // block ids of a loop (emit pass)
 __device__ __forceinline__ uint32_t loop_start_bb(const Fn& f, uint32_t loop) {
     if (KIND(f, loop) == S_While) return bb_at(f, POS_ENTER(f, loop));
@@ -705,13 +722,6 @@ __device__ __forceinline__ Desc for_variable_type(Fn& f, uint32_t i) {
     return d_id(fn_arg_type(f, cf, 1));
 }
 
-// Node i diverges (every path through it returns).  A block diverges if one of its statements does: the statement leaves a mark in the
-// block's ref word, which a block has no other use for (every writer stores the same value, so plain stores do).
-__device__ __forceinline__ void set_div(Fn& f, uint32_t i) {
-    f.st[i] |= ST_DIV;
-    const uint32_t p = f.pa[i];
-    if (p != NONE16 && KIND(f, p) == X_Block) f.ref[p] = 1u;
-}
 // Lowers node i: all events it owns.  Returns false when an input is not ready yet (count pass only).
 template <int C> __device__ __forceinline__ constexpr bool has_class(int c) { return C == KC_ANY || C == c; }
 template <bool EMIT, int C> __device__ __forceinline__ bool visit(Fn& f, uint32_t i) {
@@ -746,10 +756,7 @@ template <bool EMIT, int C> __device__ __forceinline__ bool visit(Fn& f, uint32_
                 return true;
             }
             case X_Block: { if (!has_class<C>(KC_CONTROL)) return true;
-                // diverges if one of its statements does: the statement said so in this node's ref word (set_div) — walking the
-                // statements here is a chain of dependent loads as long as the block, and was what every late round waited for
-                if (!EMIT && f.ref[i]) set_div(f, i);
-                return true;
+                return true;       // (whether it diverges is structural: k_flat_pre left ST_DIV in the state word)
             }
             case S_Expression: return true;
             case S_VariableDefinition: { if (!has_class<C>(KC_STATEMENT)) return true;   // :252-264
@@ -782,7 +789,6 @@ template <bool EMIT, int C> __device__ __forceinline__ bool visit(Fn& f, uint32_
                 Val<EMIT> fin = autocast<EMIT>(f, e, child_val<EMIT>(f, c), c, d_id(f.ret));
                 e.ins(f, I_Return, 0, fin.var);
                 close_slot(f, e);
-                if (!EMIT) set_div(f, i);
                 return true;
             }
             case S_If: case S_While: case S_For: { if (!has_class<C>(KC_CONTROL)) return true;
@@ -863,14 +869,6 @@ template <bool EMIT, int C> __device__ __forceinline__ bool visit(Fn& f, uint32_
                     e3.ins(f, I_Jump, 0, 0, 0, merge);
                     e3.newbb(f);
                     close_slot(f, e3);
-                }
-                if (!EMIT) {
-                    const bool tdiv = (f.st[tb] & ST_DIV) != 0, ediv = eb != NONE16 && (f.st[eb] & ST_DIV) != 0;
-                    bool div;
-                    if (kind == S_If) div = tdiv && ediv;
-                    else if (kind == S_For) div = ediv;
-                    else div = ediv || (KIND(f, f.fc[i]) == E_Bool && SUB(f, f.fc[i]) && !(f.st[i] & ST_HASBREAK));
-                    if (div) set_div(f, i);
                 }
                 return true;
             }
@@ -1921,8 +1919,35 @@ __device__ __forceinline__ void pre_function(Pre& f, const FlatArgs& X) {
     // every node counts the operands it has to wait for (in its own state word): each node that will be lowered adds one to its
     // parent; an integer literal that takes its type from the left side of its assignment waits for that
     for (uint32_t i = tid; i < nn; i += T) {
-        if (!(f.st[i] & (ST_DONE | ST_DEAD)) && f.pa[i] != NONE16) lds_add(&f.st[f.pa[i]], (uint32_t)ST_PEND_ONE);
+        if (!(f.st[i] & (ST_DONE | ST_DEAD))) { const uint32_t w = wait_target(f, i); if (w != NONE16) lds_add(&f.st[w], (uint32_t)ST_PEND_ONE); }
         if (literal_waits_for_lhs(f, i)) lds_add(&f.st[i], (uint32_t)ST_PEND_ONE);
+    }
+    // Which statements diverge (every path through them returns, generate_ir.rs:275-283, 284-462): structural.  Every source — a
+    // `return`, a `while true` without `break` — climbs: a block diverges with any of its statements, an `if` when both branches do,
+    // a `for` / `while` when its else branch does.  (A climber stops at a node that already diverges: whoever marked it went on.)
+    for (uint32_t i = tid; i < nn; i += T) {
+        const uint8_t k = KIND(f, i);
+        bool source = k == S_Return;
+        if (k == S_While) { const uint32_t c = f.fc[i]; source = c != NONE16 && KIND(f, c) == E_Bool && SUB(f, c) && !(f.st[i] & ST_HASBREAK); }
+        if (!source) continue;
+        uint32_t c = i;
+        for (uint32_t guard = 0; guard <= nn; guard++) {
+            if (lds_or(&f.st[c], (uint32_t)ST_DIV) & ST_DIV) break;
+            const uint32_t p = f.pa[c];
+            if (p == NONE16) break;
+            const uint8_t pk = KIND(f, p);
+            if (pk == X_Block) { c = p; continue; }
+            if (pk != S_If && pk != S_While && pk != S_For) break;
+            uint32_t cond, tb, eb; blocks_of(f, p, &cond, &tb, &eb);
+            bool up = false;
+            if (pk == S_If) {
+                const uint32_t other = c == tb ? eb : c == eb ? tb : (uint32_t)NONE16;
+                par_fence();                                  // (this branch is marked before the other one is looked at: of two climbers that meet here, one sees both)
+                up = other != NONE16 && (lds_or(&f.st[other], 0u) & ST_DIV);
+            } else up = c == eb && c != NONE16;
+            if (!up) break;
+            c = p;
+        }
     }
     PAR_SYNC();
 #ifdef OPUSFE_DIAG
@@ -1967,7 +1992,7 @@ __device__ __forceinline__ void pre_function(Pre& f, const FlatArgs& X) {
                     f.rk[i] = (uint16_t)r;
                     lds_or(&f.st[i], (uint32_t)ST_DONE);
                     if (KIND(f, i) == S_VariableDefinition) release_waiters(f.ref[i], r + 1);
-                    const uint32_t p = f.pa[i];
+                    const uint32_t p = wait_target(f, i);
                     if (p == NONE16) break;
                     const uint8_t pk = KIND(f, p);
                     if (pk == S_Assignment && f.fc[p] == i) {            // the left side: an integer literal on the right takes its type from it
