@@ -1423,25 +1423,35 @@ template <int C> __global__ FLAT_ATTR __launch_bounds__(256) void k_flat_count(S
     const uint32_t* in = X.sched + begin;
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) count_one<C>(S, A, X, in[k]);
 }
+// One round of the schedule, every class: the round's eight bins seen as ONE list, so that a lane lowers one node of the round whatever
+// its class (bin after bin, every lane paid the latency of eight visits one after the other: 130-180 us per round however few its nodes).
+__device__ __forceinline__ void count_round_nodes(const SemView& S, const ParArgs& A, const FlatArgs& X, uint32_t round, uint64_t first, uint64_t stride) {
+    uint32_t begin[KC_ACTIVE], upto[KC_ACTIVE + 1];
+    upto[0] = 0;
+#pragma unroll
+    for (uint32_t c = 0; c < KC_ACTIVE; c++) {
+        begin[c] = X.ctl[CTL_BINS + c * SCHED_R + round];
+        upto[c + 1] = upto[c] + (X.ctl[CTL_BINS + c * SCHED_R + round + 1] - begin[c]);
+    }
+    for (uint64_t j = first; j < upto[KC_ACTIVE]; j += stride) {
+        uint32_t at = 0;
+        bool found = false;
+#pragma unroll
+        for (uint32_t c = 0; c < KC_ACTIVE; c++) if (!found && j < upto[c + 1]) { at = begin[c] + ((uint32_t)j - upto[c]); found = true; }
+        count_one<KC_ANY>(S, A, X, X.sched[at]);
+    }
+}
 // The tail of the schedule — rounds [r0, r1) with few nodes each — in ONE launch of ONE workgroup: a barrier between two rounds instead
 // of a kernel boundary (what a round writes leaves through this CU's L1; the workgroup-scope barrier orders it for the CU's other waves).
 __global__ __launch_bounds__(512) void k_flat_count_tail(SemView S, ParArgs A, FlatArgs X, uint32_t r0, uint32_t r1) {
     for (uint32_t round = r0; round < r1; round++) {
-        for (uint32_t c = 0; c < KC_ACTIVE; c++) {
-            const uint32_t begin = X.ctl[CTL_BINS + c * SCHED_R + round], n = X.ctl[CTL_BINS + c * SCHED_R + round + 1] - begin;
-            const uint32_t* in = X.sched + begin;
-            for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) count_one<KC_ANY>(S, A, X, in[k]);
-        }
+        count_round_nodes(S, A, X, round, threadIdx.x, blockDim.x);
         PAR_SYNC();
     }
 }
-// a whole round with few nodes in one launch: the round's bin of every class
+// a whole round with few nodes in one launch
 __global__ __launch_bounds__(256) void k_flat_count_round(SemView S, ParArgs A, FlatArgs X, uint32_t round) {
-    for (uint32_t c = 0; c < KC_ACTIVE; c++) {
-        const uint32_t begin = X.ctl[CTL_BINS + c * SCHED_R + round], n = X.ctl[CTL_BINS + c * SCHED_R + round + 1] - begin;
-        const uint32_t* in = X.sched + begin;
-        for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) count_one<KC_ANY>(S, A, X, in[k]);
-    }
+    count_round_nodes(S, A, X, round, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, (uint64_t)gridDim.x * blockDim.x);
 }
 
 // ---- scan: one wave per function ------------------------------------------------------------------------------------------
