@@ -1870,11 +1870,13 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
             HIP_TRY(hipGetLastError());
             prof_end(ctx);
             HIP_TRY(hipMemsetAsync(X.tail, 0, (size_t)n_nodes * 2, st));      // (the bins travelled in the tail bytes)
+#ifdef OPUSFE_DIAG
             auto count_class = [&](auto cls, uint32_t r) {
                 constexpr int c = decltype(cls)::value;
                 const uint32_t begin = off[c * par::SCHED_R + r], n = off[c * par::SCHED_R + r + 1] - begin;
                 if (n) hipLaunchKernelGGL(par::k_flat_count<c>, dim3(std::min<unsigned>(grid_for(n, 256), 4096u)), dim3(256), 0, st, S, PA, X, begin, n);
             };
+#endif
             auto round_nodes = [&](uint32_t r) { uint64_t n = 0; for (uint32_t c = 0; c < par::KC_ACTIVE; c++) n += off[c * par::SCHED_R + r + 1] - off[c * par::SCHED_R + r]; return n; };
             // (every function's rounds start at 0: the first empty round ends them all); the tail = the rounds from which on none has more than 2048 nodes
             uint32_t rounds_run = 0, tail_from = 0;
@@ -1883,15 +1885,19 @@ inline void run_lower(opusfe_ctx* ctx, opusfe_unit* u) {
             for (uint32_t r = 0; r < rounds_run; r++) {
                 const uint64_t n_round = round_nodes(r);
                 if (r >= tail_from && rounds_run - r >= 2) { hipLaunchKernelGGL(par::k_flat_count_tail, dim3(1), dim3(512), 0, st, S, PA, X, r, rounds_run); break; }
+                // every round is ONE launch of the visitor for all kinds over the round's bins taken as one list (count_round_nodes).  One
+                // launch per kind class and round — specialised kernels, fewer registers — was the plan of the first flat version and
+                // is slower since the bins are one list: 33.7 ms with the rounds above 4 M nodes per class, 32.3 with none.
 #ifdef OPUSFE_DIAG
-                static const uint64_t round_nodes_max = getenv("OPUSFE_FLAT_ROUND_NODES") ? (uint64_t)atoll(getenv("OPUSFE_FLAT_ROUND_NODES")) : (1u << 22);
-#else
-                constexpr uint64_t round_nodes_max = 1u << 22;      // (measured: 38.9 ms at 64 K, 37.8 at 4 M: the classes of a round overlap inside one launch)
+                static const uint64_t round_nodes_max = getenv("OPUSFE_FLAT_ROUND_NODES") ? (uint64_t)atoll(getenv("OPUSFE_FLAT_ROUND_NODES")) : ~0ull;
+                if (n_round > round_nodes_max) {
+                    count_class(std::integral_constant<int, 0>(), r); count_class(std::integral_constant<int, 1>(), r); count_class(std::integral_constant<int, 2>(), r);
+                    count_class(std::integral_constant<int, 3>(), r); count_class(std::integral_constant<int, 4>(), r); count_class(std::integral_constant<int, 5>(), r);
+                    count_class(std::integral_constant<int, 6>(), r); count_class(std::integral_constant<int, 7>(), r);
+                    continue;
+                }
 #endif
-                if (n_round <= round_nodes_max) { hipLaunchKernelGGL(par::k_flat_count_round, dim3(std::min<unsigned>(grid_for(n_round, 256), 4096u)), dim3(256), 0, st, S, PA, X, r); continue; }
-                count_class(std::integral_constant<int, 0>(), r); count_class(std::integral_constant<int, 1>(), r); count_class(std::integral_constant<int, 2>(), r);
-                count_class(std::integral_constant<int, 3>(), r); count_class(std::integral_constant<int, 4>(), r); count_class(std::integral_constant<int, 5>(), r);
-                count_class(std::integral_constant<int, 6>(), r); count_class(std::integral_constant<int, 7>(), r);
+                hipLaunchKernelGGL(par::k_flat_count_round, dim3(std::min<unsigned>(grid_for(n_round, 256), 4096u)), dim3(256), 0, st, S, PA, X, r);
             }
             HIP_TRY(hipGetLastError());
             prof_end(ctx);

@@ -1591,7 +1591,8 @@ template <int C> __global__ FLAT_ATTR __launch_bounds__(256) void k_flat_emit(Se
 // (All classes in ONE launch, the blocks dealt to the classes in proportion to their node counts so that they walk the node-ordered lists at
 // the same relative pace and share what they fetch, was measured: 35.3 ms against 26.0 for the eight launches — the kernel then has the
 // registers and the code of its largest class.  One launch over ALL nodes in node order, one lane per node with the whole visitor —
-// neighbouring lanes on neighbouring records, no list — was measured too: 63 ms.  The pass is bound by divergence, not by what it fetches.)
+// neighbouring lanes on neighbouring records, no list — was measured too: 63 ms; the class-sorted lists as one list under one
+// visitor for all kinds (what the count pass does per round): 27.7 ms.  The pass is bound by divergence, not by what it fetches.)
 
 // ======================================================================================================================
 // k_flat_pre: what is local to a function by nature (one workgroup per function, one lane per node, state in LDS)
