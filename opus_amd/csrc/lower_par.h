@@ -12,16 +12,16 @@
 //                 defining block) — no scope stack is walked (generate_ir.rs:176-185, 857-893); the kind class of every node and
 //                 what it WAITS for: its operands, the `var` / `for` definition it reads, the left side of its assignment.
 //                 Everything a later pass reads is written to the unit-wide per-node arrays (FlatArgs).
-//   k_flat_count  (one lane per READY node, one launch per kind class and round) lowering a node = running its slice of the
-//                 reference's emission schema against an emitter that only COUNTS variables, types,
-//                 instructions and basic blocks per EVENT (the points of the Euler tour of the tree: ENTER(node), EXIT(node)).
-//                 A finished node releases who waits for it (atomic counters in the state words); what becomes ready is
-//                 appended to the next round's list of its class.  Rounds = the longest dependency chain of any function.
+//   k_flat_count  (one lane per READY node, one launch per round of the schedule that k_flat_pre computed) lowering a node =
+//                 running its slice of the reference's emission schema against an emitter that only COUNTS
+//                 variables, types, instructions and basic blocks per EVENT (the points of the Euler tour of the tree: ENTER(node),
+//                 EXIT(node)).  The schedule is static: a counting sort of (class, round) bins, no atomic and no queue between
+//                 rounds; a round's bins are gone through as one list.  Rounds = the longest dependency chain of any function.
 //   k_flat_scan   (one wave per function) exclusive scan of the counts in Euler order: variable ids, block ids, instruction
 //                 slots.  Two facts make this the final layout: (1) the current block is always the newest block, so emission
 //                 order IS block-major order; (2) every deferred terminator (`bbs[branch].push(..)`, :310-312, 357-359) goes to a
-//                 block at the moment that block stops being current.  The function takes its place in the dense result
-//                 arrays with one atomic per array.
+//                 block at the moment that block stops being current.  A device-wide scan over the functions then gives every
+//                 function its place in the dense result arrays, in definition order.
 //   k_flat_rv     (one lane per node) every node learns the id of the variable that holds its result.
 //   k_flat_emit   (one lane per node, one launch per kind class) the same visitor again, writing variables / instructions /
 //                 types at the scanned positions, straight into the dense result arrays.
